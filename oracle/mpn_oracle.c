@@ -1,0 +1,443 @@
+/*
+ * oracle/mpn_oracle.c -- TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement (plain C, scalar, single thread) of the hot path of
+ * NVlabs/motion-policy-networks.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load this library, and only as the checker.  The product
+ * (motion-policy-networks_amd/) never links, imports or calls anything in oracle/.
+ *
+ * Pinning status (see DESIGN.md "Oracle"):
+ *   - orc_*_frames / orc_*_sdf: PINNED against golden vectors generated in the build
+ *     container by importing the reference's own mpinets/geometry.py
+ *     (tests/golden/gen_geometry_golden.py -> tests/golden/geometry_*.npz).
+ *   - orc_fps / orc_ball_query / orc_group_points / orc_gather_points: restate the
+ *     published algorithm of pointnet2_ops v3.2.0 (github.com/fishbotics/pointnet2_ops,
+ *     pinned at /root/reference/docker/Dockerfile:152; call sites
+ *     /root/reference/mpinets/model.py:27,366-383).  The dependency is absent from
+ *     /root/reference and CUDA-only: PARITY UNPINNED.
+ *   - orc_franka_*: restates robofin v0.0.1's batched URDF FK (Dockerfile:153; call sites
+ *     mpinets/model.py:250,267-271,300) from the public Franka Panda URDF constants:
+ *     PARITY UNPINNED.
+ *
+ * Floating point: every function evaluates in IEEE binary32 with the operation order
+ * written here; fused multiply-adds appear only where fmaf() is written (build with
+ * -ffp-contract=off).  The HIP kernels follow the same order, so index outputs can be
+ * compared bit-for-bit and float outputs to ~1 ulp.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------------------------
+ * Primitive inverse frames.  Reference: mpinets/geometry.py:151 (quaternion normalisation),
+ * :177-223 (TorchCuboids._init_frames), :409-454 (TorchCylinders._init_frames).
+ * The matrix is reproduced AS WRITTEN in the reference, including `yz - wx` in both R[1][2]
+ * and R[2][1] (geometry.py:212-213, :443-444).
+ * frames: n x 12 floats = R (row-major 3x3) followed by Rt (3).
+ * ---------------------------------------------------------------------------------------- */
+ORC_API void orc_prim_frames(const float *centers, const float *quats, int n, float *frames) {
+  for (int i = 0; i < n; ++i) {
+    const float *q = quats + 4 * i;
+    const float *c = centers + 3 * i;
+    float nrm = sqrtf(fmaf(q[3], q[3], fmaf(q[2], q[2], fmaf(q[1], q[1], q[0] * q[0]))));
+    float w = q[0] / nrm;
+    float x = -(q[1] / nrm);
+    float y = -(q[2] / nrm);
+    float z = -(q[3] / nrm);
+    float xx = 2.0f * (x * x), yy = 2.0f * (y * y), zz = 2.0f * (z * z);
+    float wx = (2.0f * w) * x, wy = (2.0f * w) * y, wz = (2.0f * w) * z;
+    float xy = (2.0f * x) * y, xz = (2.0f * x) * z, yz = (2.0f * y) * z;
+    float R[9];
+    R[0] = (1.0f - yy) - zz; R[1] = xy - wz;          R[2] = xz + wy;
+    R[3] = xy + wz;          R[4] = (1.0f - xx) - zz; R[5] = yz - wx;
+    R[6] = xz - wy;          R[7] = yz - wx;          R[8] = (1.0f - xx) - yy;
+    float *f = frames + 12 * i;
+    for (int k = 0; k < 9; ++k) f[k] = R[k];
+    for (int r = 0; r < 3; ++r) {
+      float acc = R[3 * r + 0] * (-c[0]);
+      acc = fmaf(R[3 * r + 1], -c[1], acc);
+      acc = fmaf(R[3 * r + 2], -c[2], acc);
+      f[9 + r] = acc;
+    }
+  }
+}
+
+/* torch.isclose(x, 0) with default rtol=1e-5, atol=1e-8  ->  |x| <= 1e-8
+ * (geometry.py:56, :155-157, :385-388).  Comparison done in float like torch does for
+ * float32 tensors: |x| <= (float)1e-8.                                                   */
+static int is_zero(float x) { return fabsf(x) <= 1e-8f; }
+
+static void project(const float *f, const float *p, float *o) {
+  for (int r = 0; r < 3; ++r) {
+    float acc = f[3 * r + 0] * p[0];
+    acc = fmaf(f[3 * r + 1], p[1], acc);
+    acc = fmaf(f[3 * r + 2], p[2], acc);
+    o[r] = acc + f[9 + r];
+  }
+}
+
+/* geometry.py:276-287 (one cuboid, one projected point) */
+static float cuboid_sdf1(const float *p, const float *dims) {
+  float d0 = fabsf(p[0]) - dims[0] / 2.0f;
+  float d1 = fabsf(p[1]) - dims[1] / 2.0f;
+  float d2 = fabsf(p[2]) - dims[2] / 2.0f;
+  float m0 = fmaxf(d0, 0.0f), m1 = fmaxf(d1, 0.0f), m2 = fmaxf(d2, 0.0f);
+  float outside = sqrtf(fmaf(m2, m2, fmaf(m1, m1, m0 * m0)));
+  float inside = fminf(fmaxf(d0, fmaxf(d1, d2)), 0.0f);
+  return outside + inside;
+}
+
+/* geometry.py:486-506 (one cylinder, one projected point) */
+static float cylinder_sdf1(const float *p, float radius, float height) {
+  float rho = sqrtf(fmaf(p[1], p[1], p[0] * p[0]));
+  float d0 = fabsf(rho) - radius;
+  float d1 = fabsf(p[2]) - height / 2.0f;
+  float m0 = fmaxf(d0, 0.0f), m1 = fmaxf(d1, 0.0f);
+  float outside = sqrtf(fmaf(m1, m1, m0 * m0));
+  float inside = fminf(fmaxf(d0, d1), 0.0f);
+  return outside + inside;
+}
+
+/* TorchCuboids.sdf / sdf_sequence (geometry.py:238-288, :290-347).
+ * points [B,P,3] (P = N, or T*N flattened for sdf_sequence), out [B,P].
+ * Masked (zero-volume) cuboids contribute +inf; all masked -> +inf (geometry.py:251-254). */
+ORC_API void orc_cuboid_sdf(int B, int M, int P, const float *centers, const float *dims,
+                            const float *quats, const float *points, float *out) {
+  float *frames = (float *)malloc(sizeof(float) * 12 * (size_t)(B * M > 0 ? B * M : 1));
+  orc_prim_frames(centers, quats, B * M, frames);
+  for (int b = 0; b < B; ++b)
+    for (int n = 0; n < P; ++n) {
+      const float *p = points + ((size_t)b * P + n) * 3;
+      float best = INFINITY;
+      for (int m = 0; m < M; ++m) {
+        const float *d = dims + ((size_t)b * M + m) * 3;
+        if (is_zero(d[0]) || is_zero(d[1]) || is_zero(d[2])) continue;
+        float q[3];
+        project(frames + ((size_t)b * M + m) * 12, p, q);
+        float s = cuboid_sdf1(q, d);
+        best = s < best ? s : best;  /* torch.min: NaN not considered here */
+      }
+      out[(size_t)b * P + n] = best;
+    }
+  free(frames);
+}
+
+/* TorchCylinders.sdf / sdf_sequence (geometry.py:456-507, :509-568). */
+ORC_API void orc_cylinder_sdf(int B, int M, int P, const float *centers, const float *radii,
+                              const float *heights, const float *quats, const float *points,
+                              float *out) {
+  float *frames = (float *)malloc(sizeof(float) * 12 * (size_t)(B * M > 0 ? B * M : 1));
+  orc_prim_frames(centers, quats, B * M, frames);
+  for (int b = 0; b < B; ++b)
+    for (int n = 0; n < P; ++n) {
+      const float *p = points + ((size_t)b * P + n) * 3;
+      float best = INFINITY;
+      for (int m = 0; m < M; ++m) {
+        float r = radii[(size_t)b * M + m], h = heights[(size_t)b * M + m];
+        if (is_zero(r) || is_zero(h)) continue;
+        float q[3];
+        project(frames + ((size_t)b * M + m) * 12, p, q);
+        float s = cylinder_sdf1(q, r, h);
+        best = s < best ? s : best;
+      }
+      out[(size_t)b * P + n] = best;
+    }
+  free(frames);
+}
+
+/* TorchSpheres.sdf / sdf_sequence (geometry.py:87-123). */
+ORC_API void orc_sphere_sdf(int B, int M, int P, const float *centers, const float *radii,
+                            const float *points, float *out) {
+  for (int b = 0; b < B; ++b)
+    for (int n = 0; n < P; ++n) {
+      const float *p = points + ((size_t)b * P + n) * 3;
+      float best = INFINITY;
+      for (int m = 0; m < M; ++m) {
+        float r = radii[(size_t)b * M + m];
+        if (is_zero(r)) continue;
+        const float *c = centers + ((size_t)b * M + m) * 3;
+        float dx = p[0] - c[0], dy = p[1] - c[1], dz = p[2] - c[2];
+        float s = sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx))) - r;
+        best = s < best ? s : best;
+      }
+      out[(size_t)b * P + n] = best;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Franka forward kinematics (robofin v0.0.1 restated from the public URDF; PARITY UNPINNED).
+ * Frames (15): link0..link8, hand, leftfinger, rightfinger, leftfingertip, rightfingertip,
+ * right_gripper.  Output T[B][15][12]: R row-major 3x3 then t.
+ * ---------------------------------------------------------------------------------------- */
+
+/* sin/cos with a fixed evaluation order so that the GPU kernel can reproduce them
+ * bit-for-bit: Cody-Waite reduction by pi/2 (two constants) + degree-9/10 polynomials.      */
+static void orc_sincosf(float x, float *s_out, float *c_out) {
+  const float TWO_OVER_PI = 0.63661977236758134308f;
+  const float PIO2_HI = 1.57079625129699707031f;      /* 0x3fc90fda */
+  const float PIO2_LO = 7.54978941586159635335e-08f;  /* pi/2 - PIO2_HI */
+  float kf = rintf(x * TWO_OVER_PI);
+  float r = fmaf(-kf, PIO2_HI, x);
+  r = fmaf(-kf, PIO2_LO, r);
+  float r2 = r * r;
+  float ps = fmaf(r2, 2.7557314297e-06f, -1.9841270114e-04f);
+  ps = fmaf(ps, r2, 8.3333337680e-03f);
+  ps = fmaf(ps, r2, -1.6666667163e-01f);
+  float sn = fmaf(r * r2, ps, r);
+  float pc = fmaf(r2, -2.7557314297e-07f, 2.4801587642e-05f);
+  pc = fmaf(pc, r2, -1.3888889225e-03f);
+  pc = fmaf(pc, r2, 4.1666667908e-02f);
+  pc = fmaf(pc, r2, -0.5f);
+  float cs = fmaf(pc, r2, 1.0f);
+  int k = (int)kf & 3;
+  float s = (k & 1) ? cs : sn;
+  float c = (k & 1) ? sn : cs;
+  if (k == 1 || k == 2) c = -c;
+  if (k >= 2) s = -s;
+  *s_out = s;
+  *c_out = c;
+}
+
+ORC_API void orc_sincos(const float *x, int n, float *s, float *c) {
+  for (int i = 0; i < n; ++i) orc_sincosf(x[i], s + i, c + i);
+}
+
+/* out = a o f  (3x4 rigid composition), fixed fma order */
+static void compose(const float *a, const float *f, float *o) {
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c) {
+      float acc = a[3 * r + 0] * f[0 + c];
+      acc = fmaf(a[3 * r + 1], f[3 + c], acc);
+      acc = fmaf(a[3 * r + 2], f[6 + c], acc);
+      o[3 * r + c] = acc;
+    }
+    float acc = a[9 + r];
+    acc = fmaf(a[3 * r + 0], f[9], acc);
+    acc = fmaf(a[3 * r + 1], f[10], acc);
+    acc = fmaf(a[3 * r + 2], f[11], acc);
+    o[9 + r] = acc;
+  }
+}
+
+/* o = p with its rotation post-multiplied by Rz(theta) */
+static void rotz(const float *p, float s, float c, float *o) {
+  for (int r = 0; r < 3; ++r) {
+    float a = p[3 * r + 0], b = p[3 * r + 1];
+    o[3 * r + 0] = fmaf(b, s, a * c);
+    o[3 * r + 1] = fmaf(b, c, -(a * s));
+    o[3 * r + 2] = p[3 * r + 2];
+    o[9 + r] = p[9 + r];
+  }
+}
+
+#define SQRT_HALF 0.70710678118654752440f
+#define RX_NEG /* Rx(-pi/2) */ {1, 0, 0, 0, 0, 1, 0, -1, 0}
+#define RX_POS /* Rx(+pi/2) */ {1, 0, 0, 0, 0, -1, 0, 1, 0}
+
+ORC_API void orc_franka_fk(const float *q, int B, float finger, float *T) {
+  /* joint origins of the Franka Panda URDF: {R(9), t(3)} */
+  static const float J[7][12] = {
+      {1, 0, 0, 0, 1, 0, 0, 0, 1, 0.0f, 0.0f, 0.333f},
+      {1, 0, 0, 0, 0, 1, 0, -1, 0, 0.0f, 0.0f, 0.0f},
+      {1, 0, 0, 0, 0, -1, 0, 1, 0, 0.0f, -0.316f, 0.0f},
+      {1, 0, 0, 0, 0, -1, 0, 1, 0, 0.0825f, 0.0f, 0.0f},
+      {1, 0, 0, 0, 0, 1, 0, -1, 0, -0.0825f, 0.384f, 0.0f},
+      {1, 0, 0, 0, 0, -1, 0, 1, 0, 0.0f, 0.0f, 0.0f},
+      {1, 0, 0, 0, 0, -1, 0, 1, 0, 0.088f, 0.0f, 0.0f},
+  };
+  static const float F_LINK8[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0.0f, 0.0f, 0.107f};
+  static const float F_HAND[12] = {SQRT_HALF, SQRT_HALF, 0, -SQRT_HALF, SQRT_HALF, 0, 0, 0, 1, 0, 0, 0};
+  static const float F_TIP[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0.0f, 0.0f, 0.045f};
+  static const float F_GRIP[12] = {-SQRT_HALF, -SQRT_HALF, 0, SQRT_HALF, -SQRT_HALF, 0, 0, 0, 1, 0.0f, 0.0f, 0.1f};
+  for (int b = 0; b < B; ++b) {
+    float *out = T + (size_t)b * 15 * 12;
+    float cur[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0};
+    memcpy(out, cur, sizeof(cur));
+    for (int j = 0; j < 7; ++j) {
+      float tmp[12], s, c;
+      compose(cur, J[j], tmp);
+      orc_sincosf(q[(size_t)b * 7 + j], &s, &c);
+      rotz(tmp, s, c, cur);
+      memcpy(out + 12 * (j + 1), cur, sizeof(cur));
+    }
+    float *l8 = out + 12 * 8, *hand = out + 12 * 9;
+    compose(cur, F_LINK8, l8);
+    compose(l8, F_HAND, hand);
+    float fl[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0.0f, finger, 0.0584f};
+    float fr[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0.0f, -finger, 0.0584f};
+    compose(hand, fl, out + 12 * 10);
+    compose(hand, fr, out + 12 * 11);
+    compose(out + 12 * 10, F_TIP, out + 12 * 12);
+    compose(out + 12 * 11, F_TIP, out + 12 * 13);
+    compose(l8, F_GRIP, out + 12 * 14);
+  }
+}
+
+/* rigidly move table points by their link frame: out[b,j] = T[b,link[src]] * p[src],
+ * src = subset ? subset[j] : j.  Restates FrankaSampler.sample.        */
+ORC_API void orc_transform_table(const float *T, int B, int n_frames, const float *pts,
+                                 const int32_t *link, const int32_t *subset, int n_out,
+                                 float *out) {
+  for (int b = 0; b < B; ++b)
+    for (int j = 0; j < n_out; ++j) {
+      int src = subset ? subset[j] : j;
+      const float *f = T + ((size_t)b * n_frames + link[src]) * 12;
+      const float *p = pts + 3 * (size_t)src;
+      float *o = out + ((size_t)b * n_out + j) * 3;
+      for (int r = 0; r < 3; ++r) {
+        float acc = f[3 * r + 0] * p[0];
+        acc = fmaf(f[3 * r + 1], p[1], acc);
+        acc = fmaf(f[3 * r + 2], p[2], acc);
+        o[r] = acc + f[9 + r];
+      }
+    }
+}
+
+/* Swept-sphere collision reduce, mpinets/model.py:293-314:
+ *   has_collision[b] = any_{t,s} ( min(cuboid_sdf, cylinder_sdf)(sphere centre) <= radius_s )
+ * centres [B,T,S,3]; min_sdf (optional) [B,T,S].                                          */
+ORC_API void orc_collision_flags(int B, int T, int S, const float *centres, const float *radii,
+                                 int M1, const float *cc, const float *cd, const float *cq,
+                                 int M2, const float *yc, const float *yr, const float *yh,
+                                 const float *yq, uint8_t *flags, float *min_sdf) {
+  int P = T * S;
+  float *a = (float *)malloc(sizeof(float) * (size_t)B * P);
+  float *c = (float *)malloc(sizeof(float) * (size_t)B * P);
+  orc_cuboid_sdf(B, M1, P, cc, cd, cq, centres, a);
+  orc_cylinder_sdf(B, M2, P, yc, yr, yh, yq, centres, c);
+  for (int b = 0; b < B; ++b) {
+    uint8_t f = 0;
+    for (int i = 0; i < P; ++i) {
+      float s = fminf(a[(size_t)b * P + i], c[(size_t)b * P + i]);
+      if (min_sdf) min_sdf[(size_t)b * P + i] = s;
+      if (s <= radii[i % S]) f = 1;
+    }
+    flags[b] = f;
+  }
+  free(a);
+  free(c);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * pointnet2_ops v3.2.0 restated (PARITY UNPINNED -- see header).
+ * ---------------------------------------------------------------------------------------- */
+
+/* opt_n_threads(): largest power of two <= work_size, clamped to [1, 512] */
+ORC_API int orc_opt_n_threads(int work_size) {
+  int p = 1;
+  while (p * 2 <= work_size && p * 2 <= 512) p *= 2;
+  return p;
+}
+
+static float sqdist(const float *a, const float *b) {
+  float dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
+  /* nvcc contracts a*a + b*b + c*c into fma(c,c,fma(b,b,a*a)) by default (-fmad=true) */
+  return fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+}
+
+/* furthest_point_sampling_kernel: start at index 0; temp = 1e10; points with |p|^2 <= 1e-3
+ * are skipped; each of `bs` threads scans k = tid, tid+bs, ... keeping the first strictly
+ * greater value; shared-memory tree reduce keeps the lower thread id on ties.            */
+ORC_API void orc_fps(const float *xyz, int B, int N, int stride, int npoint, int32_t *idx) {
+  if (npoint <= 0) return;
+  int bs = orc_opt_n_threads(N);
+  float *temp = (float *)malloc(sizeof(float) * (size_t)N);
+  float *tv = (float *)malloc(sizeof(float) * (size_t)bs);
+  int *ti = (int *)malloc(sizeof(int) * (size_t)bs);
+  for (int b = 0; b < B; ++b) {
+    const float *pts = xyz + (size_t)b * N * stride;
+    int32_t *out = idx + (size_t)b * npoint;
+    for (int k = 0; k < N; ++k) temp[k] = 1e10f;
+    int old = 0;
+    out[0] = 0;
+    for (int j = 1; j < npoint; ++j) {
+      const float *p1 = pts + (size_t)old * stride;
+      for (int t = 0; t < bs; ++t) {
+        int besti = 0;
+        float best = -1.0f;
+        for (int k = t; k < N; k += bs) {
+          const float *p2 = pts + (size_t)k * stride;
+          float mag = fmaf(p2[2], p2[2], fmaf(p2[1], p2[1], p2[0] * p2[0]));
+          if (mag <= 1e-3f) continue;
+          float d = sqdist(p2, p1);
+          float d2 = fminf(d, temp[k]);
+          temp[k] = d2;
+          besti = d2 > best ? k : besti;
+          best = d2 > best ? d2 : best;
+        }
+        tv[t] = best;
+        ti[t] = besti;
+      }
+      for (int s = bs / 2; s >= 1; s /= 2)
+        for (int t = 0; t < s; ++t) {
+          float v1 = tv[t], v2 = tv[t + s];
+          int i1 = ti[t], i2 = ti[t + s];
+          tv[t] = v1 > v2 ? v1 : v2;
+          ti[t] = v2 > v1 ? i2 : i1;
+        }
+      old = ti[0];
+      out[j] = old;
+    }
+  }
+  free(temp);
+  free(tv);
+  free(ti);
+}
+
+/* gather_points_kernel, on [B,N,stride] rows: out[b,j,:3] = xyz[b,idx[b,j],:3] */
+ORC_API void orc_gather_points(const float *xyz, int B, int N, int stride, const int32_t *idx,
+                               int npoint, float *out) {
+  for (int b = 0; b < B; ++b)
+    for (int j = 0; j < npoint; ++j)
+      for (int c = 0; c < 3; ++c)
+        out[((size_t)b * npoint + j) * 3 + c] =
+            xyz[((size_t)b * N + idx[(size_t)b * npoint + j]) * stride + c];
+}
+
+/* query_ball_point_kernel: first `nsample` indices k (ascending) with d2 < r*r; all slots
+ * pre-filled with the first hit; output zero-initialised.                                */
+ORC_API void orc_ball_query(const float *new_xyz, const float *xyz, int B, int N, int stride,
+                            int npoint, float radius, int nsample, int32_t *idx) {
+  float r2 = radius * radius;
+  memset(idx, 0, sizeof(int32_t) * (size_t)B * npoint * nsample);
+  for (int b = 0; b < B; ++b)
+    for (int j = 0; j < npoint; ++j) {
+      const float *c = new_xyz + ((size_t)b * npoint + j) * 3;
+      int32_t *o = idx + ((size_t)b * npoint + j) * nsample;
+      int cnt = 0;
+      for (int k = 0; k < N && cnt < nsample; ++k) {
+        const float *p = xyz + ((size_t)b * N + k) * stride;
+        float dx = c[0] - p[0], dy = c[1] - p[1], dz = c[2] - p[2];
+        float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+        if (d2 < r2) {
+          if (cnt == 0)
+            for (int l = 0; l < nsample; ++l) o[l] = k;
+          o[cnt] = k;
+          ++cnt;
+        }
+      }
+    }
+}
+
+/* QueryAndGroup (use_xyz=True): out[b, 0:3, j, l] = xyz[idx] - new_xyz[j];
+ * out[b, 3:3+C, j, l] = feat[b, :, idx].  feat is [B,C,N] (channel-major, like the
+ * reference's features tensor).  out [B,3+C,npoint,nsample].                            */
+ORC_API void orc_group_points(const float *xyz, int stride, const float *new_xyz,
+                              const float *feat, const int32_t *idx, int B, int N, int C,
+                              int npoint, int nsample, float *out) {
+  size_t plane = (size_t)npoint * nsample;
+  for (int b = 0; b < B; ++b)
+    for (int j = 0; j < npoint; ++j)
+      for (int l = 0; l < nsample; ++l) {
+        int k = idx[((size_t)b * npoint + j) * nsample + l];
+        float *o = out + (size_t)b * (3 + C) * plane + (size_t)j * nsample + l;
+        for (int c = 0; c < 3; ++c)
+          o[c * plane] = xyz[((size_t)b * N + k) * stride + c] -
+                         new_xyz[((size_t)b * npoint + j) * 3 + c];
+        for (int c = 0; c < C; ++c)
+          o[(3 + c) * plane] = feat[((size_t)b * C + c) * N + k];
+      }
+}

@@ -1,0 +1,310 @@
+"""oracle/oracle.py -- TEST INFRASTRUCTURE ONLY (numpy/ctypes face of oracle/mpn_oracle.c).
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+this module, and only as the checker.  The product package never imports it.
+
+Two parts:
+
+* thin ctypes wrappers over ``libmpn_oracle.so`` (geometry SDFs pinned to the reference's
+  ``mpinets/geometry.py`` via ``tests/golden``; FK / FPS / ball-query: PARITY UNPINNED, see the
+  header of ``mpn_oracle.c``);
+* a numpy restatement of the policy network (``mpinets/model.py:41-66,355-426`` layer
+  dimensions; ``pointnet2_ops`` ``PointnetSAModule`` semantics [EXT-RECALL, PARITY UNPINNED]):
+  float64 accumulation, float32 storage between layers.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libmpn_oracle.so")
+
+
+def build(force: bool = False) -> str:
+    """Compile the C restatement with gcc (seconds).  Returns the library path."""
+    src = os.path.join(_HERE, "mpn_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libmpn_oracle.so"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        _lib = ctypes.CDLL(_LIB_PATH)
+    return _lib
+
+
+def _f(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _i(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _p(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+# ---------------------------------------------------------------- geometry (pinned)
+def prim_frames(centers, quats) -> np.ndarray:
+    """[...,3],[...,4] -> [...,12] (R row-major 3x3, then Rt).  geometry.py:177-223."""
+    c, q = _f(centers), _f(quats)
+    n = c.size // 3
+    out = np.empty((n, 12), np.float32)
+    lib().orc_prim_frames(_p(c), _p(q), ctypes.c_int(n), _p(out))
+    return out.reshape(c.shape[:-1] + (12,))
+
+
+def inv_frames_4x4(centers, quats) -> np.ndarray:
+    f = prim_frames(centers, quats)
+    out = np.zeros(f.shape[:-1] + (4, 4), np.float32)
+    out[..., :3, :3] = f[..., :9].reshape(f.shape[:-1] + (3, 3))
+    out[..., :3, 3] = f[..., 9:]
+    out[..., 3, 3] = 1
+    return out
+
+
+def _flat_points(points) -> Tuple[np.ndarray, tuple]:
+    p = _f(points)
+    return p.reshape(p.shape[0], -1, 3), p.shape[:-1]
+
+
+def cuboid_sdf(centers, dims, quats, points) -> np.ndarray:
+    """TorchCuboids.sdf / sdf_sequence.  points [B,N,3] or [B,T,N,3]."""
+    c, d, q = _f(centers), _f(dims), _f(quats)
+    p, oshape = _flat_points(points)
+    B, M = c.shape[:2]
+    out = np.empty((B, p.shape[1]), np.float32)
+    lib().orc_cuboid_sdf(B, M, p.shape[1], _p(c), _p(d), _p(q), _p(p), _p(out))
+    return out.reshape(oshape)
+
+
+def cylinder_sdf(centers, radii, heights, quats, points) -> np.ndarray:
+    c, r, h, q = _f(centers), _f(radii), _f(heights), _f(quats)
+    p, oshape = _flat_points(points)
+    B, M = c.shape[:2]
+    out = np.empty((B, p.shape[1]), np.float32)
+    lib().orc_cylinder_sdf(B, M, p.shape[1], _p(c), _p(r), _p(h), _p(q), _p(p), _p(out))
+    return out.reshape(oshape)
+
+
+def sphere_sdf(centers, radii, points) -> np.ndarray:
+    c, r = _f(centers), _f(radii)
+    p, oshape = _flat_points(points)
+    B, M = c.shape[:2]
+    out = np.empty((B, p.shape[1]), np.float32)
+    lib().orc_sphere_sdf(B, M, p.shape[1], _p(c), _p(r), _p(p), _p(out))
+    return out.reshape(oshape)
+
+
+def collision_flags(centres, radii, cub, cyl) -> Tuple[np.ndarray, np.ndarray]:
+    """model.py:293-314.  centres [B,T,S,3]; cub=(c,d,q); cyl=(c,r,h,q) -> (flags[B], min_sdf[B,T,S])."""
+    x = _f(centres)
+    B, T, S = x.shape[:3]
+    rad = _f(radii)
+    cc, cd, cq = map(_f, cub)
+    yc, yr, yh, yq = map(_f, cyl)
+    flags = np.zeros(B, np.uint8)
+    msdf = np.empty((B, T, S), np.float32)
+    lib().orc_collision_flags(B, T, S, _p(x), _p(rad), cc.shape[1], _p(cc), _p(cd), _p(cq),
+                              yc.shape[1], _p(yc), _p(yr), _p(yh), _p(yq), _p(flags), _p(msdf))
+    return flags.astype(bool), msdf
+
+
+# ---------------------------------------------------------------- Franka FK (unpinned)
+def sincos(x) -> Tuple[np.ndarray, np.ndarray]:
+    x = _f(x)
+    s, c = np.empty_like(x), np.empty_like(x)
+    lib().orc_sincos(_p(x), ctypes.c_int(x.size), _p(s), _p(c))
+    return s, c
+
+
+def franka_fk(q, finger: float = 0.025) -> np.ndarray:
+    """q [B,7] -> frames [B,15,12] (R row-major, t)."""
+    q = _f(q).reshape(-1, 7)
+    T = np.empty((q.shape[0], 15, 12), np.float32)
+    lib().orc_franka_fk(_p(q), ctypes.c_int(q.shape[0]), ctypes.c_float(finger), _p(T))
+    return T
+
+
+def transform_table(T, pts, link_ids, subset=None) -> np.ndarray:
+    T = _f(T)
+    pts, link_ids = _f(pts), _i(link_ids)
+    sub = None if subset is None else _i(subset)
+    n_out = len(pts) if sub is None else len(sub)
+    out = np.empty((T.shape[0], n_out, 3), np.float32)
+    lib().orc_transform_table(_p(T), T.shape[0], T.shape[1], _p(pts), _p(link_ids), _p(sub),
+                              n_out, _p(out))
+    return out
+
+
+def frames_to_4x4(T) -> np.ndarray:
+    T = np.asarray(T)
+    out = np.zeros(T.shape[:-1] + (4, 4), np.float32)
+    out[..., :3, :3] = T[..., :9].reshape(T.shape[:-1] + (3, 3))
+    out[..., :3, 3] = T[..., 9:]
+    out[..., 3, 3] = 1
+    return out
+
+
+# ---------------------------------------------------------------- pointnet2_ops (unpinned)
+def opt_n_threads(n: int) -> int:
+    return int(lib().orc_opt_n_threads(ctypes.c_int(n)))
+
+
+def fps(xyz, npoint: int) -> np.ndarray:
+    """xyz [B,N,C>=3] (first 3 columns used) -> int32 [B,npoint]."""
+    x = _f(xyz)
+    B, N, C = x.shape
+    out = np.empty((B, npoint), np.int32)
+    lib().orc_fps(_p(x), B, N, C, npoint, _p(out))
+    return out
+
+
+def gather_points(xyz, idx) -> np.ndarray:
+    x, ix = _f(xyz), _i(idx)
+    B, N, C = x.shape
+    out = np.empty((B, ix.shape[1], 3), np.float32)
+    lib().orc_gather_points(_p(x), B, N, C, _p(ix), ix.shape[1], _p(out))
+    return out
+
+
+def ball_query(new_xyz, xyz, radius: float, nsample: int) -> np.ndarray:
+    nx, x = _f(new_xyz), _f(xyz)
+    B, N, C = x.shape
+    npoint = nx.shape[1]
+    out = np.empty((B, npoint, nsample), np.int32)
+    lib().orc_ball_query(_p(nx), _p(x), B, N, C, npoint, ctypes.c_float(radius), nsample, _p(out))
+    return out
+
+
+def group_points(xyz, new_xyz, feat, idx) -> np.ndarray:
+    """-> [B, 3+C, npoint, nsample]  (xyz - centre first, then features)."""
+    x, nx, ix = _f(xyz), _f(new_xyz), _i(idx)
+    B, N, S = x.shape
+    C = 0 if feat is None else feat.shape[1]
+    ft = None if feat is None else _f(feat)
+    out = np.empty((B, 3 + C, ix.shape[1], ix.shape[2]), np.float32)
+    lib().orc_group_points(_p(x), S, _p(nx), _p(ft), _p(ix), B, N, C, ix.shape[1], ix.shape[2], _p(out))
+    return out
+
+
+# ---------------------------------------------------------------- policy network (numpy)
+def _linear(x, w, b):
+    """float64 accumulate, float32 store."""
+    return (x.astype(np.float64) @ w.astype(np.float64).T + b.astype(np.float64)).astype(np.float32)
+
+
+def _leaky(x, slope=0.01):
+    return np.where(x >= 0, x, x * np.float32(slope)).astype(np.float32)
+
+
+def _group_norm(x, groups, w, b, eps=1e-5):
+    B, C = x.shape
+    xg = x.astype(np.float64).reshape(B, groups, C // groups)
+    mean = xg.mean(axis=2, keepdims=True)
+    var = xg.var(axis=2, keepdims=True)  # biased, like torch
+    y = ((xg - mean) / np.sqrt(var + eps)).reshape(B, C)
+    return (y * w.astype(np.float64) + b.astype(np.float64)).astype(np.float32)
+
+
+def shared_mlp(x, layers: Sequence[Tuple[np.ndarray, np.ndarray]]) -> np.ndarray:
+    """x [..., Cin] -> [..., Cout]; Conv2d 1x1 + ReLU per layer (bn=False)."""
+    for w, b in layers:
+        w2 = w.reshape(w.shape[0], -1)
+        x = np.maximum(_linear(x, w2, b), 0).astype(np.float32)
+    return x
+
+
+def sa_module(xyz, feat, npoint, radius, nsample, layers):
+    """PointnetSAModule.forward.  xyz [B,N,3]; feat [B,C,N] or None.
+
+    :returns: new_xyz [B,npoint,3] | None, new_feat [B,Cout,npoint], aux dict (indices)
+    """
+    xyz = _f(xyz)
+    B = xyz.shape[0]
+    aux = {}
+    if npoint is not None:
+        fidx = fps(xyz, npoint)
+        new_xyz = gather_points(xyz, fidx)
+        bidx = ball_query(new_xyz, xyz, radius, nsample)
+        grouped = group_points(xyz, new_xyz, feat, bidx)  # [B,3+C,np,ns]
+        aux.update(fps_idx=fidx, ball_idx=bidx)
+    else:
+        new_xyz = None
+        g = [np.transpose(xyz, (0, 2, 1))[:, :, None, :]]
+        if feat is not None:
+            g.append(_f(feat)[:, :, None, :])
+        grouped = np.concatenate(g, axis=1)  # [B,3+C,1,N]
+    x = np.transpose(grouped, (0, 2, 3, 1))  # [B,np,ns,Cin]
+    y = shared_mlp(x, layers)  # [B,np,ns,Cout]
+    pooled = y.max(axis=2)  # [B,np,Cout]
+    return new_xyz, np.ascontiguousarray(np.transpose(pooled, (0, 2, 1))), aux
+
+
+def _sa_layers(sd: Dict[str, np.ndarray], i: int):
+    return [(sd[f"point_cloud_encoder.SA_modules.{i}.mlps.0.{k}.weight"],
+             sd[f"point_cloud_encoder.SA_modules.{i}.mlps.0.{k}.bias"]) for k in (0, 2, 4)]
+
+
+def pointnet_encoder(sd: Dict[str, np.ndarray], pc) -> Tuple[np.ndarray, dict]:
+    """MPiNetsPointNet.forward (model.py:409-426).  pc [B,N,4] -> [B,2048]."""
+    pc = _f(pc)
+    xyz = np.ascontiguousarray(pc[..., :3])
+    feat = np.ascontiguousarray(np.transpose(pc[..., 3:], (0, 2, 1)))
+    aux = {}
+    xyz1, f1, a1 = sa_module(xyz, feat, 512, 0.05, 128, _sa_layers(sd, 0))
+    xyz2, f2, a2 = sa_module(xyz1, f1, 128, 0.3, 128, _sa_layers(sd, 1))
+    _, f3, _ = sa_module(xyz2, f2, None, None, None, _sa_layers(sd, 2))
+    aux.update(sa1=a1, sa2=a2, xyz1=xyz1, f1=f1, xyz2=xyz2, f2=f2, f3=f3)
+    x = f3[:, :, 0]
+    p = "point_cloud_encoder.fc_layer."
+    x = _linear(x, sd[p + "0.weight"], sd[p + "0.bias"])
+    x = _leaky(_group_norm(x, 16, sd[p + "1.weight"], sd[p + "1.bias"]))
+    x = _linear(x, sd[p + "3.weight"], sd[p + "3.bias"])
+    x = _leaky(_group_norm(x, 16, sd[p + "4.weight"], sd[p + "4.bias"]))
+    x = _linear(x, sd[p + "6.weight"], sd[p + "6.bias"])
+    return x, aux
+
+
+def policy_forward(sd: Dict[str, np.ndarray], pc, q) -> Tuple[np.ndarray, dict]:
+    """MotionPolicyNetwork.forward (model.py:75-91)."""
+    enc, aux = pointnet_encoder(sd, pc)
+    x = _f(q)
+    for k in (0, 2, 4, 6, 8):
+        x = _linear(x, sd[f"feature_encoder.{k}.weight"], sd[f"feature_encoder.{k}.bias"])
+        if k != 8:
+            x = _leaky(x)
+    x = np.concatenate([enc, x], axis=1)
+    for k in (0, 2, 4, 6):
+        x = _linear(x, sd[f"decoder.{k}.weight"], sd[f"decoder.{k}.bias"])
+        if k != 6:
+            x = _leaky(x)
+    aux["encoding"] = enc
+    return x, aux
+
+
+def unnormalize(q, limits) -> np.ndarray:
+    """utils.py:207-209 with limits (-1, 1)."""
+    q = _f(q)
+    lim = _f(limits)
+    return ((q - np.float32(-1)) * (lim[:, 1] - lim[:, 0]) / np.float32(2) + lim[:, 0]).astype(np.float32)
+
+
+def normalize(q, limits) -> np.ndarray:
+    """utils.py:91-93 with limits (-1, 1)."""
+    q = _f(q)
+    lim = _f(limits)
+    return ((q - lim[:, 0]) / (lim[:, 1] - lim[:, 0]) * np.float32(2) + np.float32(-1)).astype(np.float32)
