@@ -1,0 +1,162 @@
+/*
+ * mpinets_hip.h -- C-ABI of libmpinets_hip.so, the MI355X (gfx950) engine behind the hot path
+ * of NVlabs/motion-policy-networks.
+ *
+ * The reference has no FFI of its own (it is pure Python); the seams this ABI
+ * sits behind are the Python-level call sites cited on each entry point
+ * (paths relative to /root/reference).  INTEGRATION.md shows the ctypes binding a reference
+ * maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless marked "host"; plain C types only;
+ *   - all tensors are dense, row-major, float32 / int32; "stride" arguments count floats;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls only enqueue;
+ *   - return 0 on success, non-zero on error (mpx_last_error() gives the text, per thread);
+ *   - no call allocates or frees device memory, so every call is hipGraph-capturable
+ *     (exception: none).
+ */
+#ifndef MPINETS_HIP_H
+#define MPINETS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *mpx_stream_t;
+
+#define MPX_NUM_FRAMES 15 /* link0..8, hand, leftfinger, rightfinger, l/r fingertip, right_gripper */
+
+int mpx_version(void);
+const char *mpx_last_error(void);
+/* host-side query of the device the library will launch on (name buffer may be NULL) */
+int mpx_device_info(char *name, int name_len, int *cu_count, int *lds_bytes);
+
+/* ---- geometry: mpinets/geometry.py -------------------------------------------------------- */
+
+/* TorchCuboids/TorchCylinders.__init__ + _init_frames (geometry.py:151,177-223,409-454).
+ * centers [n,3], quats [n,4] (w,x,y,z; normalised here) -> inv_frames [n,4,4] row-major:
+ * rows 0..2 = [R | R.(-c)], row 3 = [0 0 0 1].  R is the reference's matrix as written,
+ * including `yz - wx` at both R[1][2] and R[2][1].                                          */
+int mpx_prim_frames(const float *centers, const float *quats, int n, float *inv_frames,
+                    mpx_stream_t stream);
+
+/* TorchCuboids.sdf / .sdf_sequence (geometry.py:238-288, :290-347).
+ * points [B,P,3] (P = N, or T*N), out [B,P] = min over unmasked cuboids; cuboids with any
+ * |dim| <= 1e-8 are masked; all masked -> +inf.                                             */
+int mpx_cuboid_sdf(const float *inv_frames, const float *dims, int B, int M, const float *points,
+                   int P, float *out, mpx_stream_t stream);
+/* TorchCylinders.sdf / .sdf_sequence (geometry.py:456-507, :509-568). radii/heights [B,M]. */
+int mpx_cylinder_sdf(const float *inv_frames, const float *radii, const float *heights, int B,
+                     int M, const float *points, int P, float *out, mpx_stream_t stream);
+/* TorchSpheres.sdf / .sdf_sequence (geometry.py:87-123). centers [B,M,3], radii [B,M].     */
+int mpx_sphere_sdf(const float *centers, const float *radii, int B, int M, const float *points,
+                   int P, float *out, mpx_stream_t stream);
+
+/* ---- robot geometry: robofin FrankaSampler / FrankaCollisionSampler call sites ------------ */
+
+/* FK of the Franka Panda chain: q [B,7] -> frames [B,15,12] (R row-major 3x3, then t).
+ * Replaces FrankaSampler.end_effector_pose / FrankaRobot.fk (model.py:275,
+ * run_inference.py:176-178).  `finger` = prismatic finger opening (0.025 in the reference). */
+int mpx_franka_fk(const float *q, int B, float finger, float *frames, mpx_stream_t stream);
+
+/* FrankaSampler.sample (model.py:250, run_inference.py:64,111,169, data_loader.py:180-185):
+ * out[b, j, 0:3] = frame[b, link[src]] * table[src], src = subset ? subset[j] : j.
+ * out is addressed as out + b*out_batch_stride + j*out_point_stride (floats), which lets the
+ * call write straight into the xyz slab `xyz[:, :n_out, :3]` (model.py:180-181).            */
+int mpx_franka_cloud(const float *q, int B, float finger, const float *table_pts,
+                     const int32_t *table_link, const int32_t *subset, int n_out, float *out,
+                     int64_t out_batch_stride, int out_point_stride, mpx_stream_t stream);
+
+/* FrankaSampler.sample_end_effector (run_inference.py:66-69, data_loader.py:158-161):
+ * poses [B,4,4] row-major; out[b,j] = pose[b] * table[src].                                 */
+int mpx_pose_cloud(const float *poses, int B, const float *table_pts, const int32_t *subset,
+                   int n_out, float *out, int64_t out_batch_stride, int out_point_stride,
+                   mpx_stream_t stream);
+
+/* FrankaCollisionSampler.compute_spheres (model.py:300): centres [B,S,3] of the S table
+ * spheres (sph_centers [S,3] link-local, sph_link [S]) at configuration q [B,7].           */
+int mpx_franka_spheres(const float *q, int B, float finger, const float *sph_centers,
+                       const int32_t *sph_link, int S, float *out, mpx_stream_t stream);
+
+/* Fused swept-sphere collision check, model.py:293-314, for q [B,T,7]:
+ *   flags[b] |= any_{t,s} min(cuboid_sdf, cylinder_sdf)(centre[b,t,s]) <= sph_radii[s]
+ * flags int32 [B] is OR-ed into (caller zeroes it); min_sdf [B,T,S] optional (may be NULL).
+ * Either primitive set may be empty (M = 0).                                                */
+int mpx_franka_collision(const float *q, int B, int T, float finger, const float *sph_centers,
+                         const float *sph_radii, const int32_t *sph_link, int S,
+                         const float *cub_frames, const float *cub_dims, int M1,
+                         const float *cyl_frames, const float *cyl_radii,
+                         const float *cyl_heights, int M2, int32_t *flags, float *min_sdf,
+                         mpx_stream_t stream);
+
+/* rollout joint update, model.py:171-173 + utils.py:207-209:
+ *   q_norm_out = clamp(q_norm + dq, -1, 1);  q_out = (q_norm_out + 1) * (hi - lo) / 2 + lo
+ * limits [7,2] device; either output may alias q_norm.                                      */
+int mpx_joint_step(const float *q_norm, const float *dq, const float *limits, int B,
+                   float *q_norm_out, float *q_out, mpx_stream_t stream);
+
+/* ---- PointNet++ set abstraction: pointnet2_ops call sites model.py:27,366-383 ------------- */
+
+/* furthest_point_sample (+ gather_operation): xyz rows at xyz + (b*N + k)*stride, first three
+ * floats used.  idx int32 [B,npoint]; new_xyz (optional) rows at
+ * new_xyz + (b*npoint + j)*new_stride.  Index semantics follow pointnet2_ops v3.2.0 exactly
+ * (start 0, |p|^2 <= 1e-3 skipped, block-size-dependent tie order).  N <= 16384.           */
+int mpx_fps(const float *xyz, int B, int N, int stride, int npoint, int32_t *idx, float *new_xyz,
+            int new_stride, mpx_stream_t stream);
+
+/* ball_query: first `nsample` indices (ascending) with d2 < radius^2, padded with the first
+ * hit, zero when there is none.  idx int32 [B,npoint,nsample].                              */
+int mpx_ball_query(const float *new_xyz, int new_stride, const float *xyz, int stride, int B,
+                   int N, int npoint, float radius, int nsample, int32_t *idx,
+                   mpx_stream_t stream);
+
+/* QueryAndGroup (use_xyz=True) materialised like the reference does:
+ * out [B, 3+C, npoint, nsample]; feat point-major rows at feat + (b*N+k)*feat_stride.       */
+int mpx_group_points(const float *xyz, int stride, const float *new_xyz, int new_stride,
+                     const float *feat, int feat_stride, int C, const int32_t *idx, int B, int N,
+                     int npoint, int nsample, float *out, mpx_stream_t stream);
+
+/* Fused QueryAndGroup + shared MLP (3 x [1x1 conv + ReLU]) + max-pool over the neighbourhood
+ * (PointnetSAModule.forward body), fp32 MFMA, nothing materialised in HBM.
+ * Channel order of the MLP input is [dx,dy,dz, feat...] like the reference.
+ * wpack: weights + biases packed by mpx_sa_pack_weights for this (C, c1, c2, c3).
+ * out rows at out + (b*npoint + j)*out_stride, c3 floats each.
+ * Supported: (C,c1,c2,c3) = (1,64,64,64) and (64,128,128,256); nsample % 32 == 0.          */
+int mpx_sa_mlp(const float *xyz, int stride, const float *new_xyz, int new_stride,
+               const float *feat, int feat_stride, int C, const int32_t *idx, int B, int N,
+               int npoint, int nsample, const float *wpack, int c1, int c2, int c3, float *out,
+               int out_stride, mpx_stream_t stream);
+/* number of floats mpx_sa_pack_weights writes for this configuration (host call)            */
+int64_t mpx_sa_pack_size(int C, int c1, int c2, int c3);
+/* w1 [c1,3+C], w2 [c2,c1], w3 [c3,c2] row-major (Conv2d 1x1 weights), b* biases -> wpack    */
+int mpx_sa_pack_weights(const float *w1, const float *b1, const float *w2, const float *b2,
+                        const float *w3, const float *b3, int C, int c1, int c2, int c3,
+                        float *wpack, mpx_stream_t stream);
+
+/* ---- dense layers: model.py:47-66, 385-393 ------------------------------------------------- */
+
+#define MPX_ACT_NONE 0
+#define MPX_ACT_RELU 1
+#define MPX_ACT_LEAKY 2 /* slope 0.01, nn.LeakyReLU() default */
+
+/* y[m, n] = act(sum_k x[m,k] * w[n,k] + bias[n]);  x rows at x + m*ldx, y rows at y + m*ldy.
+ * fp32 MFMA.  K % 4 == 0, ldx % 4 == 0, x and w 16-byte aligned.                             */
+int mpx_linear(const float *x, int ldx, const float *w, const float *bias, int M, int N, int K,
+               int act, float *y, int ldy, mpx_stream_t stream);
+
+/* nn.GroupNorm(groups, C) (eps 1e-5, biased variance) followed by LeakyReLU(0.01), in place
+ * allowed.  x,y [M,C].                                                                       */
+int mpx_groupnorm_leaky(const float *x, const float *gamma, const float *beta, int M, int C,
+                        int groups, float eps, float *y, mpx_stream_t stream);
+
+/* max over `rows` consecutive rows: x [G*rows, C] -> y [G, C]  (max_pool2d of the group-all
+ * SA module, model.py:383)                                                                   */
+int mpx_rowmax(const float *x, int ldx, int G, int rows, int C, float *y, int ldy,
+               mpx_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPINETS_HIP_H */

@@ -1,0 +1,170 @@
+// common.h -- shared host/device helpers for libmpinets_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/mpinets_hip.h"
+
+#define MPX_EXPORT extern "C" __attribute__((visibility("default")))
+
+// ---- error plumbing -------------------------------------------------------------------------
+void mpx_set_error(const char *fmt, ...);
+
+#define MPX_REQUIRE(cond, ...)        \
+  do {                                \
+    if (!(cond)) {                    \
+      mpx_set_error(__VA_ARGS__);     \
+      return 1;                       \
+    }                                 \
+  } while (0)
+
+#define MPX_LAUNCH_CHECK(name)                                              \
+  do {                                                                      \
+    hipError_t e_ = hipGetLastError();                                      \
+    if (e_ != hipSuccess) {                                                 \
+      mpx_set_error("%s: launch failed: %s", name, hipGetErrorString(e_)); \
+      return 2;                                                             \
+    }                                                                       \
+    return 0;                                                               \
+  } while (0)
+
+static inline hipStream_t mpx_s(mpx_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// ---- device math with a pinned evaluation order ----------------------------------------------
+// Build uses -ffp-contract=off: fused multiply-adds exist only where __builtin_fmaf is written,
+// so these helpers evaluate exactly like their restatement in oracle/mpn_oracle.c.
+
+__device__ __forceinline__ float mpx_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+// Cody-Waite by pi/2 + fixed polynomials; |x| up to ~1e3 rad is far more than joint angles need.
+__device__ __forceinline__ void mpx_sincos(float x, float &s, float &c) {
+  const float TWO_OVER_PI = 0.63661977236758134308f;
+  const float PIO2_HI = 1.57079625129699707031f;
+  const float PIO2_LO = 7.54978941586159635335e-08f;
+  float kf = __builtin_rintf(x * TWO_OVER_PI);
+  float r = mpx_fma(-kf, PIO2_HI, x);
+  r = mpx_fma(-kf, PIO2_LO, r);
+  float r2 = r * r;
+  float ps = mpx_fma(r2, 2.7557314297e-06f, -1.9841270114e-04f);
+  ps = mpx_fma(ps, r2, 8.3333337680e-03f);
+  ps = mpx_fma(ps, r2, -1.6666667163e-01f);
+  float sn = mpx_fma(r * r2, ps, r);
+  float pc = mpx_fma(r2, -2.7557314297e-07f, 2.4801587642e-05f);
+  pc = mpx_fma(pc, r2, -1.3888889225e-03f);
+  pc = mpx_fma(pc, r2, 4.1666667908e-02f);
+  pc = mpx_fma(pc, r2, -0.5f);
+  float cs = mpx_fma(pc, r2, 1.0f);
+  int k = ((int)kf) & 3;
+  s = (k & 1) ? cs : sn;
+  c = (k & 1) ? sn : cs;
+  if (k == 1 || k == 2) c = -c;
+  if (k >= 2) s = -s;
+}
+
+// 3x4 rigid transform: r[9] row-major rotation, t[3]
+struct Rigid {
+  float r[9];
+  float t[3];
+};
+
+__device__ __forceinline__ Rigid rigid_compose(const Rigid &a, const float (&fr)[9], const float (&ft)[3]) {
+  Rigid o;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float acc = a.r[3 * i + 0] * fr[0 + c];
+      acc = mpx_fma(a.r[3 * i + 1], fr[3 + c], acc);
+      acc = mpx_fma(a.r[3 * i + 2], fr[6 + c], acc);
+      o.r[3 * i + c] = acc;
+    }
+    float acc = a.t[i];
+    acc = mpx_fma(a.r[3 * i + 0], ft[0], acc);
+    acc = mpx_fma(a.r[3 * i + 1], ft[1], acc);
+    acc = mpx_fma(a.r[3 * i + 2], ft[2], acc);
+    o.t[i] = acc;
+  }
+  return o;
+}
+
+__device__ __forceinline__ Rigid rigid_rotz(const Rigid &p, float s, float c) {
+  Rigid o;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    float a = p.r[3 * i + 0], b = p.r[3 * i + 1];
+    o.r[3 * i + 0] = mpx_fma(b, s, a * c);
+    o.r[3 * i + 1] = mpx_fma(b, c, -(a * s));
+    o.r[3 * i + 2] = p.r[3 * i + 2];
+    o.t[i] = p.t[i];
+  }
+  return o;
+}
+
+__device__ __forceinline__ void rigid_apply(const float *f /*12*/, float x, float y, float z, float &ox,
+                                            float &oy, float &oz) {
+  float a0 = f[0] * x;
+  a0 = mpx_fma(f[1], y, a0);
+  a0 = mpx_fma(f[2], z, a0);
+  float a1 = f[3] * x;
+  a1 = mpx_fma(f[4], y, a1);
+  a1 = mpx_fma(f[5], z, a1);
+  float a2 = f[6] * x;
+  a2 = mpx_fma(f[7], y, a2);
+  a2 = mpx_fma(f[8], z, a2);
+  ox = a0 + f[9];
+  oy = a1 + f[10];
+  oz = a2 + f[11];
+}
+
+// Franka Panda chain (public URDF constants).  Writes 15 frames x 12 floats to `out`
+// (any address space the caller indexes with a plain pointer: LDS or global).
+__device__ __forceinline__ void franka_fk_frames(const float *q7, float finger, float *out) {
+  constexpr float SH = 0.70710678118654752440f;
+  Rigid cur = {{1, 0, 0, 0, 1, 0, 0, 0, 1}, {0, 0, 0}};
+  auto put = [&](int id, const Rigid &g) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) out[12 * id + k] = g.r[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) out[12 * id + 9 + k] = g.t[k];
+  };
+  put(0, cur);
+  const float JR[7][9] = {
+      {1, 0, 0, 0, 1, 0, 0, 0, 1},  {1, 0, 0, 0, 0, 1, 0, -1, 0}, {1, 0, 0, 0, 0, -1, 0, 1, 0},
+      {1, 0, 0, 0, 0, -1, 0, 1, 0}, {1, 0, 0, 0, 0, 1, 0, -1, 0}, {1, 0, 0, 0, 0, -1, 0, 1, 0},
+      {1, 0, 0, 0, 0, -1, 0, 1, 0},
+  };
+  const float JT[7][3] = {
+      {0.0f, 0.0f, 0.333f},     {0.0f, 0.0f, 0.0f}, {0.0f, -0.316f, 0.0f}, {0.0825f, 0.0f, 0.0f},
+      {-0.0825f, 0.384f, 0.0f}, {0.0f, 0.0f, 0.0f}, {0.088f, 0.0f, 0.0f},
+  };
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    float s, c;
+    mpx_sincos(q7[j], s, c);
+    Rigid tmp = rigid_compose(cur, JR[j], JT[j]);
+    cur = rigid_rotz(tmp, s, c);
+    put(j + 1, cur);
+  }
+  const float I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  const float T8[3] = {0.0f, 0.0f, 0.107f};
+  Rigid l8 = rigid_compose(cur, I3, T8);
+  put(8, l8);
+  const float RH[9] = {SH, SH, 0, -SH, SH, 0, 0, 0, 1};
+  const float Z3[3] = {0.0f, 0.0f, 0.0f};
+  Rigid hand = rigid_compose(l8, RH, Z3);
+  put(9, hand);
+  const float TL[3] = {0.0f, finger, 0.0584f};
+  const float TR[3] = {0.0f, -finger, 0.0584f};
+  Rigid lf = rigid_compose(hand, I3, TL);
+  Rigid rf = rigid_compose(hand, I3, TR);
+  put(10, lf);
+  put(11, rf);
+  const float TT[3] = {0.0f, 0.0f, 0.045f};
+  put(12, rigid_compose(lf, I3, TT));
+  put(13, rigid_compose(rf, I3, TT));
+  const float RG[9] = {-SH, -SH, 0, SH, -SH, 0, 0, 0, 1};
+  const float TG[3] = {0.0f, 0.0f, 0.1f};
+  put(14, rigid_compose(l8, RG, TG));
+}

@@ -1,0 +1,208 @@
+// dense.hip -- dense layers of the policy: y = act(x . W^T + b) on the exact-fp32 matrix cores,
+// GroupNorm + LeakyReLU, and the row-max pooling of the group-all set-abstraction module.
+//
+// Reference layers (all torch nn.Linear / Conv2d 1x1 / GroupNorm in the reference):
+//   MPiNetsPointNet SA3 mlp [256(+3),512,512,1024] + max over the 128 points   model.py:383
+//   fc_layer 1024->4096 GN(16) LeakyReLU ->2048 GN(16) LeakyReLU ->2048        model.py:385-393
+//   feature_encoder 7->32->64->128->128->64                                     model.py:47-57
+//   decoder 2112->512->256->128->7                                              model.py:58-66
+//
+// GEMM: 128x128 output tile per 256-thread workgroup (4 waves as 2x2, 64x64 per wave =
+// 2x2 v_mfma_f32_32x32x2_f32 tiles), K walked 16 at a time through a double-buffered LDS stage
+// (register prefetch of slab k+1 while slab k feeds the matrix pipe, one barrier per slab).
+// Within a slab lane-half h consumes k = 8h..8h+7, so each lane fetches its 8 operands of a
+// tile row with two 16-byte LDS reads; rows are padded to 20 floats, which makes those reads
+// conflict-free for the ds_read_b128 lane groups.  fp32 in, fp32 accumulate (bit-identical to
+// an fmaf chain in this k order): bound by the 157 TFLOP/s fp32 MFMA pipe.
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 128, BK = 16, LDT = BK + 4;
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+  if (act == MPX_ACT_RELU) return fmaxf(v, 0.0f);
+  if (act == MPX_ACT_LEAKY) return v >= 0.0f ? v : v * 0.01f;
+  return v;
+}
+
+__global__ void __launch_bounds__(256)
+    linear_kernel(const float *__restrict__ x, int ldx, const float *__restrict__ w,
+                  const float *__restrict__ bias, int M, int N, int K, int act, float *__restrict__ y, int ldy) {
+  __shared__ __attribute__((aligned(16))) float As[2][BM * LDT];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+
+  // staging map: thread -> (row, 4-float column chunk), two rows (r, r+64) per matrix
+  const int srow = tid >> 2, scol = (tid & 3) * 4;
+  float4 pa[2], pb[2];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = srow + 64 * i;
+      const int kk = k0 + scol;
+      pa[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      pb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m0 + r < M && kk < K) pa[i] = *reinterpret_cast<const float4 *>(x + (size_t)(m0 + r) * ldx + kk);
+      if (n0 + r < N && kk < K) pb[i] = *reinterpret_cast<const float4 *>(w + (size_t)(n0 + r) * K + kk);
+    }
+  };
+  auto sstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = srow + 64 * i;
+      *reinterpret_cast<float4 *>(&As[buf][r * LDT + scol]) = pa[i];
+      *reinterpret_cast<float4 *>(&Bs[buf][r * LDT + scol]) = pb[i];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+  const int nk = (K + BK - 1) / BK;
+  gload(0);
+  sstore(0);
+  __syncthreads();
+  for (int kb = 0; kb < nk; ++kb) {
+    const int buf = kb & 1;
+    if (kb + 1 < nk) gload((kb + 1) * BK);
+    float4 a[2][2], b[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int v = 0; v < 2; ++v) {
+        a[t][v] = *reinterpret_cast<const float4 *>(&As[buf][(wm * 64 + t * 32 + l31) * LDT + 8 * half + 4 * v]);
+        b[t][v] = *reinterpret_cast<const float4 *>(&Bs[buf][(wn * 64 + t * 32 + l31) * LDT + 8 * half + 4 * v]);
+      }
+#pragma unroll
+    for (int v = 0; v < 2; ++v)
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const float av = u == 0 ? a[i][v].x : (u == 1 ? a[i][v].y : (u == 2 ? a[i][v].z : a[i][v].w));
+            const float bv = u == 0 ? b[j][v].x : (u == 1 ? b[j][v].y : (u == 2 ? b[j][v].z : b[j][v].w));
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+          }
+    if (kb + 1 < nk) sstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: C[row][col], col = lane&31, row = (r&3) + 8*(r>>2) + 4*half
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = n0 + wn * 64 + j * 32 + l31;
+    if (col >= N) continue;
+    const float bv = bias ? bias[col] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (row < M) y[(size_t)row * ldy + col] = act_apply(acc[i][j][r] + bv, act);
+      }
+  }
+}
+
+MPX_EXPORT int mpx_linear(const float *x, int ldx, const float *w, const float *bias, int M, int N, int K,
+                          int act, float *y, int ldy, mpx_stream_t stream) {
+  MPX_REQUIRE(M >= 0 && N >= 1 && K >= 1, "mpx_linear: bad size");
+  MPX_REQUIRE(K % 4 == 0 && ldx % 4 == 0, "mpx_linear: K and ldx must be multiples of 4 (got %d, %d)", K, ldx);
+  MPX_REQUIRE((((uintptr_t)x | (uintptr_t)w) & 15) == 0, "mpx_linear: x and w must be 16-byte aligned");
+  MPX_REQUIRE(ldx >= K && ldy >= N, "mpx_linear: leading dimension too small");
+  MPX_REQUIRE(act >= 0 && act <= 2, "mpx_linear: unknown activation %d", act);
+  if (M == 0) return 0;
+  MPX_REQUIRE(cdiv(M, BM) <= 65535, "mpx_linear: M too large");
+  hipLaunchKernelGGL(linear_kernel, dim3(cdiv(N, BN), cdiv(M, BM)), dim3(256), 0, mpx_s(stream), x, ldx, w, bias,
+                     M, N, K, act, y, ldy);
+  MPX_LAUNCH_CHECK("mpx_linear");
+}
+
+// ---- GroupNorm + LeakyReLU ---------------------------------------------------------------------------
+// one wave per (row, group); values held in registers between the mean and variance passes.
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+__global__ void __launch_bounds__(256)
+    groupnorm_leaky_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
+                           const float *__restrict__ beta, int64_t n_rg, int C, int groups, float eps,
+                           float *__restrict__ y) {
+  const int lane = threadIdx.x & 63;
+  const int64_t rg = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (rg >= n_rg) return;
+  const int gs = C / groups;
+  const int64_t row = rg / groups;
+  const int g = (int)(rg % groups);
+  const float *xp = x + row * C + (int64_t)g * gs;
+  float *yp = y + row * C + (int64_t)g * gs;
+  constexpr int MAXV = 8;  // gs <= 512
+  float v[MAXV];
+  float s = 0.0f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + 64 * i;
+    v[i] = c < gs ? xp[c] : 0.0f;
+    s += v[i];
+  }
+  const float mean = wave_sum(s) / (float)gs;
+  float q = 0.0f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + 64 * i;
+    const float d = c < gs ? v[i] - mean : 0.0f;
+    q += d * d;
+  }
+  const float var = wave_sum(q) / (float)gs;  // biased, like torch
+  const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + 64 * i;
+    if (c < gs) {
+      const float o = (v[i] - mean) * rstd * gamma[g * gs + c] + beta[g * gs + c];
+      yp[c] = o >= 0.0f ? o : o * 0.01f;
+    }
+  }
+}
+
+MPX_EXPORT int mpx_groupnorm_leaky(const float *x, const float *gamma, const float *beta, int M, int C,
+                                   int groups, float eps, float *y, mpx_stream_t stream) {
+  MPX_REQUIRE(M >= 0 && C >= 1 && groups >= 1 && C % groups == 0, "mpx_groupnorm_leaky: bad size");
+  MPX_REQUIRE(C / groups <= 512, "mpx_groupnorm_leaky: group size %d > 512 unsupported", C / groups);
+  if (M == 0) return 0;
+  const int64_t n = (int64_t)M * groups;
+  hipLaunchKernelGGL(groupnorm_leaky_kernel, dim3(cdiv(n, 4)), dim3(256), 0, mpx_s(stream), x, gamma, beta, n, C,
+                     groups, eps, y);
+  MPX_LAUNCH_CHECK("mpx_groupnorm_leaky");
+}
+
+// ---- max over groups of consecutive rows -------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+    rowmax_kernel(const float *__restrict__ x, int ldx, int rows, int C, float *__restrict__ y, int ldy) {
+  const int g = blockIdx.y;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const float *p = x + (size_t)g * rows * ldx + c;
+  float m = -__builtin_inff();
+  for (int r = 0; r < rows; ++r) m = fmaxf(m, p[(size_t)r * ldx]);
+  y[(size_t)g * ldy + c] = m;
+}
+
+MPX_EXPORT int mpx_rowmax(const float *x, int ldx, int G, int rows, int C, float *y, int ldy,
+                          mpx_stream_t stream) {
+  MPX_REQUIRE(G >= 0 && rows >= 1 && C >= 1 && ldx >= C && ldy >= C, "mpx_rowmax: bad size");
+  MPX_REQUIRE(G <= 65535, "mpx_rowmax: G > 65535 (slab the batch)");
+  if (G == 0) return 0;
+  hipLaunchKernelGGL(rowmax_kernel, dim3(cdiv(C, 256), G), dim3(256), 0, mpx_s(stream), x, ldx, rows, C, y, ldy);
+  MPX_LAUNCH_CHECK("mpx_rowmax");
+}

@@ -1,0 +1,219 @@
+// franka.hip -- Franka Panda forward kinematics, robot point cloud, collision spheres and the
+// fused swept-sphere collision check.
+//
+// Replaces (reference call sites; the implementations live in un-vendored robofin v0.0.1):
+//   FrankaSampler.sample              mpinets/model.py:250, run_inference.py:64,111,169
+//   FrankaSampler.sample_end_effector run_inference.py:66-69, data_loader.py:158-161
+//   FrankaSampler.end_effector_pose   mpinets/model.py:275
+//   FrankaCollisionSampler.compute_spheres + the SDF sweep   mpinets/model.py:293-314
+//   joint update of the rollout       mpinets/model.py:171-173, utils.py:207-209
+//
+// FK is a 7-step dependent chain (~650 VALU instructions) -- far more than the ~12
+// instructions a table point needs -- so a workgroup computes FK for EPB configurations on EPB
+// lanes at once (one instruction stream), parks the 15 frames of each in LDS and then all 256
+// threads stream table points through them.
+#include "common.h"
+#include "sdf_device.h"
+
+constexpr int FRAME_FLOATS = MPX_NUM_FRAMES * 12;  // 180
+
+// ---- FK frames to global -----------------------------------------------------------------------
+__global__ void __launch_bounds__(64) franka_fk_kernel(const float *__restrict__ q, int B, float finger,
+                                                       float *__restrict__ frames) {
+  __shared__ float lds[64 * FRAME_FLOATS];
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b < B) {
+    float qq[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) qq[j] = q[(size_t)b * 7 + j];
+    franka_fk_frames(qq, finger, lds + threadIdx.x * FRAME_FLOATS);
+  }
+  __syncthreads();
+  // coalesced copy-out
+  const int nb = min(64, B - blockIdx.x * 64);
+  float *dst = frames + (size_t)blockIdx.x * 64 * FRAME_FLOATS;
+  for (int i = threadIdx.x; i < nb * FRAME_FLOATS; i += 64) dst[i] = lds[i];
+}
+
+MPX_EXPORT int mpx_franka_fk(const float *q, int B, float finger, float *frames, mpx_stream_t stream) {
+  MPX_REQUIRE(B >= 0, "mpx_franka_fk: B < 0");
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(franka_fk_kernel, dim3(cdiv(B, 64)), dim3(64), 0, mpx_s(stream), q, B, finger, frames);
+  MPX_LAUNCH_CHECK("mpx_franka_fk");
+}
+
+// ---- table points moved by FK frames -------------------------------------------------------------
+constexpr int CLOUD_EPB = 16;  // configurations per workgroup
+
+__global__ void __launch_bounds__(256)
+    franka_cloud_kernel(const float *__restrict__ q, int B, float finger, const float *__restrict__ tpts,
+                        const int32_t *__restrict__ tlink, const int32_t *__restrict__ subset, int n_out,
+                        float *__restrict__ out, int64_t obs, int ops) {
+  __shared__ float lds[CLOUD_EPB * FRAME_FLOATS];
+  const int b0 = blockIdx.x * CLOUD_EPB;
+  const int nb = min(CLOUD_EPB, B - b0);
+  if (threadIdx.x < nb) {
+    float qq[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) qq[j] = q[(size_t)(b0 + threadIdx.x) * 7 + j];
+    franka_fk_frames(qq, finger, lds + threadIdx.x * FRAME_FLOATS);
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < n_out; j += 256) {
+    const int src = subset ? subset[j] : j;
+    const float px = tpts[3 * (size_t)src + 0], py = tpts[3 * (size_t)src + 1], pz = tpts[3 * (size_t)src + 2];
+    const int link = tlink[src];
+    for (int e = 0; e < nb; ++e) {
+      float ox, oy, oz;
+      rigid_apply(lds + e * FRAME_FLOATS + 12 * link, px, py, pz, ox, oy, oz);
+      float *o = out + (int64_t)(b0 + e) * obs + (int64_t)j * ops;
+      o[0] = ox;
+      o[1] = oy;
+      o[2] = oz;
+    }
+  }
+}
+
+MPX_EXPORT int mpx_franka_cloud(const float *q, int B, float finger, const float *table_pts,
+                                const int32_t *table_link, const int32_t *subset, int n_out, float *out,
+                                int64_t out_batch_stride, int out_point_stride, mpx_stream_t stream) {
+  MPX_REQUIRE(B >= 0 && n_out >= 0, "mpx_franka_cloud: negative size");
+  MPX_REQUIRE(out_point_stride >= 3, "mpx_franka_cloud: out_point_stride < 3");
+  if (B == 0 || n_out == 0) return 0;
+  hipLaunchKernelGGL(franka_cloud_kernel, dim3(cdiv(B, CLOUD_EPB)), dim3(256), 0, mpx_s(stream), q, B,
+                     finger, table_pts, table_link, subset, n_out, out, out_batch_stride, out_point_stride);
+  MPX_LAUNCH_CHECK("mpx_franka_cloud");
+}
+
+MPX_EXPORT int mpx_franka_spheres(const float *q, int B, float finger, const float *sph_centers,
+                                  const int32_t *sph_link, int S, float *out, mpx_stream_t stream) {
+  return mpx_franka_cloud(q, B, finger, sph_centers, sph_link, nullptr, S, out, (int64_t)S * 3, 3, stream);
+}
+
+// ---- table points moved by one given pose per batch element ----------------------------------------
+__global__ void __launch_bounds__(256)
+    pose_cloud_kernel(const float *__restrict__ poses, const float *__restrict__ tpts,
+                      const int32_t *__restrict__ subset, int n_out, float *__restrict__ out, int64_t obs,
+                      int ops) {
+  const int b = blockIdx.y;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n_out) return;
+  const float *P = poses + 16 * (size_t)b;  // block-uniform -> scalar loads
+  const int src = subset ? subset[j] : j;
+  const float px = tpts[3 * (size_t)src + 0], py = tpts[3 * (size_t)src + 1], pz = tpts[3 * (size_t)src + 2];
+  float ox, oy, oz;
+  mpx_project(P, px, py, pz, ox, oy, oz);
+  float *o = out + (int64_t)b * obs + (int64_t)j * ops;
+  o[0] = ox;
+  o[1] = oy;
+  o[2] = oz;
+}
+
+MPX_EXPORT int mpx_pose_cloud(const float *poses, int B, const float *table_pts, const int32_t *subset,
+                              int n_out, float *out, int64_t out_batch_stride, int out_point_stride,
+                              mpx_stream_t stream) {
+  MPX_REQUIRE(B >= 0 && B <= 65535 && n_out >= 0, "mpx_pose_cloud: bad size (B <= 65535)");
+  if (B == 0 || n_out == 0) return 0;
+  hipLaunchKernelGGL(pose_cloud_kernel, dim3(cdiv(n_out, 256), B), dim3(256), 0, mpx_s(stream), poses,
+                     table_pts, subset, n_out, out, out_batch_stride, out_point_stride);
+  MPX_LAUNCH_CHECK("mpx_pose_cloud");
+}
+
+// ---- fused FK + sphere-vs-primitive SDF + collision flags ------------------------------------------
+// One workgroup = COL_PPB consecutive (env, waypoint) pairs g = b*T + t.  FK for all of them runs
+// on COL_PPB lanes of wave 0; then each of the 4 waves takes pairs round-robin with the S spheres
+// on its lanes.  Primitive data of the pair's environment is wave-uniform (scalar loads).
+// Algorithmic bytes per pair: 28 (q) + per-env primitive data amortised over T; writes 4*S when
+// min_sdf is requested, else nothing but the rare atomicOr.
+constexpr int COL_PPB = 16;
+
+__global__ void __launch_bounds__(256)
+    franka_collision_kernel(const float *__restrict__ q, int G, int T, float finger,
+                            const float *__restrict__ sc, const float *__restrict__ sr,
+                            const int32_t *__restrict__ sl, int S, const float *__restrict__ cub_f,
+                            const float *__restrict__ cub_d, int M1, const float *__restrict__ cyl_f,
+                            const float *__restrict__ cyl_r, const float *__restrict__ cyl_h, int M2,
+                            int32_t *__restrict__ flags, float *__restrict__ min_sdf) {
+  __shared__ float lds[COL_PPB * FRAME_FLOATS];
+  const int g0 = blockIdx.x * COL_PPB;
+  const int ng = min(COL_PPB, G - g0);
+  if (threadIdx.x < ng) {
+    float qq[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) qq[j] = q[(size_t)(g0 + threadIdx.x) * 7 + j];
+    franka_fk_frames(qq, finger, lds + threadIdx.x * FRAME_FLOATS);
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  for (int i = wave; i < ng; i += 4) {
+    const int g = g0 + i;
+    const int b = g / T;  // wave-uniform
+    const float *cf = cub_f + (size_t)b * M1 * 16;
+    const float *cd = cub_d + (size_t)b * M1 * 3;
+    const float *yf = cyl_f + (size_t)b * M2 * 16;
+    const float *yr = cyl_r + (size_t)b * M2;
+    const float *yh = cyl_h + (size_t)b * M2;
+    bool any_hit = false;
+    for (int s = lane; s < S; s += 64) {
+      float x, y, z;
+      rigid_apply(lds + i * FRAME_FLOATS + 12 * sl[s], sc[3 * s + 0], sc[3 * s + 1], sc[3 * s + 2], x, y, z);
+      float best = __builtin_inff();
+      for (int m = 0; m < M1; ++m) {
+        float v = cuboid_sdf(cf + 16 * m, cd[3 * m + 0], cd[3 * m + 1], cd[3 * m + 2], x, y, z);
+        best = v < best ? v : best;
+      }
+      float besty = __builtin_inff();
+      for (int m = 0; m < M2; ++m) {
+        float v = cylinder_sdf(yf + 16 * m, yr[m], yh[m], x, y, z);
+        besty = v < besty ? v : besty;
+      }
+      best = fminf(best, besty);  // torch.minimum(cuboids, cylinders), model.py:304-307
+      if (min_sdf) min_sdf[(size_t)g * S + s] = best;
+      any_hit |= best <= sr[s];  // model.py:309-311
+    }
+    if (__any(any_hit) && lane == 0) atomicOr(flags + b, 1);
+  }
+}
+
+MPX_EXPORT int mpx_franka_collision(const float *q, int B, int T, float finger, const float *sph_centers,
+                                    const float *sph_radii, const int32_t *sph_link, int S,
+                                    const float *cub_frames, const float *cub_dims, int M1,
+                                    const float *cyl_frames, const float *cyl_radii,
+                                    const float *cyl_heights, int M2, int32_t *flags, float *min_sdf,
+                                    mpx_stream_t stream) {
+  MPX_REQUIRE(B >= 0 && T >= 0 && S >= 0 && M1 >= 0 && M2 >= 0, "mpx_franka_collision: negative size");
+  MPX_REQUIRE((int64_t)B * T < (int64_t)1 << 31, "mpx_franka_collision: B*T overflows int32");
+  if (B == 0 || T == 0 || S == 0) return 0;
+  const int G = B * T;
+  hipLaunchKernelGGL(franka_collision_kernel, dim3(cdiv(G, COL_PPB)), dim3(256), 0, mpx_s(stream), q, G, T,
+                     finger, sph_centers, sph_radii, sph_link, S, cub_frames, cub_dims, M1, cyl_frames,
+                     cyl_radii, cyl_heights, M2, flags, min_sdf);
+  MPX_LAUNCH_CHECK("mpx_franka_collision");
+}
+
+// ---- rollout joint update ------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+    joint_step_kernel(const float *__restrict__ qn, const float *__restrict__ dq,
+                      const float *__restrict__ limits, int n, float *__restrict__ qn_out,
+                      float *__restrict__ q_out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int j = i % 7;
+  float v = qn[i] + dq[i];
+  v = fminf(fmaxf(v, -1.0f), 1.0f);  // torch.clamp(q + self(xyz, q), min=-1, max=1), model.py:171
+  const float lo = limits[2 * j], hi = limits[2 * j + 1];
+  // utils.py:207-209 with limits=(-1,1): (x - (-1)) * range / 2 + lower
+  const float u = (v - (-1.0f)) * (hi - lo) / 2.0f + lo;
+  if (qn_out) qn_out[i] = v;
+  if (q_out) q_out[i] = u;
+}
+
+MPX_EXPORT int mpx_joint_step(const float *q_norm, const float *dq, const float *limits, int B,
+                              float *q_norm_out, float *q_out, mpx_stream_t stream) {
+  MPX_REQUIRE(B >= 0, "mpx_joint_step: B < 0");
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(joint_step_kernel, dim3(cdiv((int64_t)B * 7, 256)), dim3(256), 0, mpx_s(stream), q_norm,
+                     dq, limits, B * 7, q_norm_out, q_out);
+  MPX_LAUNCH_CHECK("mpx_joint_step");
+}

@@ -1,0 +1,274 @@
+// pointnet.hip -- farthest-point sampling, ball query and neighbourhood grouping.
+//
+// Replaces the pointnet2_ops v3.2.0 CUDA extension the reference pip-installs
+// (/root/reference/docker/Dockerfile:152; call sites mpinets/model.py:27,366-383,423-424).
+// Index semantics are those of that extension (restated in oracle/mpn_oracle.c):
+//   FPS   start at index 0; running distance 1e10; points with |p|^2 <= 1e-3 never update and
+//         are never candidates; the arg-max over d2 breaks ties towards the smallest
+//         (k mod bs, k) pair, bs = opt_n_threads(N) -- the order its strided thread scan +
+//         shared-memory tree reduction produces;
+//   ball  first `nsample` indices in ascending order with d2 < r^2, all slots pre-filled with
+//         the first hit, zeros when nothing is in range.
+// Distances are fma(dz,dz,fma(dy,dy,dx*dx)), the contraction nvcc applies to the CUDA source.
+//
+// CDNA4 design: one workgroup per environment; the whole cloud lives in registers
+// (x,y,z,running distance: PTS points per lane) with an LDS copy used only to broadcast the
+// coordinates of the point just selected.  Each of the npoint-1 dependent iterations is one
+// pass of VALU work, a DPP (cross-lane) arg-max inside every wave and ONE barrier: waves publish
+// a 64-bit key {float bits of d2, ~tie-rank} into a double-buffered LDS slot array and every wave
+// re-reduces the <=16 slots itself.  The kernel is latency/LDS-bound, not HBM-bound: HBM traffic
+// is the 12 (or 16) bytes per point read once.
+#include "common.h"
+
+typedef unsigned long long u64;
+
+// ---- DPP helpers --------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ u64 dpp_mov64(u64 v) {
+  unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+  lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)lo, CTRL, 0xf, 0xf, true);
+  hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)hi, CTRL, 0xf, 0xf, true);
+  return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ u64 umax64(u64 a, u64 b) { return a > b ? a : b; }
+
+// max over each 16-lane row, result in every lane of the row
+__device__ __forceinline__ u64 row_max64(u64 v) {
+  v = umax64(v, dpp_mov64<0xB1>(v));   // quad_perm [1,0,3,2]
+  v = umax64(v, dpp_mov64<0x4E>(v));   // quad_perm [2,3,0,1]
+  v = umax64(v, dpp_mov64<0x141>(v));  // row_half_mirror
+  v = umax64(v, dpp_mov64<0x140>(v));  // row_mirror
+  return v;
+}
+__device__ __forceinline__ u64 readlane64(u64 v, int lane) {
+  unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, lane);
+  unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), lane);
+  return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ u64 wave_max64(u64 v) {
+  v = row_max64(v);
+  u64 a = umax64(readlane64(v, 0), readlane64(v, 16));
+  u64 b = umax64(readlane64(v, 32), readlane64(v, 48));
+  return umax64(a, b);
+}
+
+// ---- farthest point sampling --------------------------------------------------------------------
+// grid B, block = min(1024, roundup64(N)); dynamic LDS = 3*N floats + 2*16 u64 slots.
+template <int PTS>
+__global__ void __launch_bounds__(1024)
+    fps_kernel(const float *__restrict__ xyz, int N, int stride, int npoint, int log2bs,
+               int32_t *__restrict__ idx, float *__restrict__ new_xyz, int new_stride) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  u64 *slots = reinterpret_cast<u64 *>(smem);              // [2][16]
+  float *sx = reinterpret_cast<float *>(smem + 256);       // [N]
+  float *sy = sx + N;
+  float *sz = sy + N;
+
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int nthr = blockDim.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const float *pts = xyz + (size_t)b * N * stride;
+  int32_t *out = idx + (size_t)b * npoint;
+  float *nxyz = new_xyz ? new_xyz + (size_t)b * npoint * new_stride : nullptr;
+  const unsigned bsmask = (1u << log2bs) - 1u;
+
+  float x[PTS], y[PTS], z[PTS], dist[PTS];
+  unsigned keylo[PTS];
+#pragma unroll
+  for (int i = 0; i < PTS; ++i) {
+    const int k = tid + i * nthr;
+    x[i] = y[i] = z[i] = 0.0f;
+    dist[i] = 0.0f;  // a point that may never be picked keeps key == 0
+    keylo[i] = 0u;
+    if (k < N) {
+      x[i] = pts[(size_t)k * stride + 0];
+      y[i] = pts[(size_t)k * stride + 1];
+      z[i] = pts[(size_t)k * stride + 2];
+      sx[k] = x[i];
+      sy[k] = y[i];
+      sz[k] = z[i];
+      const float mag = mpx_fma(z[i], z[i], mpx_fma(y[i], y[i], x[i] * x[i]));
+      if (!(mag <= 1e-3f)) {
+        dist[i] = 1e10f;
+        // tie order of the reference: smaller (k mod bs, k / bs) wins -> larger key wins
+        const unsigned rank = (((unsigned)k & bsmask) << 16) | ((unsigned)k >> log2bs);
+        keylo[i] = 0xFFFFFFFFu - rank;
+      }
+    }
+  }
+  if (tid < 32) slots[tid] = 0;
+  __syncthreads();
+
+  int old = 0;
+  for (int j = 1; j < npoint; ++j) {
+    const float x1 = sx[old], y1 = sy[old], z1 = sz[old];
+    if (tid == 0) {
+      out[j - 1] = old;
+      if (nxyz) {
+        nxyz[(size_t)(j - 1) * new_stride + 0] = x1;
+        nxyz[(size_t)(j - 1) * new_stride + 1] = y1;
+        nxyz[(size_t)(j - 1) * new_stride + 2] = z1;
+      }
+    }
+    u64 best = 0;
+#pragma unroll
+    for (int i = 0; i < PTS; ++i) {
+      const float dx = x[i] - x1, dy = y[i] - y1, dz = z[i] - z1;
+      const float d = mpx_fma(dz, dz, mpx_fma(dy, dy, dx * dx));
+      const float d2 = fminf(d, dist[i]);
+      dist[i] = d2;
+      const u64 key = ((u64)__float_as_uint(d2) << 32) | keylo[i];
+      // keylo == 0 marks "not a candidate" (its dist stays +0, so the whole key is 0)
+      best = umax64(best, keylo[i] ? key : 0);
+    }
+    best = wave_max64(best);
+    u64 *slot = slots + (j & 1) * 16;
+    if (lane == 0) slot[wave] = best;
+    __syncthreads();
+    u64 m = row_max64(slot[lane & 15]);
+    m = readlane64(m, 0);
+    if (m == 0) {
+      old = 0;  // nothing was a candidate: the reference's besti stays 0
+    } else {
+      const unsigned rank = 0xFFFFFFFFu - (unsigned)m;
+      old = (int)(((rank & 0xFFFFu) << log2bs) | (rank >> 16));
+    }
+  }
+  if (tid == 0 && npoint > 0) {
+    out[npoint - 1] = old;
+    if (nxyz) {
+      nxyz[(size_t)(npoint - 1) * new_stride + 0] = sx[old];
+      nxyz[(size_t)(npoint - 1) * new_stride + 1] = sy[old];
+      nxyz[(size_t)(npoint - 1) * new_stride + 2] = sz[old];
+    }
+  }
+}
+
+static int opt_n_threads_log2(int n) {
+  int l = 0;
+  while ((2 << l) <= n && (2 << l) <= 512) ++l;
+  return l;
+}
+
+MPX_EXPORT int mpx_fps(const float *xyz, int B, int N, int stride, int npoint, int32_t *idx, float *new_xyz,
+                       int new_stride, mpx_stream_t stream) {
+  MPX_REQUIRE(B >= 0 && N >= 1 && npoint >= 0 && stride >= 3, "mpx_fps: bad size");
+  MPX_REQUIRE(N <= 8192, "mpx_fps: N = %d > 8192 unsupported", N);
+  MPX_REQUIRE(new_xyz == nullptr || new_stride >= 3, "mpx_fps: new_stride < 3");
+  if (B == 0 || npoint == 0) return 0;
+  const int log2bs = opt_n_threads_log2(N);
+  int block = ((N + 63) / 64) * 64;
+  if (block > 1024) block = 1024;
+  const int pts = (N + block - 1) / block;
+  const size_t lds = 256 + (size_t)3 * N * sizeof(float);
+  dim3 g(B), t(block);
+#define FPS_LAUNCH(P)                                                                                     \
+  do {                                                                                                    \
+    if (lds > 64 * 1024) {                                                                                \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fps_kernel<P>),                   \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
+      MPX_REQUIRE(e == hipSuccess, "mpx_fps: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e)); \
+    }                                                                                                     \
+    hipLaunchKernelGGL(fps_kernel<P>, g, t, lds, mpx_s(stream), xyz, N, stride, npoint, log2bs, idx,      \
+                       new_xyz, new_stride);                                                              \
+  } while (0)
+  switch (pts) {
+    case 1: FPS_LAUNCH(1); break;
+    case 2: FPS_LAUNCH(2); break;
+    case 3: FPS_LAUNCH(3); break;
+    case 4: FPS_LAUNCH(4); break;
+    case 5: FPS_LAUNCH(5); break;
+    case 6: FPS_LAUNCH(6); break;
+    case 7: FPS_LAUNCH(7); break;
+    default: FPS_LAUNCH(8); break;
+  }
+#undef FPS_LAUNCH
+  MPX_LAUNCH_CHECK("mpx_fps");
+}
+
+// ---- ball query ------------------------------------------------------------------------------------
+// One wave per query point; the wave sweeps the cloud 64 points at a time, ballots the hits and
+// compacts them in index order with a prefix popcount.  grid (ceil(npoint/4), B), block 256.
+__global__ void __launch_bounds__(256)
+    ball_query_kernel(const float *__restrict__ new_xyz, int new_stride, const float *__restrict__ xyz,
+                      int stride, int N, int npoint, float radius2, int nsample, int32_t *__restrict__ idx) {
+  const int b = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= npoint) return;
+  const float *c = new_xyz + ((size_t)b * npoint + j) * new_stride;
+  const float cx = c[0], cy = c[1], cz = c[2];
+  const float *pts = xyz + (size_t)b * N * stride;
+  int32_t *out = idx + ((size_t)b * npoint + j) * nsample;
+  int cnt = 0;
+  int first = 0;
+  for (int k0 = 0; k0 < N && cnt < nsample; k0 += 64) {
+    const int k = k0 + lane;
+    bool hit = false;
+    if (k < N) {
+      const float *p = pts + (size_t)k * stride;
+      const float dx = cx - p[0], dy = cy - p[1], dz = cz - p[2];
+      const float d2 = mpx_fma(dz, dz, mpx_fma(dy, dy, dx * dx));
+      hit = d2 < radius2;
+    }
+    const u64 mask = __ballot(hit);
+    if (mask) {
+      if (cnt == 0) first = k0 + (int)__builtin_ctzll(mask);
+      const int pos = cnt + (int)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
+      if (hit && pos < nsample) out[pos] = k;
+      cnt += (int)__builtin_popcountll(mask);
+    }
+  }
+  if (cnt > nsample) cnt = nsample;
+  // remaining slots: the first hit (or 0 if there was none -- the reference's zero-initialised output)
+  for (int l = cnt + lane; l < nsample; l += 64) out[l] = first;
+}
+
+MPX_EXPORT int mpx_ball_query(const float *new_xyz, int new_stride, const float *xyz, int stride, int B, int N,
+                              int npoint, float radius, int nsample, int32_t *idx, mpx_stream_t stream) {
+  MPX_REQUIRE(B >= 0 && N >= 0 && npoint >= 0 && nsample >= 0, "mpx_ball_query: negative size");
+  MPX_REQUIRE(stride >= 3 && new_stride >= 3, "mpx_ball_query: stride < 3");
+  MPX_REQUIRE(B <= 65535, "mpx_ball_query: B > 65535 (slab the batch)");
+  if (B == 0 || npoint == 0 || nsample == 0) return 0;
+  const float r2 = radius * radius;  // float product, like the reference kernel
+  hipLaunchKernelGGL(ball_query_kernel, dim3(cdiv(npoint, 4), B), dim3(256), 0, mpx_s(stream), new_xyz,
+                     new_stride, xyz, stride, N, npoint, r2, nsample, idx);
+  MPX_LAUNCH_CHECK("mpx_ball_query");
+}
+
+// ---- QueryAndGroup, materialised (API parity with the reference's unfused path) ---------------------
+// out [B, 3+C, npoint, nsample]; thread per (j,l) pair, channel loop writes coalesced planes.
+__global__ void __launch_bounds__(256)
+    group_points_kernel(const float *__restrict__ xyz, int stride, const float *__restrict__ new_xyz,
+                        int new_stride, const float *__restrict__ feat, int feat_stride, int C,
+                        const int32_t *__restrict__ idx, int N, int npoint, int nsample, float *__restrict__ out) {
+  const int b = blockIdx.y;
+  const size_t plane = (size_t)npoint * nsample;
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= plane) return;
+  const int j = (int)(e / nsample);
+  const int k = idx[(size_t)b * plane + e];
+  const float *p = xyz + ((size_t)b * N + k) * stride;
+  const float *c = new_xyz + ((size_t)b * npoint + j) * new_stride;
+  float *o = out + (size_t)b * (3 + C) * plane + e;
+  o[0 * plane] = p[0] - c[0];
+  o[1 * plane] = p[1] - c[1];
+  o[2 * plane] = p[2] - c[2];
+  if (C > 0) {
+    const float *f = feat + ((size_t)b * N + k) * feat_stride;
+    for (int ch = 0; ch < C; ++ch) o[(size_t)(3 + ch) * plane] = f[ch];
+  }
+}
+
+MPX_EXPORT int mpx_group_points(const float *xyz, int stride, const float *new_xyz, int new_stride,
+                                const float *feat, int feat_stride, int C, const int32_t *idx, int B, int N,
+                                int npoint, int nsample, float *out, mpx_stream_t stream) {
+  MPX_REQUIRE(B >= 0 && B <= 65535 && C >= 0, "mpx_group_points: bad size");
+  if (B == 0 || npoint == 0 || nsample == 0) return 0;
+  hipLaunchKernelGGL(group_points_kernel, dim3(cdiv((int64_t)npoint * nsample, 256), B), dim3(256), 0,
+                     mpx_s(stream), xyz, stride, new_xyz, new_stride, feat, feat_stride, C, idx, N, npoint,
+                     nsample, out);
+  MPX_LAUNCH_CHECK("mpx_group_points");
+}

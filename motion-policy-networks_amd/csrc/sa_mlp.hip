@@ -1,0 +1,336 @@
+// sa_mlp.hip -- fused QueryAndGroup + shared MLP (3 x [1x1 conv + ReLU]) + neighbourhood max-pool,
+// i.e. the body of pointnet2_ops' PointnetSAModule.forward as the reference configures it
+// (/root/reference/mpinets/model.py:366-382: SA1 mlp [1(+3),64,64,64], SA2 mlp [64(+3),128,128,256],
+// bn=False, nsample 128).  The reference materialises the grouped tensor [B,3+C,npoint,nsample] and
+// every activation in HBM (16.8 MB per environment per SA1 layer); here nothing but the pooled
+// [npoint, c3] rows is written.
+//
+// CDNA4 mapping (exact-fp32 matrix cores, v_mfma_f32_32x32x2_f32):
+//   * one wave owns one query point and walks its neighbourhood 32 points at a time;
+//   * layers 1 and 2 are computed as  H^T = W . X^T  (A operand = weights, B operand = activations):
+//     the 32x32 result tile then has the POINT on the lane axis (col = lane&31) and the output
+//     channels on the register axis (row = (r&3) + 8*(r>>2) + 4*(lane>>5)) -- which is already the
+//     B-operand layout of the next layer if the k-steps walk the input channels in that same
+//     (register, half) order.  So activations never leave registers, never move across lanes and
+//     need no LDS: k-step t of a layer whose input came from tile `it` register `r` simply feeds
+//     acc[it][r].  The weight stream is packed on the host side (mpx_sa_pack_weights) in exactly the
+//     order the k-steps consume it: one float per lane per MFMA, fetched 4 steps at a time (16 B).
+//   * the last layer flips roles (A = activations, B = weights) so that the POINTS land on the
+//     register axis: the max-pool over the neighbourhood is then an in-lane max over 16 registers,
+//     one cross-half exchange at the very end, and bias + ReLU are applied after pooling
+//     (max and x -> relu(x + b) commute).
+// The kernel is bound by the fp32 MFMA pipe (64 cycles per 32x32x2 on each SIMD; 157 TFLOP/s chip
+// peak): per neighbourhood tile SA1 issues 132 and SA2 904 MFMAs while loading 2 KB of weights per
+// 8 MFMAs from L1/L2 -- 16 B/clk/CU.  Summation order differs from a plain dot product (k walks the
+// register order above), which is the only numerical difference to the oracle.
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define PAD_CH (-1)
+
+template <int CF, int C1, int C2, int C3>
+struct SaCfg {
+  static_assert(CF == 1 || CF % 2 == 0, "feature channels must be 1 or even");
+  static_assert(C1 % 32 == 0 && C2 % 32 == 0 && C3 % 32 == 0, "layer widths must be multiples of 32");
+  static constexpr int CIN = 3 + CF;
+  static constexpr int KS0 = (CF == 1) ? 2 : 2 + CF / 2;  // k-steps of layer 1
+  static constexpr int KS1 = C1 / 2, KS2 = C2 / 2;        // k-steps of layers 2, 3
+  static constexpr int OT1 = C1 / 32, OT2 = C2 / 32, OT3 = C3 / 32;
+  static constexpr int S1 = KS0 * OT1, S2 = KS1 * OT2, S3 = OT3 * KS2;  // MFMA steps per layer
+  static_assert(S1 % 4 == 0 && S2 % 4 == 0 && S3 % 4 == 0, "steps are fetched four at a time");
+  static constexpr int64_t W1_OFF = 0, W2_OFF = (int64_t)S1 * 64, W3_OFF = W2_OFF + (int64_t)S2 * 64;
+  static constexpr int64_t B1_OFF = W3_OFF + (int64_t)S3 * 64, B2_OFF = B1_OFF + C1, B3_OFF = B2_OFF + C2;
+  static constexpr int64_t TOTAL = B3_OFF + C3;
+
+  // input channel consumed by k-step t on lane-half h, for each layer
+  __host__ __device__ static int chan0(int t, int h) {
+    if (CF == 1) return 2 * t + h;  // (dx,dy), (dz,label)
+    if (t == 0) return h;           // (dx,dy)
+    if (t == 1) return h ? PAD_CH : 2;  // (dz, -)
+    return 3 + h * (CF / 2) + (t - 2);  // each half streams a contiguous half of the feature row
+  }
+  __host__ __device__ static int chan_tile(int t, int h) {
+    const int it = t >> 4, r = t & 15;
+    return it * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+  }
+};
+
+// ---- weight packing ----------------------------------------------------------------------------------
+template <class Cfg>
+__global__ void __launch_bounds__(256)
+    sa_pack_kernel(const float *__restrict__ w1, const float *__restrict__ b1, const float *__restrict__ w2,
+                   const float *__restrict__ b2, const float *__restrict__ w3, const float *__restrict__ b3,
+                   int c1, int c2, int c3, float *__restrict__ wpack) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= Cfg::TOTAL) return;
+  float v;
+  if (e >= Cfg::B1_OFF) {
+    const int64_t i = e - Cfg::B1_OFF;
+    v = i < c1 ? b1[i] : (i < c1 + c2 ? b2[i - c1] : b3[i - c1 - c2]);
+  } else {
+    // element (group g of 4 steps, lane, step-in-group)
+    int layer;
+    int64_t r = e;
+    if (r >= Cfg::W3_OFF) { layer = 3; r -= Cfg::W3_OFF; }
+    else if (r >= Cfg::W2_OFF) { layer = 2; r -= Cfg::W2_OFF; }
+    else { layer = 1; }
+    const int s = (int)(r / 256) * 4 + (int)(r & 3);
+    const int lane = (int)((r >> 2) & 63);
+    const int h = lane >> 5, o32 = lane & 31;
+    int t, ot, in, cin;
+    const float *w;
+    if (layer == 1) { t = s / Cfg::OT1; ot = s % Cfg::OT1; in = Cfg::chan0(t, h); cin = Cfg::CIN; w = w1; }
+    else if (layer == 2) { t = s / Cfg::OT2; ot = s % Cfg::OT2; in = Cfg::chan_tile(t, h); cin = c1; w = w2; }
+    else { ot = s / Cfg::KS2; t = s % Cfg::KS2; in = Cfg::chan_tile(t, h); cin = c2; w = w3; }
+    v = in == PAD_CH ? 0.0f : w[(size_t)(ot * 32 + o32) * cin + in];
+  }
+  wpack[e] = v;
+}
+
+// ---- the fused kernel ----------------------------------------------------------------------------------
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// 16-byte buffer load: wave-uniform descriptor + scalar byte offset + per-lane byte offset.  All
+// address arithmetic stays on the scalar unit (no 64-bit VGPR pointers to keep alive or spill).
+__device__ __forceinline__ float4 bload16(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff) {
+  const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
+  return make_float4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w));
+}
+
+__device__ __forceinline__ f32x16 bias_tile(__amdgpu_buffer_rsrc_t rsrc, int bias_off_bytes, int ot, int half) {
+  // register r of a tile holds channel ot*32 + (r&3) + 8*(r>>2) + 4*half
+  f32x16 v;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const float4 q = bload16(rsrc, half * 16, bias_off_bytes + (ot * 32 + 8 * g) * 4);
+    v[4 * g + 0] = q.x;
+    v[4 * g + 1] = q.y;
+    v[4 * g + 2] = q.z;
+    v[4 * g + 3] = q.w;
+  }
+  return v;
+}
+
+__device__ __forceinline__ float comp(const float4 &q, int i) {
+  return i == 0 ? q.x : (i == 1 ? q.y : (i == 2 ? q.z : q.w));
+}
+
+
+// Streams NG float4 weight groups (one per 4 MFMA steps) through a two-deep register ring:
+// chunk c+1 is in flight while chunk c feeds the matrix pipe.  The empty asm statements are
+// compiler barriers for memory operations only -- without them hipcc hoists every load of the
+// fully unrolled layer to its top and spills.
+template <int NG, class F>
+__device__ __forceinline__ void stream_weights(__amdgpu_buffer_rsrc_t rsrc, int voff, int base, F &&body) {
+  constexpr int CH = 4;
+  constexpr int NC = (NG + CH - 1) / CH;
+  float4 buf[2][CH];
+#pragma unroll
+  for (int u = 0; u < CH; ++u)
+    if (u < NG) buf[0][u] = bload16(rsrc, voff, base + u * 1024);
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    if (c + 1 < NC) {
+#pragma unroll
+      for (int u = 0; u < CH; ++u)
+        if ((c + 1) * CH + u < NG) buf[(c + 1) & 1][u] = bload16(rsrc, voff, base + ((c + 1) * CH + u) * 1024);
+    }
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int u = 0; u < CH; ++u)
+      if (c * CH + u < NG) body(c * CH + u, buf[c & 1][u]);
+  }
+}
+
+template <int CF, int C1, int C2, int C3>
+__global__ void __launch_bounds__(256, 2)
+    sa_mlp_kernel(const float *__restrict__ xyz, int stride, const float *__restrict__ new_xyz, int new_stride,
+                  const float *__restrict__ feat, int feat_stride, const int32_t *__restrict__ idx,
+                  int64_t n_query, int N, int npoint, int nsample, const float *__restrict__ wpack,
+                  float *__restrict__ out, int out_stride) {
+  using Cfg = SaCfg<CF, C1, C2, C3>;
+  const int lane = threadIdx.x & 63;
+  const int half = lane >> 5, col = lane & 31;
+  const int64_t qid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (qid >= n_query) return;  // wave-uniform
+  const int64_t b = qid / npoint;
+
+  const __amdgpu_buffer_rsrc_t wrsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(wpack), 0, (int)(Cfg::TOTAL * 4), 0x00020000);
+  const int wvoff = lane * 16;
+  const float *bias3 = wpack + Cfg::B3_OFF;
+
+  const float *ctr = new_xyz + qid * new_stride;
+  const float cx = ctr[0], cy = ctr[1], cz = ctr[2];
+  const int32_t *nbr = idx + qid * nsample;
+  const float *cloud = xyz + b * N * (int64_t)stride;
+  const float *fbase = feat + b * N * (int64_t)feat_stride;
+
+  float omax[Cfg::OT3];
+#pragma unroll
+  for (int ot = 0; ot < Cfg::OT3; ++ot) omax[ot] = -__builtin_inff();
+
+  for (int rt = 0; rt < nsample; rt += 32) {
+    // Loop-invariant buffer offsets are laundered through an empty asm each iteration: otherwise LICM
+    // hoists the (invariant) bias and first-chunk weight loads out of the loop and they are spilled.
+    int w1o = (int)Cfg::W1_OFF * 4, w2o = (int)Cfg::W2_OFF * 4, w3o = (int)Cfg::W3_OFF * 4;
+    int b1o = (int)Cfg::B1_OFF * 4, b2o = (int)Cfg::B2_OFF * 4;
+    asm volatile("" : "+s"(w1o), "+s"(w2o), "+s"(w3o), "+s"(b1o), "+s"(b2o));
+    const int k = nbr[rt + col];
+    const float *p = cloud + (int64_t)k * stride;
+    const float *f = fbase + (int64_t)k * feat_stride;
+
+    // ---- layer-1 B operands: this lane's half of its point's input vector ---------------------------
+    float x0[Cfg::KS0];
+    {
+      const float dx = p[0] - cx, dy = p[1] - cy, dz = p[2] - cz;
+      x0[0] = half ? dy : dx;
+      if (CF == 1) {
+        x0[1] = half ? f[0] : dz;
+      } else {
+        x0[1] = half ? 0.0f : dz;
+        const float4 *fr = reinterpret_cast<const float4 *>(f + half * (CF / 2));
+#pragma unroll
+        for (int i = 0; i < CF / 8; ++i) {
+          const float4 v = fr[i];
+          x0[2 + 4 * i + 0] = v.x;
+          x0[2 + 4 * i + 1] = v.y;
+          x0[2 + 4 * i + 2] = v.z;
+          x0[2 + 4 * i + 3] = v.w;
+        }
+      }
+    }
+
+    // ---- layer 1: H1^T = W1 . X^T --------------------------------------------------------------------
+    f32x16 a1[Cfg::OT1];
+#pragma unroll
+    for (int ot = 0; ot < Cfg::OT1; ++ot) a1[ot] = bias_tile(wrsrc, b1o, ot, half);
+    stream_weights<Cfg::S1 / 4>(wrsrc, wvoff, w1o, [&](int g, const float4 &w) __attribute__((always_inline)) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int s = 4 * g + u, t = s / Cfg::OT1, ot = s % Cfg::OT1;
+        a1[ot] = mfma32(comp(w, u), x0[t], a1[ot]);
+      }
+    });
+#pragma unroll
+    for (int ot = 0; ot < Cfg::OT1; ++ot)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a1[ot][r] = fmaxf(a1[ot][r], 0.0f);
+
+    // ---- layer 2: H2^T = W2 . H1^T ---------------------------------------------------------------------
+    f32x16 a2[Cfg::OT2];
+#pragma unroll
+    for (int ot = 0; ot < Cfg::OT2; ++ot) a2[ot] = bias_tile(wrsrc, b2o, ot, half);
+    stream_weights<Cfg::S2 / 4>(wrsrc, wvoff, w2o, [&](int g, const float4 &w) __attribute__((always_inline)) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int s = 4 * g + u, t = s / Cfg::OT2, ot = s % Cfg::OT2;
+        a2[ot] = mfma32(comp(w, u), a1[t >> 4][t & 15], a2[ot]);
+      }
+    });
+#pragma unroll
+    for (int ot = 0; ot < Cfg::OT2; ++ot)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a2[ot][r] = fmaxf(a2[ot][r], 0.0f);
+
+    // ---- layer 3 (roles flipped): H3 = H2 . W3^T, then max over this tile's 32 points -------------------
+    {
+      f32x16 a3;
+      constexpr int GPT = Cfg::KS2 / 4;  // weight groups per output tile
+      stream_weights<Cfg::S3 / 4>(wrsrc, wvoff, w3o, [&](int g, const float4 &w) __attribute__((always_inline)) {
+        const int ot = g / GPT, gg = g % GPT;
+        if (gg == 0) a3 = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int t = 4 * gg + u;
+          a3 = mfma32(a2[t >> 4][t & 15], comp(w, u), a3);
+        }
+        if (gg == GPT - 1) {
+          float m = a3[0];
+#pragma unroll
+          for (int r = 1; r < 16; ++r) m = fmaxf(m, a3[r]);
+          omax[ot] = fmaxf(omax[ot], m);
+        }
+      });
+    }
+  }
+
+  // ---- pooled row: combine the two halves (they hold disjoint points), bias, ReLU, store ----------------
+  float *orow = out + qid * out_stride;
+#pragma unroll
+  for (int ot = 0; ot < Cfg::OT3; ++ot) {
+    float v = omax[ot];
+    v = fmaxf(v, __shfl_xor(v, 32));
+    const int ch = ot * 32 + col;
+    v = fmaxf(v + bias3[ch], 0.0f);
+    if (half == 0) orow[ch] = v;
+  }
+}
+
+// ---- host entry points -----------------------------------------------------------------------------------
+template <int CF, int C1, int C2, int C3>
+static int launch_sa(const float *xyz, int stride, const float *new_xyz, int new_stride, const float *feat,
+                     int feat_stride, const int32_t *idx, int B, int N, int npoint, int nsample,
+                     const float *wpack, float *out, int out_stride, mpx_stream_t stream) {
+  const int64_t nq = (int64_t)B * npoint;
+  MPX_REQUIRE(nq / 4 + 1 < ((int64_t)1 << 31), "mpx_sa_mlp: too many query points");
+  hipLaunchKernelGGL((sa_mlp_kernel<CF, C1, C2, C3>), dim3((unsigned)((nq + 3) / 4)), dim3(256), 0,
+                     mpx_s(stream), xyz, stride, new_xyz, new_stride, feat, feat_stride, idx, nq, N, npoint,
+                     nsample, wpack, out, out_stride);
+  MPX_LAUNCH_CHECK("mpx_sa_mlp");
+}
+
+#define SA_DISPATCH(CALL)                                                          \
+  if (C == 1 && c1 == 64 && c2 == 64 && c3 == 64) { CALL(1, 64, 64, 64); }         \
+  else if (C == 64 && c1 == 128 && c2 == 128 && c3 == 256) { CALL(64, 128, 128, 256); } \
+  else {                                                                           \
+    mpx_set_error("mpx_sa: unsupported MLP (C=%d, %d, %d, %d)", C, c1, c2, c3);    \
+    return 1;                                                                      \
+  }
+
+MPX_EXPORT int mpx_sa_mlp(const float *xyz, int stride, const float *new_xyz, int new_stride,
+                          const float *feat, int feat_stride, int C, const int32_t *idx, int B, int N,
+                          int npoint, int nsample, const float *wpack, int c1, int c2, int c3, float *out,
+                          int out_stride, mpx_stream_t stream) {
+  MPX_REQUIRE(B >= 0 && N >= 1 && npoint >= 0, "mpx_sa_mlp: bad size");
+  MPX_REQUIRE(nsample > 0 && nsample % 32 == 0, "mpx_sa_mlp: nsample must be a positive multiple of 32");
+  MPX_REQUIRE(stride >= 3 && new_stride >= 3 && out_stride >= c3, "mpx_sa_mlp: bad stride");
+  MPX_REQUIRE(C == 1 || (feat_stride % 4 == 0 && ((uintptr_t)feat & 15) == 0),
+              "mpx_sa_mlp: feature rows must be 16-byte aligned");
+  MPX_REQUIRE(((uintptr_t)wpack & 15) == 0, "mpx_sa_mlp: wpack must be 16-byte aligned");
+  if (B == 0 || npoint == 0) return 0;
+#define CALL(a, b, c, d) \
+  return launch_sa<a, b, c, d>(xyz, stride, new_xyz, new_stride, feat, feat_stride, idx, B, N, npoint, nsample, wpack, out, out_stride, stream)
+  SA_DISPATCH(CALL)
+#undef CALL
+}
+
+MPX_EXPORT int64_t mpx_sa_pack_size(int C, int c1, int c2, int c3) {
+#define CALL(a, b, c, d) return SaCfg<a, b, c, d>::TOTAL
+  if (C == 1 && c1 == 64 && c2 == 64 && c3 == 64) { CALL(1, 64, 64, 64); }
+  else if (C == 64 && c1 == 128 && c2 == 128 && c3 == 256) { CALL(64, 128, 128, 256); }
+#undef CALL
+  return -1;
+}
+
+template <int CF, int C1, int C2, int C3>
+static int launch_pack(const float *w1, const float *b1, const float *w2, const float *b2, const float *w3,
+                       const float *b3, float *wpack, mpx_stream_t stream) {
+  using Cfg = SaCfg<CF, C1, C2, C3>;
+  hipLaunchKernelGGL(sa_pack_kernel<Cfg>, dim3(cdiv(Cfg::TOTAL, 256)), dim3(256), 0, mpx_s(stream), w1, b1, w2,
+                     b2, w3, b3, C1, C2, C3, wpack);
+  MPX_LAUNCH_CHECK("mpx_sa_pack_weights");
+}
+
+MPX_EXPORT int mpx_sa_pack_weights(const float *w1, const float *b1, const float *w2, const float *b2,
+                                   const float *w3, const float *b3, int C, int c1, int c2, int c3,
+                                   float *wpack, mpx_stream_t stream) {
+#define CALL(a, b, c, d) return launch_pack<a, b, c, d>(w1, b1, w2, b2, w3, b3, wpack, stream)
+  SA_DISPATCH(CALL)
+#undef CALL
+}

@@ -1,0 +1,115 @@
+"""ctypes binding of libmpinets_hip.so (the C-ABI declared in include/mpinets_hip.h).
+
+There is no CPU fallback: if the library is missing, fails to load, or a call returns non-zero,
+an exception is raised.  PyTorch is used only for device memory and streams -- tensors are passed
+as raw device pointers and every call is enqueued on torch's current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+from typing import Optional
+
+import torch  # noqa: F401  (must be imported first: it loads the HIP runtime the library binds to)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmpinets_hip.so")
+
+P, I, F, L = c_void_p, c_int, c_float, c_int64
+
+# name -> argtypes (the trailing stream argument included); restype is int unless listed below
+PROTOTYPES = {
+    "mpx_version": [],
+    "mpx_device_info": [c_char_p, I, P, P],
+    "mpx_prim_frames": [P, P, I, P, P],
+    "mpx_cuboid_sdf": [P, P, I, I, P, I, P, P],
+    "mpx_cylinder_sdf": [P, P, P, I, I, P, I, P, P],
+    "mpx_sphere_sdf": [P, P, I, I, P, I, P, P],
+    "mpx_franka_fk": [P, I, F, P, P],
+    "mpx_franka_cloud": [P, I, F, P, P, P, I, P, L, I, P],
+    "mpx_pose_cloud": [P, I, P, P, I, P, L, I, P],
+    "mpx_franka_spheres": [P, I, F, P, P, I, P, P],
+    "mpx_franka_collision": [P, I, I, F, P, P, P, I, P, P, I, P, P, P, I, P, P, P],
+    "mpx_joint_step": [P, P, P, I, P, P, P],
+    "mpx_fps": [P, I, I, I, I, P, P, I, P],
+    "mpx_ball_query": [P, I, P, I, I, I, I, F, I, P, P],
+    "mpx_group_points": [P, I, P, I, P, I, I, P, I, I, I, I, P, P],
+    "mpx_sa_mlp": [P, I, P, I, P, I, I, P, I, I, I, I, P, I, I, I, P, I, P],
+    "mpx_sa_pack_size": [I, I, I, I],
+    "mpx_sa_pack_weights": [P, P, P, P, P, P, I, I, I, I, P, P],
+    "mpx_linear": [P, I, P, P, I, I, I, I, P, I, P],
+    "mpx_groupnorm_leaky": [P, P, P, I, I, I, F, P, P],
+    "mpx_rowmax": [P, I, I, I, I, P, I, P],
+}
+RESTYPES = {"mpx_last_error": c_char_p, "mpx_sa_pack_size": c_int64}
+
+_lib: Optional[ctypes.CDLL] = None
+
+
+class MpxError(RuntimeError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    """Load the HIP library (raises if it has not been built: run ``__graft_entry__.build()``)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MpxError(
+            f"{LIB_PATH} not found -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C motion-policy-networks_amd/csrc`). There is no CPU fallback."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.mpx_last_error.restype = c_char_p
+    lib.mpx_last_error.argtypes = []
+    for name, argtypes in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError here == header/library mismatch
+        fn.argtypes = argtypes
+        fn.restype = RESTYPES.get(name, c_int)
+    _lib = lib
+    return lib
+
+
+def exported_symbols():
+    """Names the header declares (used by the CPU-side symbol test)."""
+    return ["mpx_last_error"] + list(PROTOTYPES)
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t: Optional[torch.Tensor]):
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def call(name: str, *args):
+    """Call ``name`` with the current torch stream appended; raise on a non-zero status."""
+    lib = load()
+    fn = getattr(lib, name)
+    rc = fn(*args, stream_ptr())
+    if rc != 0:
+        raise MpxError(f"{name} failed ({rc}): {lib.mpx_last_error().decode()}")
+
+
+def require_cuda(*tensors: Optional[torch.Tensor]):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise MpxError("CPU tensors are not supported by the HIP engine (no CPU fallback)")
+
+
+def f32c(t: torch.Tensor) -> torch.Tensor:
+    """float32 + contiguous (no copy when already so)."""
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def i32c(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != torch.int32:
+        t = t.int()
+    return t if t.is_contiguous() else t.contiguous()

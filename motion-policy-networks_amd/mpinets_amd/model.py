@@ -1,0 +1,266 @@
+"""Policy network and rollouts with the reference's interface (``mpinets/model.py``).
+
+``MotionPolicyNetwork().forward(xyz [B,N,4], q [B,7]) -> [B,7]`` (model.py:75-91), submodule names
+and ``state_dict`` keys identical to the reference (``point_cloud_encoder.SA_modules.{0,1,2}.mlps.0.
+{0,2,4}``, ``point_cloud_encoder.fc_layer.{0,1,3,4,6}``, ``feature_encoder.{0,2,4,6,8}``,
+``decoder.{0,2,4,6}``) so a Lightning checkpoint's ``state_dict`` loads unchanged.
+``TrainingMotionPolicyNetwork.rollout(batch, rollout_length, sampler, unnormalize)`` mirrors
+model.py:128-183 including the in-place ``xyz[:, :P, :3] = samples`` update.
+
+The forward pass never calls torch compute: FPS / ball query / fused grouped MLP / GEMMs /
+GroupNorm all run in ``libmpinets_hip.so`` (fp32 end to end, fp32 MFMA for every contraction).
+``pytorch_lightning`` is not required; the classes are plain ``nn.Module``s.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Optional, Sequence
+
+import torch
+from torch import nn
+
+from . import _lib
+from .pointnet2 import PointnetSAModule, SAWeights, groupnorm_leaky, linear, sa_mlp_fused
+from .utils import unnormalize_franka_joints
+
+ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
+
+
+class MPiNetsPointNet(nn.Module):
+    """PointNet++ encoder of the reference (model.py:355-426)."""
+
+    def __init__(self):
+        super().__init__()
+        self._build_model()
+
+    def _build_model(self):
+        self.SA_modules = nn.ModuleList()
+        self.SA_modules.append(PointnetSAModule(npoint=512, radius=0.05, nsample=128, mlp=[1, 64, 64, 64], bn=False))
+        self.SA_modules.append(PointnetSAModule(npoint=128, radius=0.3, nsample=128, mlp=[64, 128, 128, 256], bn=False))
+        self.SA_modules.append(PointnetSAModule(mlp=[256, 512, 512, 1024], bn=False))
+        self.fc_layer = nn.Sequential(
+            nn.Linear(1024, 4096),
+            nn.GroupNorm(16, 4096),
+            nn.LeakyReLU(inplace=True),
+            nn.Linear(4096, 2048),
+            nn.GroupNorm(16, 2048),
+            nn.LeakyReLU(inplace=True),
+            nn.Linear(2048, 2048),
+        )
+        self._sa3_w0 = None  # first group-all layer with K padded 259 -> 260
+
+    @staticmethod
+    def _break_up_pc(pc: torch.Tensor):
+        xyz = pc[..., 0:3].contiguous()
+        features = pc[..., 3:].transpose(1, 2).contiguous()
+        return xyz, features
+
+    def forward_modules(self, point_cloud: torch.Tensor) -> torch.Tensor:
+        """Module-by-module evaluation exactly in the reference's shape conventions
+        (model.py:409-426); used by tests and by callers that hold their own SA modules."""
+        assert point_cloud.size(2) == 4
+        xyz, features = self._break_up_pc(point_cloud)
+        for module in self.SA_modules:
+            xyz, features = module(xyz, features)
+        return self._fc(features.squeeze(-1))
+
+    def _fc(self, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        fc = self.fc_layer
+        h = linear(x, fc[0].weight, fc[0].bias)
+        h = groupnorm_leaky(h, fc[1].weight, fc[1].bias, fc[1].num_groups, fc[1].eps, out=h)
+        h = linear(h, fc[3].weight, fc[3].bias)
+        h = groupnorm_leaky(h, fc[4].weight, fc[4].bias, fc[4].num_groups, fc[4].eps, out=h)
+        return linear(h, fc[6].weight, fc[6].bias, out=out)
+
+    def _sa3_first_weight(self) -> torch.Tensor:
+        conv = self.SA_modules[2].convs()[0]
+        key = (conv.weight._version, conv.weight.data_ptr())
+        if self._sa3_w0 is None or self._sa3_w0[0] != key:
+            w = conv.weight.detach().reshape(conv.out_channels, -1)
+            self._sa3_w0 = (key, torch.nn.functional.pad(w, (0, (-w.size(1)) % 4)).contiguous())
+        return self._sa3_w0[1]
+
+    def forward(self, point_cloud: torch.Tensor, out: Optional[torch.Tensor] = None,
+                aux: Optional[dict] = None) -> torch.Tensor:
+        """point_cloud [B,N,4] (x,y,z,label) on the GPU -> [B,2048].
+
+        Engine path: the slab is read in place (stride-4 rows, label column = SA1's feature),
+        features stay point-major between modules, SA2 writes straight into the group-all
+        module's input rows and nothing is transposed.
+        """
+        if not point_cloud.is_cuda:
+            raise _lib.MpxError("CPU tensors not supported (reference: model.py:417)")
+        assert point_cloud.ndim == 3 and point_cloud.size(2) == 4
+        pc = _lib.f32c(point_cloud)
+        B, N, _ = pc.shape
+        dev = pc.device
+        sa1, sa2, sa3 = self.SA_modules
+        lib = _lib
+        # ---- SA1 -------------------------------------------------------------------------------
+        idx1 = torch.empty((B, sa1.npoint), dtype=torch.int32, device=dev)
+        xyz1 = torch.empty((B, sa1.npoint, 3), dtype=torch.float32, device=dev)
+        lib.call("mpx_fps", lib.ptr(pc), B, N, 4, sa1.npoint, lib.ptr(idx1), lib.ptr(xyz1), 3)
+        nbr1 = torch.empty((B, sa1.npoint, sa1.nsample), dtype=torch.int32, device=dev)
+        lib.call("mpx_ball_query", lib.ptr(xyz1), 3, lib.ptr(pc), 4, B, N, sa1.npoint, float(sa1.radius),
+                 sa1.nsample, lib.ptr(nbr1))
+        c1 = sa1.convs()
+        w1 = sa1._packed.get(c1, 1)
+        f1 = torch.empty((B, sa1.npoint, c1[-1].out_channels), dtype=torch.float32, device=dev)
+        lib.call("mpx_sa_mlp", lib.ptr(pc), 4, lib.ptr(xyz1), 3, lib.ptr(pc) + 12, 4, 1, lib.ptr(nbr1), B, N,
+                 sa1.npoint, sa1.nsample, lib.ptr(w1), c1[0].out_channels, c1[1].out_channels,
+                 c1[2].out_channels, lib.ptr(f1), f1.stride(1))
+        # ---- SA2 (writes into the group-all input rows [xyz2 | f2 | 0]) ----------------------------
+        c2 = sa2.convs()
+        C2o = c2[-1].out_channels
+        K3 = (3 + C2o + 3) // 4 * 4
+        sa3_in = torch.zeros((B, sa2.npoint, K3), dtype=torch.float32, device=dev)
+        idx2 = torch.empty((B, sa2.npoint), dtype=torch.int32, device=dev)
+        lib.call("mpx_fps", lib.ptr(xyz1), B, sa1.npoint, 3, sa2.npoint, lib.ptr(idx2), lib.ptr(sa3_in), K3)
+        nbr2 = torch.empty((B, sa2.npoint, sa2.nsample), dtype=torch.int32, device=dev)
+        lib.call("mpx_ball_query", lib.ptr(sa3_in), K3, lib.ptr(xyz1), 3, B, sa1.npoint, sa2.npoint,
+                 float(sa2.radius), sa2.nsample, lib.ptr(nbr2))
+        w2 = sa2._packed.get(c2, f1.size(2))
+        lib.call("mpx_sa_mlp", lib.ptr(xyz1), 3, lib.ptr(sa3_in), K3, lib.ptr(f1), f1.stride(1), f1.size(2),
+                 lib.ptr(nbr2), B, sa1.npoint, sa2.npoint, sa2.nsample, lib.ptr(w2), c2[0].out_channels,
+                 c2[1].out_channels, C2o, lib.ptr(sa3_in) + 12, K3)
+        # ---- SA3 (group-all): three GEMMs over B*128 rows + max over each environment's rows ------------
+        c3 = sa3.convs()
+        h = sa3_in.view(B * sa2.npoint, K3)
+        h = linear(h, self._sa3_first_weight(), c3[0].bias, ACT_RELU)
+        h = linear(h, c3[1].weight.view(c3[1].out_channels, -1), c3[1].bias, ACT_RELU)
+        h = linear(h, c3[2].weight.view(c3[2].out_channels, -1), c3[2].bias, ACT_RELU)
+        pooled = torch.empty((B, h.size(1)), dtype=torch.float32, device=dev)
+        for b0 in range(0, B, 65535):
+            nb = min(65535, B - b0)
+            lib.call("mpx_rowmax", lib.ptr(h[b0 * sa2.npoint:]), h.stride(0), nb, sa2.npoint, h.size(1),
+                     lib.ptr(pooled[b0:]), pooled.stride(0))
+        if aux is not None:
+            aux.update(fps_idx1=idx1, xyz1=xyz1, ball_idx1=nbr1, f1=f1, fps_idx2=idx2, ball_idx2=nbr2,
+                       sa3_in=sa3_in, f3=pooled)
+        return self._fc(pooled, out=out)
+
+
+class MotionPolicyNetwork(nn.Module):
+    """The default MPiNets architecture (model.py:35-91)."""
+
+    def __init__(self):
+        super().__init__()
+        self.point_cloud_encoder = MPiNetsPointNet()
+        self.feature_encoder = nn.Sequential(
+            nn.Linear(7, 32), nn.LeakyReLU(), nn.Linear(32, 64), nn.LeakyReLU(), nn.Linear(64, 128),
+            nn.LeakyReLU(), nn.Linear(128, 128), nn.LeakyReLU(), nn.Linear(128, 64),
+        )
+        self.decoder = nn.Sequential(
+            nn.Linear(2048 + 64, 512), nn.LeakyReLU(), nn.Linear(512, 256), nn.LeakyReLU(), nn.Linear(256, 128),
+            nn.LeakyReLU(), nn.Linear(128, 7),
+        )
+        self._q_w0 = None
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    def configure_optimizers(self):
+        return torch.optim.Adam(self.parameters(), lr=1e-4)
+
+    @classmethod
+    def load_from_checkpoint(cls, path: str, map_location="cpu", **kwargs):
+        """Reads a Lightning ``.ckpt`` (``{'state_dict': ...}``) or a bare state dict
+        (run_inference.py:262)."""
+        ckpt = torch.load(path, map_location=map_location)
+        sd = ckpt.get("state_dict", ckpt)
+        mdl = cls(**kwargs)
+        mdl.load_state_dict({k: v for k, v in sd.items() if not k.startswith("loss_fun")})
+        return mdl
+
+    def _q_first_weight(self) -> torch.Tensor:
+        lin = self.feature_encoder[0]
+        key = (lin.weight._version, lin.weight.data_ptr())
+        if self._q_w0 is None or self._q_w0[0] != key:
+            self._q_w0 = (key, torch.nn.functional.pad(lin.weight.detach(), (0, 1)).contiguous())
+        return self._q_w0[1]
+
+    def forward(self, xyz: torch.Tensor, q: torch.Tensor, aux: Optional[dict] = None) -> torch.Tensor:
+        """xyz [B,N,4], q [B,7] normalised to [-1,1] -> displacement [B,7] (normalised space)."""
+        if not xyz.is_cuda:
+            raise _lib.MpxError("CPU tensors not supported (reference: model.py:417)")
+        B = xyz.size(0)
+        dev = xyz.device
+        cat = torch.empty((B, 2048 + 64), dtype=torch.float32, device=dev)
+        self.point_cloud_encoder(xyz, out=cat[:, :2048], aux=aux)
+        fe = self.feature_encoder
+        q8 = torch.zeros((B, 8), dtype=torch.float32, device=dev)
+        q8[:, :7] = q
+        h = linear(q8, self._q_first_weight(), fe[0].bias, ACT_LEAKY)
+        h = linear(h, fe[2].weight, fe[2].bias, ACT_LEAKY)
+        h = linear(h, fe[4].weight, fe[4].bias, ACT_LEAKY)
+        h = linear(h, fe[6].weight, fe[6].bias, ACT_LEAKY)
+        linear(h, fe[8].weight, fe[8].bias, ACT_NONE, out=cat[:, 2048:])
+        de = self.decoder
+        h = linear(cat, de[0].weight, de[0].bias, ACT_LEAKY)
+        h = linear(h, de[2].weight, de[2].bias, ACT_LEAKY)
+        h = linear(h, de[4].weight, de[4].bias, ACT_LEAKY)
+        if aux is not None:
+            aux["encoding"] = cat[:, :2048]
+        return linear(h, de[6].weight, de[6].bias, ACT_NONE)
+
+
+class TrainingMotionPolicyNetwork(MotionPolicyNetwork):
+    """Adds the rollout / validation helpers of the reference (model.py:94-318), forward only."""
+
+    def __init__(self, num_robot_points: int, point_match_loss_weight: float = 1.0,
+                 collision_loss_weight: float = 1.0):
+        super().__init__()
+        self.num_robot_points = num_robot_points
+        self.point_match_loss_weight = point_match_loss_weight
+        self.collision_loss_weight = collision_loss_weight
+        self.fk_sampler = None
+        self.collision_sampler = None
+
+    def rollout(self, batch: Dict[str, torch.Tensor], rollout_length: int,
+                sampler: Callable[[torch.Tensor], torch.Tensor], unnormalize: bool = False) -> List[torch.Tensor]:
+        """model.py:128-183: ``q = clamp(q + self(xyz, q), -1, 1)``; resample the robot points at the
+        new configuration and overwrite ``xyz[:, :P, :3]`` in place; returns rollout_length+1 tensors."""
+        xyz, q = batch["xyz"], batch["configuration"]
+        if q.ndim == 1:
+            xyz = xyz.unsqueeze(0)
+            q = q.unsqueeze(0)
+        if unnormalize:
+            q_unnorm = unnormalize_franka_joints(q)
+            assert isinstance(q_unnorm, torch.Tensor)
+            trajectory = [q_unnorm]
+        else:
+            trajectory = [q]
+        for _ in range(rollout_length):
+            q = torch.clamp(q + self(xyz, q), min=-1, max=1)
+            q_unnorm = unnormalize_franka_joints(q).type_as(q)
+            trajectory.append(q_unnorm if unnormalize else q)
+            samples = sampler(q_unnorm).type_as(xyz)
+            xyz[:, : samples.shape[1], :3] = samples
+        return trajectory
+
+    def sample(self, q: torch.Tensor) -> torch.Tensor:
+        assert self.fk_sampler is not None
+        return self.fk_sampler.sample(q, self.num_robot_points)
+
+    @torch.no_grad()
+    def validation_step(self, batch: Dict[str, torch.Tensor], batch_idx: int = 0, rollout_length: int = 69):
+        """model.py:252-318: rollout, final target error, swept-sphere collision rate."""
+        from .geometry import TorchCuboids, TorchCylinders
+        from .robot import FrankaCollisionSampler, FrankaSampler
+
+        dev = batch["xyz"].device
+        if self.fk_sampler is None:
+            self.fk_sampler = FrankaSampler(dev, use_cache=True)
+        if self.collision_sampler is None:
+            self.collision_sampler = FrankaCollisionSampler(dev, with_base_link=False)
+        rollout = self.rollout(batch, rollout_length, self.sample, unnormalize=True)
+        eff = self.fk_sampler.end_effector_pose(rollout[-1])
+        position_error = torch.linalg.vector_norm(eff[:, :3, -1] - batch["target_position"], dim=1)
+        cuboids = TorchCuboids(batch["cuboid_centers"], batch["cuboid_dims"], batch["cuboid_quats"])
+        cylinders = TorchCylinders(batch["cylinder_centers"], batch["cylinder_radii"], batch["cylinder_heights"],
+                                   batch["cylinder_quats"])
+        traj = torch.stack(rollout, dim=1)  # [B, L+1, 7]
+        has_collision = self.collision_sampler.check(traj, cuboids, cylinders)
+        B = traj.size(0)
+        return {"avg_target_error": torch.mean(position_error),
+                "avg_collision_rate": torch.count_nonzero(has_collision) / B}

@@ -1,0 +1,193 @@
+"""PointNet++ op seam: drop-in for ``pointnet2_ops`` as the reference uses it.
+
+Reference call sites: ``from pointnet2_ops.pointnet2_modules import PointnetSAModule``
+(mpinets/model.py:27), constructed at model.py:366-383, called at model.py:423-424 with
+``xyz [B,N,3]`` contiguous and ``features [B,C,N]`` contiguous; returns
+``(new_xyz [B,npoint,3] | None, new_features [B,mlp[-1],npoint])``.  xyz is concatenated before
+the features (3 extra input channels), ``bn=False`` gives Conv2d(bias=True)+ReLU per layer, and the
+state-dict keys are ``mlps.0.{0,2,4}.{weight,bias}`` ([EXT-RECALL]).
+
+All compute runs in ``libmpinets_hip.so``; CPU tensors are rejected like in the reference
+(model.py:417 "CPU tensors not supported").
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import torch
+from torch import nn
+
+from . import _lib
+
+
+# ---- functional ops (pointnet2_utils equivalents) --------------------------------------------------
+def furthest_point_sample(xyz: torch.Tensor, npoint: int, return_xyz: bool = False):
+    """xyz [B,N,3|4] float32 (rows may be slab rows: only the first three columns are read)
+    -> idx int32 [B,npoint] (and new_xyz [B,npoint,3])."""
+    _lib.require_cuda(xyz)
+    assert xyz.ndim == 3 and xyz.size(2) >= 3 and xyz.dtype == torch.float32 and xyz.is_contiguous()
+    B, N, S = xyz.shape
+    idx = torch.empty((B, npoint), dtype=torch.int32, device=xyz.device)
+    new_xyz = torch.empty((B, npoint, 3), dtype=torch.float32, device=xyz.device) if return_xyz else None
+    _lib.call("mpx_fps", _lib.ptr(xyz), B, N, S, npoint, _lib.ptr(idx), _lib.ptr(new_xyz), 3)
+    return (idx, new_xyz) if return_xyz else idx
+
+
+def gather_operation(features: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    """features [B,C,N], idx [B,npoint] -> [B,C,npoint] (index plumbing, torch)."""
+    return torch.gather(features, 2, idx.long().unsqueeze(1).expand(-1, features.size(1), -1))
+
+
+def ball_query(radius: float, nsample: int, xyz: torch.Tensor, new_xyz: torch.Tensor) -> torch.Tensor:
+    """-> idx int32 [B,npoint,nsample] (argument order of pointnet2_utils.ball_query)."""
+    _lib.require_cuda(xyz, new_xyz)
+    assert xyz.is_contiguous() and new_xyz.is_contiguous()
+    B, N, S = xyz.shape
+    npoint = new_xyz.size(1)
+    idx = torch.empty((B, npoint, nsample), dtype=torch.int32, device=xyz.device)
+    _lib.call("mpx_ball_query", _lib.ptr(new_xyz), new_xyz.size(2), _lib.ptr(xyz), S, B, N, npoint,
+              float(radius), nsample, _lib.ptr(idx))
+    return idx
+
+
+def query_and_group(xyz: torch.Tensor, new_xyz: torch.Tensor, features_pm: Optional[torch.Tensor],
+                    idx: torch.Tensor) -> torch.Tensor:
+    """Materialised QueryAndGroup(use_xyz=True): -> [B,3+C,npoint,nsample].
+    ``features_pm`` is point-major [B,N,C]."""
+    B, N, S = xyz.shape
+    npoint, nsample = idx.shape[1:]
+    C = 0 if features_pm is None else features_pm.size(2)
+    out = torch.empty((B, 3 + C, npoint, nsample), dtype=torch.float32, device=xyz.device)
+    _lib.call("mpx_group_points", _lib.ptr(xyz), S, _lib.ptr(new_xyz), new_xyz.size(2), _lib.ptr(features_pm),
+              C if features_pm is None else features_pm.stride(1), C, _lib.ptr(idx), B, N, npoint, nsample,
+              _lib.ptr(out))
+    return out
+
+
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], act: int = 0,
+           out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y = act(x @ weight.T + bias) on the fp32 matrix cores.  x [M,K] (row stride may exceed K),
+    weight [N,K].  ``out`` may be a column slice of a wider row-major buffer."""
+    assert x.ndim == 2 and weight.ndim == 2 and x.size(1) == weight.size(1)
+    assert x.stride(1) == 1 and weight.is_contiguous()
+    M, K = x.shape
+    N = weight.size(0)
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    assert out.shape == (M, N) and out.stride(1) == 1
+    _lib.call("mpx_linear", _lib.ptr(x), x.stride(0), _lib.ptr(weight), _lib.ptr(bias), M, N, K, act,
+              _lib.ptr(out), out.stride(0))
+    return out
+
+
+def groupnorm_leaky(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, groups: int, eps: float = 1e-5,
+                    out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    assert x.ndim == 2 and x.is_contiguous()
+    if out is None:
+        out = torch.empty_like(x)
+    _lib.call("mpx_groupnorm_leaky", _lib.ptr(x), _lib.ptr(weight), _lib.ptr(bias), x.size(0), x.size(1), groups,
+              float(eps), _lib.ptr(out))
+    return out
+
+
+class SAWeights:
+    """Packed (MFMA-stream order) weights of one shared MLP, refreshed when parameters change."""
+
+    def __init__(self):
+        self.pack = None
+        self.versions = None
+
+    def get(self, convs: List[nn.Conv2d], C: int) -> torch.Tensor:
+        ver = tuple((c.weight._version, c.bias._version, c.weight.data_ptr()) for c in convs)
+        if self.pack is None or ver != self.versions:
+            c1, c2, c3 = (c.out_channels for c in convs)
+            n = _lib.load().mpx_sa_pack_size(C, c1, c2, c3)
+            if n < 0:
+                raise _lib.MpxError(f"unsupported shared-MLP shape C={C} mlp=({c1},{c2},{c3})")
+            dev = convs[0].weight.device
+            self.pack = torch.empty(n, dtype=torch.float32, device=dev)
+            w = [_lib.f32c(c.weight.detach().reshape(c.out_channels, -1)) for c in convs]
+            b = [_lib.f32c(c.bias.detach()) for c in convs]
+            _lib.call("mpx_sa_pack_weights", _lib.ptr(w[0]), _lib.ptr(b[0]), _lib.ptr(w[1]), _lib.ptr(b[1]),
+                      _lib.ptr(w[2]), _lib.ptr(b[2]), C, c1, c2, c3, _lib.ptr(self.pack))
+            self.versions = ver
+        return self.pack
+
+
+def sa_mlp_fused(xyz: torch.Tensor, new_xyz: torch.Tensor, feat: torch.Tensor, feat_stride: int, C: int,
+                 idx: torch.Tensor, wpack: torch.Tensor, widths: Tuple[int, int, int],
+                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Fused group + MLP + max-pool.  xyz [B,N,S]; new_xyz [B,npoint,S']; feat: tensor whose
+    ``data_ptr`` is the first feature of point 0 with ``feat_stride`` floats between points;
+    -> out [B,npoint,c3] point-major (``out`` may be a column slice of a wider buffer)."""
+    B, N, S = xyz.shape
+    npoint, nsample = idx.shape[1:]
+    c1, c2, c3 = widths
+    if out is None:
+        out = torch.empty((B, npoint, c3), dtype=torch.float32, device=xyz.device)
+    assert out.stride(2) == 1 and out.stride(0) == npoint * out.stride(1)
+    _lib.call("mpx_sa_mlp", _lib.ptr(xyz), S, _lib.ptr(new_xyz), new_xyz.stride(1), _lib.ptr(feat), feat_stride, C,
+              _lib.ptr(idx), B, N, npoint, nsample, _lib.ptr(wpack), c1, c2, c3, _lib.ptr(out), out.stride(1))
+    return out
+
+
+# ---- module -------------------------------------------------------------------------------------------
+class PointnetSAModule(nn.Module):
+    """``PointnetSAModule(npoint=None, radius=None, nsample=None, mlp=[...], bn=False, use_xyz=True)``.
+
+    ``forward(xyz [B,N,3], features [B,C,N]) -> (new_xyz [B,npoint,3] | None, [B,mlp[-1],npoint])``.
+    """
+
+    def __init__(self, *, mlp: List[int], npoint: Optional[int] = None, radius: Optional[float] = None,
+                 nsample: Optional[int] = None, bn: bool = False, use_xyz: bool = True):
+        super().__init__()
+        if bn:
+            raise NotImplementedError("bn=True is not used by the reference (model.py:366-383)")
+        assert use_xyz, "the reference relies on use_xyz=True (3 extra input channels)"
+        self.npoint, self.radius, self.nsample = npoint, radius, nsample
+        spec = list(mlp)
+        spec[0] += 3
+        layers: List[nn.Module] = []
+        for i in range(len(spec) - 1):
+            layers.append(nn.Conv2d(spec[i], spec[i + 1], kernel_size=1, bias=True))
+            layers.append(nn.ReLU(inplace=True))
+        # same container shape as pointnet2_ops: self.mlps = ModuleList([Sequential(conv, relu, ...)])
+        self.mlps = nn.ModuleList([nn.Sequential(*layers)])
+        self._packed = SAWeights()
+
+    def convs(self) -> List[nn.Conv2d]:
+        return [m for m in self.mlps[0] if isinstance(m, nn.Conv2d)]
+
+    def forward(self, xyz: torch.Tensor, features: Optional[torch.Tensor] = None):
+        if not xyz.is_cuda:
+            raise _lib.MpxError("CPU tensors not supported (reference: model.py:417)")
+        xyz = _lib.f32c(xyz)
+        B, N, _ = xyz.shape
+        convs = self.convs()
+        if self.npoint is not None:
+            assert features is not None
+            C = features.size(1)
+            feat_pm = _lib.f32c(features).transpose(1, 2).contiguous()  # [B,N,C] point-major
+            idx, new_xyz = furthest_point_sample(xyz, self.npoint, return_xyz=True)
+            nbr = ball_query(self.radius, self.nsample, xyz, new_xyz)
+            wpack = self._packed.get(convs, C)
+            out = sa_mlp_fused(xyz, new_xyz, feat_pm, C, C, nbr, wpack, tuple(c.out_channels for c in convs))
+            return new_xyz, out.transpose(1, 2).contiguous()
+        # group-all: one "neighbourhood" holding every point, xyz NOT re-centred
+        parts = [xyz]
+        if features is not None:
+            parts.append(_lib.f32c(features).transpose(1, 2))
+        x = torch.cat(parts, dim=2)  # [B,N,3+C]
+        K = x.size(2)
+        Kp = (K + 3) // 4 * 4
+        if Kp != K:
+            x = torch.nn.functional.pad(x, (0, Kp - K))
+        h = x.reshape(B * N, Kp).contiguous()
+        for conv in convs:
+            w = conv.weight.detach().reshape(conv.out_channels, -1)
+            if w.size(1) != h.size(1):
+                w = torch.nn.functional.pad(w, (0, h.size(1) - w.size(1)))
+            h = linear(h, _lib.f32c(w), _lib.f32c(conv.bias.detach()), act=1)
+        pooled = torch.empty((B, h.size(1)), dtype=torch.float32, device=xyz.device)
+        _lib.call("mpx_rowmax", _lib.ptr(h), h.stride(0), B, N, h.size(1), _lib.ptr(pooled), pooled.stride(0))
+        return None, pooled.unsqueeze(-1)

@@ -1,0 +1,178 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol the header declares, host
+logic (tables, joint normalisation, scene-cloud host API) behaves like the reference."""
+import ctypes
+import os
+import random
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "mpinets_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mpx_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from mpinets_amd import _lib
+
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    names = header_symbols()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/mpinets_hip.h but not exported"
+    assert sorted(_lib.exported_symbols()) == names  # the ctypes prototypes cover the whole header
+
+
+def test_library_loads_and_reports_errors_without_gpu():
+    from mpinets_amd import _lib
+
+    lib = _lib.load()
+    assert lib.mpx_version() == 100
+    assert lib.mpx_sa_pack_size(1, 64, 64, 64) == (4 + 64 + 64) * 64 + 3 * 64
+    assert lib.mpx_sa_pack_size(64, 128, 128, 256) == (136 + 256 + 512) * 64 + 128 + 128 + 256
+    assert lib.mpx_sa_pack_size(5, 8, 8, 8) == -1
+    # argument validation happens on the host, before any launch
+    assert lib.mpx_linear(None, 8, None, None, 4, 4, 6, 0, None, 4, None) != 0
+    assert b"multiples of 4" in lib.mpx_last_error()
+    assert lib.mpx_fps(None, 1, 100000, 3, 4, None, None, 3, None) != 0
+    assert b"8192" in lib.mpx_last_error()
+
+
+def test_cpu_tensors_are_rejected_not_silently_computed():
+    from mpinets_amd import _lib
+    from mpinets_amd.model import MotionPolicyNetwork
+    from mpinets_amd.pointnet2 import PointnetSAModule
+
+    with pytest.raises(_lib.MpxError):
+        MotionPolicyNetwork()(torch.zeros(1, 6272, 4), torch.zeros(1, 7))
+    with pytest.raises(_lib.MpxError):
+        PointnetSAModule(npoint=4, radius=0.1, nsample=32, mlp=[1, 64, 64, 64])(torch.zeros(1, 10, 3), torch.zeros(1, 1, 10))
+
+
+def test_joint_normalisation_matches_reference_arithmetic(golden):
+    from mpinets_amd.utils import normalize_franka_joints, unnormalize_franka_joints
+
+    qn = torch.from_numpy(golden["utils/q_norm"])
+    un = unnormalize_franka_joints(qn)
+    np.testing.assert_allclose(un.numpy(), golden["utils/unnormalized"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(normalize_franka_joints(un).numpy(), golden["utils/renormalized"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(unnormalize_franka_joints(golden["utils/q_norm_np64"]),
+                               golden["utils/unnormalized_np64"], rtol=0, atol=1e-12)
+    with pytest.raises(NotImplementedError):
+        normalize_franka_joints([0.0] * 7)
+    with pytest.raises(AssertionError):
+        unnormalize_franka_joints(torch.full((7,), 1.5))  # utils.py:200-201 range assert
+
+
+class _Obstacle:
+    def __init__(self, area, tag):
+        self.surface_area, self.tag, self.calls = area, tag, []
+
+    def sample_surface(self, n):
+        self.calls.append(n)
+        return np.full((n, 3), float(self.tag))
+
+
+def test_construct_mixed_point_cloud_matches_reference_under_same_seed(golden):
+    from mpinets_amd.geometry import construct_mixed_point_cloud
+
+    obs = [_Obstacle(a, i) for i, a in enumerate(golden["mixed/areas"])]
+    random.seed(7)
+    np.random.seed(7)
+    pc = construct_mixed_point_cloud(obs, 4096)
+    assert pc.shape == tuple(golden["mixed/shape"]) and pc.dtype == np.float64
+    np.testing.assert_array_equal([o.calls[0] for o in obs], golden["mixed/alloc"])
+    np.testing.assert_array_equal([pc[pc[:, 0] == i][0, 3] for i in range(len(obs))], golden["mixed/labels"])
+    np.testing.assert_array_equal([(pc[:, 0] == i).sum() for i in range(len(obs))], golden["mixed/counts"])
+    assert construct_mixed_point_cloud([], 4096).shape == tuple(golden["mixed/empty_shape"]) == (1, 0)
+
+
+def test_primitives_sample_on_their_surface():
+    from mpinets_amd.geometry import construct_mixed_point_cloud
+    from mpinets_amd.primitives import Cuboid, Cylinder, Sphere
+
+    np.random.seed(0)
+    random.seed(0)
+    prims = [Cuboid([0.5, 0, 0.2], [0.3, 0.2, 0.4], [0.9, 0.1, 0.2, 0.3]), Cylinder([0, 0.4, 0.1], 0.1, 0.3, [0.7, 0, 0.7, 0]),
+             Sphere([0, 0, 1], 0.2)]
+    for p in prims:
+        assert np.abs(p.sdf(p.sample_surface(500))).max() < 1e-9 and not p.is_zero_volume()
+    pc = construct_mixed_point_cloud(prims, 1024)
+    assert pc.shape == (1024, 4) and set(np.unique(pc[:, 3])) <= {1.0, 2.0, 3.0}
+    assert Cuboid([0, 0, 0], [0.1, 0.0, 0.1]).is_zero_volume() and Cylinder([0, 0, 0], 0.0, 1.0).is_zero_volume()
+
+
+def test_franka_tables_are_consistent():
+    from mpinets_amd import franka_tables as ft
+
+    c, r, l, groups = ft.collision_sphere_table(False)
+    assert c.shape == (56, 3) and len(groups) == 9 and sum(g[2] for g in groups) == 56
+    c2, _, _, g2 = ft.collision_sphere_table(True)
+    assert c2.shape == (57, 3) and len(g2) == 10
+    pts, links = ft.link_point_table()
+    assert pts.shape == (4096, 3) and links.min() >= 0 and links.max() < ft.NUM_FRAMES
+    # every table point lies on the surface of one of its link's spheres and outside the others
+    for name, spheres in ft.COLLISION_SPHERES.items():
+        p = pts[links == ft.LINK_ID[name]].astype(np.float64)
+        d = np.stack([np.linalg.norm(p - np.array(cc), axis=1) - rr for cc, rr in spheres], 1)
+        assert np.abs(d.min(1)).max() < 1e-6
+    assert ft.end_effector_point_table().shape == (512, 3)
+    assert (ft.JOINT_LIMITS_REAL[:, 0] >= ft.JOINT_LIMITS_PUBLISHED[:, 0] - 1.0).all()
+
+
+def test_oracle_fk_geometry(oracle):
+    """Sanity of the (unpinned) FK restatement against hand-derivable poses."""
+    from mpinets_amd import franka_tables as ft
+
+    T = oracle.franka_fk(np.zeros((1, 7), np.float32))[0]
+    # all joints at zero: flange at x = 0.088, z = 0.333 + 0.316 + 0.384 - 0.107
+    np.testing.assert_allclose(T[8, 9:], [0.088, 0.0, 0.333 + 0.316 + 0.384 - 0.107], atol=1e-6)
+    R = T[:, :9].reshape(15, 3, 3)
+    assert np.abs(R @ R.transpose(0, 2, 1) - np.eye(3)).max() < 1e-6
+    # right_gripper is 0.1 along link8's z axis
+    np.testing.assert_allclose(T[14, 9:] - T[8, 9:], R[8] @ np.array([0, 0, 0.1]), atol=1e-6)
+    # fingers are 2 * 0.025 apart
+    np.testing.assert_allclose(np.linalg.norm(T[10, 9:] - T[11, 9:]), 0.05, atol=1e-6)
+    # rotating joint 1 rotates the flange about the world z axis
+    Tq = oracle.franka_fk(np.array([[0.7, 0, 0, 0, 0, 0, 0]], np.float32))[0]
+    c, s = np.cos(0.7), np.sin(0.7)
+    np.testing.assert_allclose(Tq[8, 9:], [c * T[8, 9], s * T[8, 9], T[8, 11]], atol=1e-6)
+
+
+def test_oracle_fps_and_ball_query_properties(oracle):
+    rng = np.random.default_rng(0)
+    x = rng.uniform(-1, 1, (2, 700, 3)).astype(np.float32)
+    idx = oracle.fps(x, 64)
+    assert (idx[:, 0] == 0).all() and all(len(set(r)) == 64 for r in idx)
+    # brute-force restatement (no exact ties in generic random data)
+    for b in range(2):
+        d = np.full(700, 1e10, np.float32)
+        cur, ref = 0, [0]
+        for _ in range(63):
+            diff = x[b] - x[b, cur]
+            dd = (diff[:, 0] * diff[:, 0] + diff[:, 1] * diff[:, 1] + diff[:, 2] * diff[:, 2]).astype(np.float32)
+            d = np.minimum(d, dd)
+            cur = int(np.argmax(d))
+            ref.append(cur)
+        assert (np.array(ref) == idx[b]).mean() > 0.95  # fma rounding may flip a near-tie, not more
+    centres = oracle.gather_points(x, idx)
+    nbr = oracle.ball_query(centres, x, 0.3, 16)
+    d2 = ((x[:, None, :, :] - centres[:, :, None, :]) ** 2).sum(-1)
+    for b in range(2):
+        for j in range(64):
+            inside = np.nonzero(d2[b, j] < np.float32(0.3) ** 2 - 1e-6)[0]
+            k = min(16, len(inside))
+            assert (nbr[b, j, :k] == inside[:k]).all() or len(inside) != (d2[b, j] < 0.09 + 1e-6).sum()
+            assert (nbr[b, j, k:] == nbr[b, j, 0]).all() or k == 16
+    # tie order: duplicated points -> the reference prefers the smaller (k mod bs, k)
+    y = np.zeros((1, 1024, 3), np.float32)
+    y[0, :, 0] = 1.0
+    y[0, 600] = [5, 0, 0]
+    y[0, 90] = [5, 0, 0]  # 600 mod 512 = 88 < 90
+    assert oracle.fps(y, 2)[0, 1] == 600

@@ -1,0 +1,92 @@
+"""FPS / ball query / grouping: bit-exact index parity with the oracle (pointnet2_ops semantics)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev())
+
+
+def clouds(B, N, seed, stride=3):
+    rng = np.random.default_rng(seed)
+    x = rng.uniform(-1, 1, (B, N, stride)).astype(np.float32)
+    return x
+
+
+@pytest.mark.parametrize("B,N,npoint,stride", [(3, 6272, 512, 4), (4, 512, 128, 3), (2, 1000, 64, 3),
+                                               (2, 63, 17, 3), (1, 8192, 300, 4), (2, 2500, 100, 3)])
+def test_fps_bit_exact(oracle, B, N, npoint, stride):
+    from mpinets_amd.pointnet2 import furthest_point_sample
+
+    x = clouds(B, N, N + npoint, stride)
+    idx, nx = furthest_point_sample(T(x), npoint, return_xyz=True)
+    ref = oracle.fps(x, npoint)
+    np.testing.assert_array_equal(idx.cpu().numpy(), ref)
+    np.testing.assert_array_equal(nx.cpu().numpy(), oracle.gather_points(x, ref))
+
+
+def test_fps_ties_duplicates_and_skipped_points(oracle):
+    """Exact ties (lattice points, duplicated points) exercise the (k mod bs, k) tie order; points
+    with |p|^2 <= 1e-3 must be skipped; an all-skipped cloud returns zeros."""
+    from mpinets_amd.pointnet2 import furthest_point_sample
+
+    rng = np.random.default_rng(5)
+    g = np.stack(np.meshgrid(*[np.arange(-7, 8)] * 3, indexing="ij"), -1).reshape(-1, 3).astype(np.float32) * 0.125
+    lattice = g[rng.permutation(len(g))][:3000]
+    dup = clouds(1, 1500, 1)[0]
+    dup = np.concatenate([dup, dup[::-1]], 0)  # every point twice
+    near0 = clouds(1, 3000, 2)[0]
+    near0[::3] *= 0.01  # a third of the points inside the skipped ball
+    x = np.stack([lattice, dup, near0])
+    x[2, 0] = [0.001, 0.0, 0.0]  # the start index itself is a skipped point
+    idx = furthest_point_sample(T(x), 256)
+    np.testing.assert_array_equal(idx.cpu().numpy(), oracle.fps(x, 256))
+    z = np.zeros((2, 700, 3), np.float32)
+    z[1] = 0.01
+    np.testing.assert_array_equal(furthest_point_sample(T(z), 9).cpu().numpy(), oracle.fps(z, 9))
+    assert (oracle.fps(z, 9) == 0).all()
+
+
+def test_fps_on_real_slab(oracle):
+    """Scene-like slab rows (robot | scene | target) at the model's sizes."""
+    from mpinets_amd.pointnet2 import furthest_point_sample
+    from mpinets_amd.scenes import make_problem_batch
+
+    prob = make_problem_batch(3, seed=4, device=dev(), kinds=("tabletop", "cubby", "dresser"), M1=40)
+    xyz = prob["xyz"]
+    idx = furthest_point_sample(xyz, 512)
+    np.testing.assert_array_equal(idx.cpu().numpy(), oracle.fps(xyz.cpu().numpy(), 512))
+
+
+@pytest.mark.parametrize("B,N,npoint,radius,nsample,stride", [(2, 6272, 512, 0.05, 128, 4), (3, 512, 128, 0.3, 128, 3),
+                                                              (2, 700, 50, 0.4, 32, 3), (1, 100, 10, 5.0, 64, 3)])
+def test_ball_query_bit_exact(oracle, B, N, npoint, radius, nsample, stride):
+    from mpinets_amd.pointnet2 import ball_query
+
+    x = clouds(B, N, 17 + N, stride)
+    x[..., :3] *= 0.5
+    centres = np.ascontiguousarray(x[:, :npoint, :3]).copy()
+    centres[:, -1] = 50.0  # a query with no neighbour at all -> zeros
+    idx = ball_query(radius, nsample, T(x), T(centres))
+    ref = oracle.ball_query(centres, x, radius, nsample)
+    np.testing.assert_array_equal(idx.cpu().numpy(), ref)
+    assert (ref[:, -1] == 0).all()
+
+
+def test_group_points_matches_oracle(oracle):
+    from mpinets_amd.pointnet2 import ball_query, furthest_point_sample, query_and_group
+
+    x = clouds(2, 900, 3)
+    feat = np.random.default_rng(1).normal(size=(2, 5, 900)).astype(np.float32)
+    idx, nx = furthest_point_sample(T(x), 40, return_xyz=True)
+    nbr = ball_query(0.4, 32, T(x), nx)
+    got = query_and_group(T(x), nx, T(np.ascontiguousarray(feat.transpose(0, 2, 1))), nbr)
+    ref = oracle.group_points(x, nx.cpu().numpy(), feat, nbr.cpu().numpy())
+    np.testing.assert_array_equal(got.cpu().numpy(), ref)

@@ -1,0 +1,197 @@
+"""Grouped MLP, dense layers, full policy forward and rollout vs the numpy oracle (fp32, 1e-5)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5  # BASELINE.json: "fp32 SDF and policy deltas within 1e-5"
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev())
+
+
+def test_mfma_operand_layout_probe():
+    """mpx_linear on asymmetric data: catches a transposed / mis-mapped MFMA fragment."""
+    from mpinets_amd.pointnet2 import linear
+
+    rng = np.random.default_rng(0)
+    for (M, N, K) in [(32, 32, 16), (128, 128, 16), (130, 7, 8), (257, 200, 260), (5, 4096, 1024), (1000, 64, 2112)]:
+        x = rng.normal(size=(M, K)).astype(np.float32)
+        w = rng.normal(size=(N, K)).astype(np.float32)
+        b = rng.normal(size=N).astype(np.float32)
+        for act in (0, 1, 2):
+            y = linear(T(x), T(w), T(b), act).cpu().numpy()
+            ref = x.astype(np.float64) @ w.astype(np.float64).T + b
+            if act == 1:
+                ref = np.maximum(ref, 0)
+            if act == 2:
+                ref = np.where(ref >= 0, ref, 0.01 * ref)
+            scale = np.sqrt(K)
+            assert np.abs(y - ref).max() <= 3e-6 * scale, (M, N, K, act, np.abs(y - ref).max())
+
+
+def test_linear_strided_output_and_input():
+    from mpinets_amd.pointnet2 import linear
+
+    rng = np.random.default_rng(1)
+    xw = T(rng.normal(size=(70, 40)).astype(np.float32))
+    w = T(rng.normal(size=(24, 32)).astype(np.float32))
+    out = torch.full((70, 100), -5.0, device=dev())
+    linear(xw[:, :32], w, None, 0, out=out[:, 8:32])
+    ref = xw[:, :32].double() @ w.double().T
+    assert (out[:, 8:32].double() - ref).abs().max() < 1e-4
+    assert (out[:, :8] == -5).all() and (out[:, 32:] == -5).all()
+
+
+def test_groupnorm_leaky_and_rowmax(oracle):
+    from mpinets_amd import _lib
+    from mpinets_amd.pointnet2 import groupnorm_leaky
+
+    rng = np.random.default_rng(2)
+    for C in (4096, 2048, 64):
+        x = (rng.normal(size=(9, C)) * 3 + 1).astype(np.float32)
+        g, b = rng.normal(size=C).astype(np.float32), rng.normal(size=C).astype(np.float32)
+        y = groupnorm_leaky(T(x), T(g), T(b), 16).cpu().numpy()
+        ref = oracle._leaky(oracle._group_norm(x, 16, g, b))
+        np.testing.assert_allclose(y, ref, rtol=0, atol=2e-5)
+    x = rng.normal(size=(6 * 128, 300)).astype(np.float32)
+    tx = T(x)
+    y = torch.empty(6, 300, device=dev())
+    _lib.call("mpx_rowmax", _lib.ptr(tx), 300, 6, 128, 300, _lib.ptr(y), 300)
+    np.testing.assert_array_equal(y.cpu().numpy(), x.reshape(6, 128, 300).max(1))
+
+
+def _sa_inputs(B, N, C, npoint, radius, seed):
+    rng = np.random.default_rng(seed)
+    xyz = (rng.uniform(-1, 1, (B, N, 3)) * 0.5).astype(np.float32)
+    feat = rng.normal(size=(B, C, N)).astype(np.float32)
+    return xyz, feat
+
+
+@pytest.mark.parametrize("cfg", [dict(C=1, mlp=[1, 64, 64, 64], N=3000, npoint=64, radius=0.12),
+                                 dict(C=64, mlp=[64, 128, 128, 256], N=512, npoint=32, radius=0.3)])
+def test_sa_module_matches_oracle(oracle, cfg):
+    """PointnetSAModule drop-in: (new_xyz, new_features) vs the oracle's unfused restatement."""
+    from mpinets_amd.pointnet2 import PointnetSAModule
+
+    torch.manual_seed(7)
+    mod = PointnetSAModule(npoint=cfg["npoint"], radius=cfg["radius"], nsample=128, mlp=list(cfg["mlp"]), bn=False).to(dev())
+    xyz, feat = _sa_inputs(2, cfg["N"], cfg["C"], cfg["npoint"], cfg["radius"], 3)
+    with torch.no_grad():
+        nx, nf = mod(T(xyz), T(feat))
+    layers = [(c.weight.detach().cpu().numpy(), c.bias.detach().cpu().numpy()) for c in mod.convs()]
+    onx, onf, _ = oracle.sa_module(xyz, feat, cfg["npoint"], cfg["radius"], 128, layers)
+    np.testing.assert_array_equal(nx.cpu().numpy(), onx)
+    assert nf.shape == (2, cfg["mlp"][-1], cfg["npoint"])
+    np.testing.assert_allclose(nf.cpu().numpy(), onf, rtol=1e-5, atol=TOL)
+
+
+def test_group_all_module_matches_oracle(oracle):
+    from mpinets_amd.pointnet2 import PointnetSAModule
+
+    torch.manual_seed(8)
+    mod = PointnetSAModule(mlp=[256, 512, 512, 1024], bn=False).to(dev())
+    xyz, feat = _sa_inputs(3, 128, 256, None, None, 4)
+    with torch.no_grad():
+        nx, nf = mod(T(xyz), T(feat))
+    layers = [(c.weight.detach().cpu().numpy(), c.bias.detach().cpu().numpy()) for c in mod.convs()]
+    _, onf, _ = oracle.sa_module(xyz, feat, None, None, None, layers)
+    assert nx is None and nf.shape == (3, 1024, 1)
+    np.testing.assert_allclose(nf.cpu().numpy(), onf, rtol=1e-5, atol=TOL)
+
+
+def _state(mdl):
+    return {k: v.detach().cpu().numpy() for k, v in mdl.state_dict().items()}
+
+
+def test_policy_forward_matches_oracle(oracle):
+    """model.forward(xyz, q): bit-exact FPS / ball-query indices, policy deltas within 1e-5."""
+    from mpinets_amd.model import MotionPolicyNetwork
+    from mpinets_amd.scenes import make_problem_batch
+
+    torch.manual_seed(0)
+    mdl = MotionPolicyNetwork().to(dev()).eval()
+    prob = make_problem_batch(3, seed=1, device=dev(), kinds=("tabletop", "cubby", "dresser"), M1=40)
+    aux = {}
+    with torch.no_grad():
+        dq = mdl(prob["xyz"], prob["q_norm"], aux=aux)
+    odq, oaux = oracle.policy_forward(_state(mdl), prob["xyz"].cpu().numpy(), prob["q_norm"].cpu().numpy())
+    np.testing.assert_array_equal(aux["fps_idx1"].cpu().numpy(), oaux["sa1"]["fps_idx"])
+    np.testing.assert_array_equal(aux["ball_idx1"].cpu().numpy(), oaux["sa1"]["ball_idx"])
+    np.testing.assert_array_equal(aux["fps_idx2"].cpu().numpy(), oaux["sa2"]["fps_idx"])
+    np.testing.assert_array_equal(aux["ball_idx2"].cpu().numpy(), oaux["sa2"]["ball_idx"])
+    np.testing.assert_allclose(aux["f1"].cpu().numpy(), oaux["f1"].transpose(0, 2, 1), rtol=1e-5, atol=TOL)
+    np.testing.assert_allclose(aux["f3"].cpu().numpy(), oaux["f3"][:, :, 0], rtol=1e-5, atol=TOL)
+    np.testing.assert_allclose(aux["encoding"].cpu().numpy(), oaux["encoding"], rtol=1e-4, atol=TOL)
+    err = np.abs(dq.cpu().numpy() - odq).max()
+    print("policy delta max abs err vs oracle: %.3e (|dq| max %.3e)" % (err, np.abs(odq).max()))
+    assert err <= TOL
+    # module-by-module path (reference shape conventions) gives the same encoding
+    with torch.no_grad():
+        enc2 = mdl.point_cloud_encoder.forward_modules(prob["xyz"])
+    np.testing.assert_allclose(enc2.cpu().numpy(), aux["encoding"].cpu().numpy(), rtol=1e-5, atol=TOL)
+
+
+def test_state_dict_keys_and_checkpoint_roundtrip(tmp_path):
+    from mpinets_amd.model import MotionPolicyNetwork
+
+    mdl = MotionPolicyNetwork()
+    keys = set(mdl.state_dict().keys())
+    for k in ("point_cloud_encoder.SA_modules.0.mlps.0.0.weight", "point_cloud_encoder.SA_modules.2.mlps.0.4.bias",
+              "point_cloud_encoder.fc_layer.6.weight", "point_cloud_encoder.fc_layer.4.bias",
+              "feature_encoder.8.weight", "decoder.6.bias"):
+        assert k in keys
+    assert mdl.state_dict()["point_cloud_encoder.SA_modules.0.mlps.0.0.weight"].shape == (64, 4, 1, 1)
+    assert sum(p.numel() for p in mdl.parameters()) == 19068103
+    path = tmp_path / "m.ckpt"
+    torch.save({"state_dict": mdl.state_dict()}, path)
+    m2 = MotionPolicyNetwork.load_from_checkpoint(str(path))
+    for k, v in mdl.state_dict().items():
+        assert torch.equal(v, m2.state_dict()[k])
+
+
+def test_rollout_matches_oracle_and_mutates_slab(oracle):
+    """TrainingMotionPolicyNetwork.rollout (model.py:128-183) for 3 steps vs an oracle loop."""
+    from mpinets_amd import franka_tables as ft
+    from mpinets_amd.model import TrainingMotionPolicyNetwork
+    from mpinets_amd.robot import FrankaSampler
+    from mpinets_amd.scenes import make_problem_batch
+
+    torch.manual_seed(1)
+    mdl = TrainingMotionPolicyNetwork(num_robot_points=2048).to(dev()).eval()
+    prob = make_problem_batch(2, seed=2, device=dev())
+    smp = FrankaSampler(dev())
+    subset = prob["robot_subset"]
+
+    def sampler(q):
+        out = torch.empty((q.size(0), 2048, 3), device=dev())
+        smp.sample_into(q, out, subset)
+        return out
+
+    xyz0 = prob["xyz"].clone()
+    batch = {"xyz": prob["xyz"], "configuration": prob["q_norm"]}
+    with torch.no_grad():
+        traj = mdl.rollout(batch, 3, sampler, unnormalize=True)
+    assert len(traj) == 4 and traj[0].shape == (2, 7)
+    assert not torch.equal(prob["xyz"][:, :2048, :3], xyz0[:, :2048, :3])  # robot rows rewritten in place
+    assert torch.equal(prob["xyz"][:, 2048:], xyz0[:, 2048:])
+    # oracle loop
+    sd = {k: v.detach().cpu().numpy() for k, v in mdl.state_dict().items()}
+    x = xyz0.cpu().numpy().copy()
+    q = prob["q_norm"].cpu().numpy()
+    lim = ft.JOINT_LIMITS_REAL
+    otraj = [oracle.unnormalize(q, lim)]
+    for _ in range(3):
+        dq, _ = oracle.policy_forward(sd, x, q)
+        q = np.clip(q + dq, -1, 1).astype(np.float32)
+        qu = oracle.unnormalize(q, lim)
+        otraj.append(qu)
+        x[:, :2048, :3] = oracle.transform_table(oracle.franka_fk(qu), smp.table_pts.cpu().numpy(),
+                                                 smp.table_link.cpu().numpy(), subset.cpu().numpy())
+    for a, b in zip(traj, otraj):
+        np.testing.assert_allclose(a.cpu().numpy(), b, rtol=0, atol=5e-5)
