@@ -4,9 +4,10 @@
 // (/root/reference/docker/Dockerfile:152; call sites mpinets/model.py:27,366-383,423-424).
 // Index semantics are those of that extension (restated in oracle/mpn_oracle.c):
 //   FPS   start at index 0; running distance 1e10; points with |p|^2 <= 1e-3 never update and
-//         are never candidates; the arg-max over d2 breaks ties towards the smallest
-//         (k mod bs, k) pair, bs = opt_n_threads(N) -- the order its strided thread scan +
-//         shared-memory tree reduction produces;
+//         are never candidates; the arg-max over d2 breaks ties the way the reference's strided
+//         thread scan (thread t = k mod bs keeps its first maximum, bs = opt_n_threads(N)) followed
+//         by its shared-memory tree reduction (slot t absorbs slot t+s, ties keep slot t,
+//         s = bs/2..1) does: the smallest BIT-REVERSED thread id wins, then the smallest k;
 //   ball  first `nsample` indices in ascending order with d2 < r^2, all slots pre-filled with
 //         the first hit, zeros when nothing is in range.
 // Distances are fma(dz,dz,fma(dy,dy,dx*dx)), the contraction nvcc applies to the CUDA source.
@@ -92,8 +93,9 @@ __global__ void __launch_bounds__(1024)
       const float mag = mpx_fma(z[i], z[i], mpx_fma(y[i], y[i], x[i] * x[i]));
       if (!(mag <= 1e-3f)) {
         dist[i] = 1e10f;
-        // tie order of the reference: smaller (k mod bs, k / bs) wins -> larger key wins
-        const unsigned rank = (((unsigned)k & bsmask) << 16) | ((unsigned)k >> log2bs);
+        // tie order of the reference: smaller (bitrev(k mod bs), k / bs) wins -> larger key wins.
+        // brev of a < 2^9 value lands in the top 9 bits: keeping the top 16 preserves the order.
+        const unsigned rank = (__brev((unsigned)k & bsmask) & 0xFFFF0000u) | ((unsigned)k >> log2bs);
         keylo[i] = 0xFFFFFFFFu - rank;
       }
     }
@@ -133,7 +135,7 @@ __global__ void __launch_bounds__(1024)
       old = 0;  // nothing was a candidate: the reference's besti stays 0
     } else {
       const unsigned rank = 0xFFFFFFFFu - (unsigned)m;
-      old = (int)(((rank & 0xFFFFu) << log2bs) | (rank >> 16));
+      old = (int)(((rank & 0xFFFFu) << log2bs) | __brev(rank & 0xFFFF0000u));
     }
   }
   if (tid == 0 && npoint > 0) {

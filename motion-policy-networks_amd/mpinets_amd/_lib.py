@@ -87,11 +87,36 @@ def ptr(t: Optional[torch.Tensor]):
     return t.data_ptr()
 
 
+# name -> list of (start_event, end_event) recorded around each launch of that entry point while
+# profiling is on (bench.py's live per-kernel timing; events sit on the launch stream).
+PROFILE: Optional[dict] = None
+
+
+def profile_start(*names: str) -> None:
+    global PROFILE
+    PROFILE = {n: [] for n in names}
+
+
+def profile_stop() -> dict:
+    """-> {name: [milliseconds per launch, in call order]} (synchronises the device)."""
+    global PROFILE
+    prof, PROFILE = PROFILE or {}, None
+    torch.cuda.synchronize()
+    return {n: [a.elapsed_time(b) for a, b in evs] for n, evs in prof.items()}
+
+
 def call(name: str, *args):
     """Call ``name`` with the current torch stream appended; raise on a non-zero status."""
     lib = load()
     fn = getattr(lib, name)
+    evs = None
+    if PROFILE is not None and name in PROFILE:
+        evs = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        evs[0].record()
     rc = fn(*args, stream_ptr())
+    if evs is not None:
+        evs[1].record()
+        PROFILE[name].append(evs)
     if rc != 0:
         raise MpxError(f"{name} failed ({rc}): {lib.mpx_last_error().decode()}")
 

@@ -1,0 +1,74 @@
+"""Sharding of independent planning problems across the GPUs of one node.
+
+Every environment (planning problem) is independent in every stage of the path (SURVEY.md
+section 8e), so rank r of W simply owns environments [r*E, (r+1)*E): weights and robot tables are
+replicated, there is NO collective on the step, and results come back with one final gather.
+``torch.distributed`` (RCCL on the GPU box, gloo in the CPU tests) is used only for the
+start/stop barrier of a timed region and for that final gather.
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def world() -> Tuple[int, int, int]:
+    """(rank, world_size, local_rank) from the torchrun environment (1-process defaults)."""
+    return int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+
+
+def init(backend: Optional[str] = None) -> Tuple[int, int, int]:
+    rank, ws, local = world()
+    if ws > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kwargs = {}
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            kwargs["device_id"] = torch.device("cuda", local)
+        dist.init_process_group(backend, rank=rank, world_size=ws, **kwargs)
+    return rank, ws, local
+
+
+def env_range(rank: int, world_size: int, envs_per_rank: int) -> range:
+    """Weak scaling: every rank owns ``envs_per_rank`` environments; global ids are contiguous."""
+    return range(rank * envs_per_rank, (rank + 1) * envs_per_rank)
+
+
+def split_even(total: int, world_size: int) -> List[range]:
+    """Strong scaling: contiguous, near-equal ranges covering ``total`` environments."""
+    base, rem = divmod(total, world_size)
+    out, start = [], 0
+    for r in range(world_size):
+        n = base + (1 if r < rem else 0)
+        out.append(range(start, start + n))
+        start += n
+    return out
+
+
+def barrier() -> None:
+    if dist.is_initialized():
+        dist.barrier()
+
+
+def max_over_ranks(value: float, device=None) -> float:
+    if not dist.is_initialized():
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def gather_to_rank0(t: torch.Tensor) -> Optional[torch.Tensor]:
+    """Final host gather: equal-shaped per-rank results -> concatenated on rank 0 (None elsewhere)."""
+    if not dist.is_initialized():
+        return t
+    rank, ws = dist.get_rank(), dist.get_world_size()
+    bufs = [torch.empty_like(t) for _ in range(ws)] if rank == 0 else None
+    dist.gather(t, bufs, dst=0)
+    return torch.cat(bufs, dim=0) if rank == 0 else None

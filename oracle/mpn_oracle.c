@@ -340,7 +340,8 @@ static float sqdist(const float *a, const float *b) {
 
 /* furthest_point_sampling_kernel: start at index 0; temp = 1e10; points with |p|^2 <= 1e-3
  * are skipped; each of `bs` threads scans k = tid, tid+bs, ... keeping the first strictly
- * greater value; shared-memory tree reduce keeps the lower thread id on ties.            */
+ * greater value; the shared-memory tree reduce (slot t absorbs slot t+s, ties keep slot t)
+ * is emulated literally -- on ties it favours the smallest bit-reversed thread id.       */
 ORC_API void orc_fps(const float *xyz, int B, int N, int stride, int npoint, int32_t *idx) {
   if (npoint <= 0) return;
   int bs = orc_opt_n_threads(N);

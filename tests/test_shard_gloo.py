@@ -1,0 +1,62 @@
+"""N > 1 path on CPU: env sharding + barrier + max-over-ranks + final gather with gloo, world_size 2."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, envs_per_rank, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from mpinets_amd import shard
+
+    r, w, _ = shard.init(backend="gloo")
+    assert (r, w) == (rank, world)
+    ids = shard.env_range(r, w, envs_per_rank)
+    # stand-in for the per-rank rollout result: a deterministic function of the GLOBAL env id
+    q = torch.tensor([[float(i) + 0.1 * j for j in range(7)] for i in ids])
+    flags = torch.tensor([i % 3 == 0 for i in ids], dtype=torch.int32)
+    shard.barrier()
+    t = shard.max_over_ranks(1.0 + rank)
+    assert t == float(world)
+    q_all = shard.gather_to_rank0(q)
+    f_all = shard.gather_to_rank0(flags)
+    if r == 0:
+        np.save(os.path.join(out_dir, "q.npy"), q_all.numpy())
+        np.save(os.path.join(out_dir, "f.npy"), f_all.numpy())
+    else:
+        assert q_all is None and f_all is None
+    shard.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_shard_equals_single_rank(tmp_path):
+    world, per_rank = 2, 5
+    mp.spawn(_worker, args=(world, _free_port(), per_rank, str(tmp_path)), nprocs=world, join=True)
+    q = np.load(tmp_path / "q.npy")
+    f = np.load(tmp_path / "f.npy")
+    ids = np.arange(world * per_rank)
+    np.testing.assert_allclose(q, ids[:, None] + 0.1 * np.arange(7)[None], rtol=1e-6)
+    np.testing.assert_array_equal(f, (ids % 3 == 0).astype(np.int32))
+
+
+def test_split_even_covers_everything():
+    from mpinets_amd.shard import env_range, split_even
+
+    for total, w in [(8192, 8), (10, 3), (7, 8), (65536, 8)]:
+        parts = split_even(total, w)
+        assert sum(len(p) for p in parts) == total and parts[0].start == 0 and parts[-1].stop == total
+        assert all(a.stop == b.start for a, b in zip(parts, parts[1:]))
+        assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+    assert list(env_range(3, 8, 1024))[:2] == [3072, 3073]

@@ -1,12 +1,29 @@
 #!/bin/bash
-# One GPU-box visit: parity tests (no -x: collect everything), smoke, timings.  Logs -> gpurun_out/
+# One GPU-box visit.  usage: tools/gpu_session.sh [tests] [smoke] [timing[=B]] [bench[=ARGS]] [prof[=ARGS]]
+# Logs -> gpurun_out/ (merged back by gpurun).
 mkdir -p gpurun_out
 export PYTHONUNBUFFERED=1
-( rocm-smi --showproductname 2>/dev/null | head -8; nproc ) > gpurun_out/box.log 2>&1
-timeout 1500 python -m pytest tests -m gpu -q -rA --tb=short -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1
-echo "pytest exit: $?" >> gpurun_out/pytest_gpu.log
-timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1
-echo "smoke exit: $?" >> gpurun_out/smoke.log
-timeout 600 python tools/quick_timing.py ${1:-512} > gpurun_out/timing.log 2>&1
-echo "timing exit: $?" >> gpurun_out/timing.log
-tail -5 gpurun_out/pytest_gpu.log; tail -3 gpurun_out/smoke.log; tail -15 gpurun_out/timing.log
+REPO=$(pwd)
+( rocm-smi --showproductname 2>/dev/null | grep -i "card\|gfx" | head -4; echo "host cores: $(nproc)"; free -g | head -2 ) > gpurun_out/box.log 2>&1
+for arg in "$@"; do
+  key=${arg%%=*}; val=""; [[ "$arg" == *=* ]] && val=${arg#*=}
+  case $key in
+    tests)
+      timeout 1500 python -m pytest tests -m gpu -q -rA --tb=short -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1
+      echo "pytest exit: $?" >> gpurun_out/pytest_gpu.log; tail -4 gpurun_out/pytest_gpu.log ;;
+    smoke)
+      timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1
+      echo "smoke exit: $?" >> gpurun_out/smoke.log; tail -2 gpurun_out/smoke.log ;;
+    timing)
+      timeout 900 python tools/quick_timing.py ${val:-512} > gpurun_out/timing.log 2>&1
+      echo "timing exit: $?" >> gpurun_out/timing.log; tail -14 gpurun_out/timing.log ;;
+    bench)
+      timeout 1200 python bench.py $val > gpurun_out/bench.log 2> gpurun_out/bench.err
+      echo "bench exit: $?" >> gpurun_out/bench.err; tail -3 gpurun_out/bench.err; cat gpurun_out/bench.log ;;
+    prof)
+      ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof && timeout 1200 rocprofv3 --kernel-trace --stats -d /tmp/prof -o run -- python $REPO/bench.py ${val:---steps 3 --warmup 1 --cpu-envs 0} > $REPO/gpurun_out/prof_bench.log 2> $REPO/gpurun_out/prof.err
+        echo "prof exit: $?" >> $REPO/gpurun_out/prof.err
+        mkdir -p $REPO/gpurun_out/prof; find /tmp/prof -name "*stats*" -exec cp {} $REPO/gpurun_out/prof/ \; ; ls -la /tmp/prof/* | head -20 >> $REPO/gpurun_out/prof.err )
+      tail -5 gpurun_out/prof.err; cat gpurun_out/prof_bench.log | tail -2 ;;
+  esac
+done
