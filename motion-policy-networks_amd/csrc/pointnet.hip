@@ -191,41 +191,83 @@ MPX_EXPORT int mpx_fps(const float *xyz, int B, int N, int stride, int npoint, i
 }
 
 // ---- ball query ------------------------------------------------------------------------------------
-// One wave per query point; the wave sweeps the cloud 64 points at a time, ballots the hits and
-// compacts them in index order with a prefix popcount.  grid (ceil(npoint/4), B), block 256.
+// One QUERY per lane (64 queries per wave, 256 per workgroup); the cloud is walked in index order
+// with wave-uniform addresses, so every point arrives through the scalar cache as SGPR operands
+// and costs one pass of ~9 VALU instructions for 64 queries.  A lane appends its hits to its own
+// output row as they occur (index order is the loop order; few hits, scattered 4-byte stores);
+// the padding of the remaining slots -- most of the 512-byte row -- is written cooperatively,
+// one row at a time, fully coalesced.  Algorithmic HBM traffic: cloud read once per workgroup
+// (L2-resident across an environment's workgroups) + npoint*nsample*4 bytes written.
+// grid (ceil(npoint/256), B), block 256.
+template <int STRIDE, bool ALIGNED64>
 __global__ void __launch_bounds__(256)
     ball_query_kernel(const float *__restrict__ new_xyz, int new_stride, const float *__restrict__ xyz,
-                      int stride, int N, int npoint, float radius2, int nsample, int32_t *__restrict__ idx) {
+                      int stride_rt, int N, int npoint, float radius2, int nsample, int32_t *__restrict__ idx) {
+  const int stride = STRIDE > 0 ? STRIDE : stride_rt;
   const int b = blockIdx.y;
   const int lane = threadIdx.x & 63;
-  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (j >= npoint) return;
-  const float *c = new_xyz + ((size_t)b * npoint + j) * new_stride;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  const bool live = j < npoint;
+  const int jc = live ? j : npoint - 1;
+  const float *c = new_xyz + ((size_t)b * npoint + jc) * new_stride;
   const float cx = c[0], cy = c[1], cz = c[2];
-  const float *pts = xyz + (size_t)b * N * stride;
-  int32_t *out = idx + ((size_t)b * npoint + j) * nsample;
-  int cnt = 0;
+  const float *pts = xyz + (size_t)b * N * stride;  // block-uniform: scalar loads below
+  int32_t *out = idx + ((size_t)b * npoint + jc) * nsample;
+  int cnt = live ? 0 : nsample;  // dead lanes never take a hit
   int first = 0;
-  for (int k0 = 0; k0 < N && cnt < nsample; k0 += 64) {
-    const int k = k0 + lane;
-    bool hit = false;
-    if (k < N) {
-      const float *p = pts + (size_t)k * stride;
-      const float dx = cx - p[0], dy = cy - p[1], dz = cz - p[2];
-      const float d2 = mpx_fma(dz, dz, mpx_fma(dy, dy, dx * dx));
-      hit = d2 < radius2;
+  auto test_point = [&](int k, float px, float py, float pz) {
+    const float dx = cx - px, dy = cy - py, dz = cz - pz;
+    const float d2 = mpx_fma(dz, dz, mpx_fma(dy, dy, dx * dx));
+    if (d2 < radius2 && cnt < nsample) {
+      if (cnt == 0) first = k;
+      out[cnt] = k;
+      ++cnt;
     }
-    const u64 mask = __ballot(hit);
-    if (mask) {
-      if (cnt == 0) first = k0 + (int)__builtin_ctzll(mask);
-      const int pos = cnt + (int)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
-      if (hit && pos < nsample) out[pos] = k;
-      cnt += (int)__builtin_popcountll(mask);
+  };
+  constexpr int U = 8;  // points fetched per scalar-load batch
+  int k = 0;
+  if (STRIDE == 4 && ALIGNED64) {
+    // slab rows: 4 points = one 64-byte scalar load (the launcher checked the alignment)
+    // (hipcc turns a plain uniform 64-byte load into per-point vector loads here, so the scalar
+    // loads and their wait are spelled out; the wait is inside the statement, section 5.7 rule 1.)
+    typedef float f32x16s __attribute__((ext_vector_type(16)));
+    for (; k + U <= N; k += U) {
+      f32x16s a, c2;
+      const float *src = pts + (size_t)k * 4;
+      asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&s"(a), "=&s"(c2)
+                   : "s"(src)
+                   : "memory");
+#pragma unroll
+      for (int u = 0; u < 4; ++u) test_point(k + u, a[4 * u], a[4 * u + 1], a[4 * u + 2]);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) test_point(k + 4 + u, c2[4 * u], c2[4 * u + 1], c2[4 * u + 2]);
+      if ((k & 63) == 56 && __all(cnt >= nsample)) break;
+    }
+  } else {
+    for (; k + U <= N; k += U) {
+      float p[U][3];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        p[u][0] = pts[(size_t)(k + u) * stride + 0];
+        p[u][1] = pts[(size_t)(k + u) * stride + 1];
+        p[u][2] = pts[(size_t)(k + u) * stride + 2];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) test_point(k + u, p[u][0], p[u][1], p[u][2]);
+      if ((k & 63) == 56 && __all(cnt >= nsample)) break;  // every query of the wave is full
     }
   }
-  if (cnt > nsample) cnt = nsample;
-  // remaining slots: the first hit (or 0 if there was none -- the reference's zero-initialised output)
-  for (int l = cnt + lane; l < nsample; l += 64) out[l] = first;
+  if (!__all(cnt >= nsample))
+    for (; k < N; ++k) test_point(k, pts[(size_t)k * stride + 0], pts[(size_t)k * stride + 1], pts[(size_t)k * stride + 2]);
+  // cooperative, coalesced padding: row q of this wave gets `first_q` in slots [cnt_q, nsample)
+  const int jw = j - lane;  // first query of this wave
+  for (int q = 0; q < 64; ++q) {
+    if (jw + q >= npoint) break;
+    const int cq = __shfl(cnt, q), fq = __shfl(first, q);
+    int32_t *row = idx + ((size_t)b * npoint + jw + q) * nsample;
+    for (int l = cq + lane; l < nsample; l += 64) row[l] = fq;
+  }
 }
 
 MPX_EXPORT int mpx_ball_query(const float *new_xyz, int new_stride, const float *xyz, int stride, int B, int N,
@@ -235,8 +277,20 @@ MPX_EXPORT int mpx_ball_query(const float *new_xyz, int new_stride, const float 
   MPX_REQUIRE(B <= 65535, "mpx_ball_query: B > 65535 (slab the batch)");
   if (B == 0 || npoint == 0 || nsample == 0) return 0;
   const float r2 = radius * radius;  // float product, like the reference kernel
-  hipLaunchKernelGGL(ball_query_kernel, dim3(cdiv(npoint, 4), B), dim3(256), 0, mpx_s(stream), new_xyz,
-                     new_stride, xyz, stride, N, npoint, r2, nsample, idx);
+  dim3 g(cdiv(npoint, 256), B), t(256);
+  const bool al64 = stride == 4 && ((uintptr_t)xyz & 63) == 0 && N % 4 == 0;
+  if (al64)
+    hipLaunchKernelGGL((ball_query_kernel<4, true>), g, t, 0, mpx_s(stream), new_xyz, new_stride, xyz, stride, N, npoint,
+                       r2, nsample, idx);
+  else if (stride == 4)
+    hipLaunchKernelGGL((ball_query_kernel<4, false>), g, t, 0, mpx_s(stream), new_xyz, new_stride, xyz, stride, N, npoint,
+                       r2, nsample, idx);
+  else if (stride == 3)
+    hipLaunchKernelGGL((ball_query_kernel<3, false>), g, t, 0, mpx_s(stream), new_xyz, new_stride, xyz, stride, N, npoint,
+                       r2, nsample, idx);
+  else
+    hipLaunchKernelGGL((ball_query_kernel<0, false>), g, t, 0, mpx_s(stream), new_xyz, new_stride, xyz, stride, N, npoint,
+                       r2, nsample, idx);
   MPX_LAUNCH_CHECK("mpx_ball_query");
 }
 
