@@ -93,9 +93,37 @@ int mpx_franka_collision(const float *q, int B, int T, float finger, const float
 
 /* rollout joint update, model.py:171-173 + utils.py:207-209:
  *   q_norm_out = clamp(q_norm + dq, -1, 1);  q_out = (q_norm_out + 1) * (hi - lo) / 2 + lo
- * limits [7,2] device; either output may alias q_norm.                                      */
+ * limits [7,2] device; either output may alias q_norm; environments with frozen[b] != 0
+ * (optional int32 [B]) keep their configuration.                                            */
 int mpx_joint_step(const float *q_norm, const float *dq, const float *limits, int B,
-                   float *q_norm_out, float *q_out, mpx_stream_t stream);
+                   float *q_norm_out, float *q_out, const int32_t *frozen, mpx_stream_t stream);
+
+/* early-stop test of rollout_until_success (run_inference.py:176-187), on the device:
+ *   success = |t(right_gripper(q)) - t(target)| < pos_tol  &&  cos(angle(R R_t^T)) > cos_rot_tol
+ * target_poses [B,4,4] row-major.  done int32 [B] is OR-ed (a set flag freezes that environment in
+ * mpx_joint_step); steps (optional) counts the policy steps taken until done; pos_err / cos_angle
+ * (optional) [B] return the two measured quantities.                                            */
+int mpx_franka_success(const float *q, const float *target_poses, int B, float finger, float pos_tol,
+                       float cos_rot_tol, int32_t *done, int32_t *steps, float *pos_err,
+                       float *cos_angle, mpx_stream_t stream);
+
+/* ---- scene point clouds: mpinets/geometry.py:571-608 (construct_mixed_point_cloud), batched ----- */
+
+/* For every environment: area-proportional pool sizes int(p_i*N)+500, N pool slots drawn without
+ * replacement in random order (only the owning obstacle matters: an urn process), one fresh
+ * uniform surface sample per slot, labels = shuffled 1..K.  Counter RNG Philox4x32-10 keyed by
+ * (seed, environment): results depend on nothing else.  Zero-volume primitives are skipped;
+ * obstacle ids count cuboids first, then cylinders.  An environment without obstacles gets
+ * ids 0xFFFF and zero points (the reference returns an empty array, geometry.py:586-587).
+ *   assign uint16 [B,N] (required scratch/output), labels uint8 [B,M1+M2] (optional),
+ *   n_obstacles int32 [B] (optional); out rows at out + b*out_batch_stride + j*out_point_stride
+ *   receive x,y,z (and the label as float in column 3 when write_label != 0).                 */
+int mpx_scene_cloud(const float *cub_centers, const float *cub_dims, const float *cub_quats, int M1,
+                    const float *cyl_centers, const float *cyl_radii, const float *cyl_heights,
+                    const float *cyl_quats, int M2, int B, int num_points, uint64_t seed,
+                    uint16_t *assign, uint8_t *labels, int32_t *n_obstacles, float *out,
+                    int64_t out_batch_stride, int out_point_stride, int write_label,
+                    mpx_stream_t stream);
 
 /* ---- PointNet++ set abstraction: pointnet2_ops call sites model.py:27,366-383 ------------- */
 

@@ -196,11 +196,13 @@ MPX_EXPORT int mpx_franka_collision(const float *q, int B, int T, float finger, 
 __global__ void __launch_bounds__(256)
     joint_step_kernel(const float *__restrict__ qn, const float *__restrict__ dq,
                       const float *__restrict__ limits, int n, float *__restrict__ qn_out,
-                      float *__restrict__ q_out) {
+                      float *__restrict__ q_out, const int32_t *__restrict__ frozen) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const int j = i % 7;
-  float v = qn[i] + dq[i];
+  float v = qn[i];
+  // a finished rollout (run_inference.py:180-187 `break`) keeps its last configuration
+  if (!(frozen && frozen[i / 7])) v = v + dq[i];
   v = fminf(fmaxf(v, -1.0f), 1.0f);  // torch.clamp(q + self(xyz, q), min=-1, max=1), model.py:171
   const float lo = limits[2 * j], hi = limits[2 * j + 1];
   // utils.py:207-209 with limits=(-1,1): (x - (-1)) * range / 2 + lower
@@ -210,10 +212,53 @@ __global__ void __launch_bounds__(256)
 }
 
 MPX_EXPORT int mpx_joint_step(const float *q_norm, const float *dq, const float *limits, int B,
-                              float *q_norm_out, float *q_out, mpx_stream_t stream) {
+                              float *q_norm_out, float *q_out, const int32_t *frozen, mpx_stream_t stream) {
   MPX_REQUIRE(B >= 0, "mpx_joint_step: B < 0");
   if (B == 0) return 0;
   hipLaunchKernelGGL(joint_step_kernel, dim3(cdiv((int64_t)B * 7, 256)), dim3(256), 0, mpx_s(stream), q_norm,
-                     dq, limits, B * 7, q_norm_out, q_out);
+                     dq, limits, B * 7, q_norm_out, q_out, frozen);
   MPX_LAUNCH_CHECK("mpx_joint_step");
+}
+
+// ---- rollout success test -------------------------------------------------------------------------
+// run_inference.py:176-187: stop when the end effector (`right_gripper`) is within 1 cm and 15 deg of
+// the target.  The reference does this on the host after a device->host copy every step; here it is
+// a flag per environment on the device.  angle(R_eff R_t^T) < tol  <=>  (trace - 1)/2 > cos(tol).
+__global__ void __launch_bounds__(64)
+    franka_success_kernel(const float *__restrict__ q, const float *__restrict__ targets, int B, float finger,
+                          float pos_tol, float cos_tol, int32_t *__restrict__ done, int32_t *__restrict__ steps,
+                          float *__restrict__ pos_err, float *__restrict__ cos_ang) {
+  __shared__ float lds[64 * FRAME_FLOATS];
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= B) return;
+  float qq[7];
+#pragma unroll
+  for (int j = 0; j < 7; ++j) qq[j] = q[(size_t)b * 7 + j];
+  float *fr = lds + threadIdx.x * FRAME_FLOATS;
+  franka_fk_frames(qq, finger, fr);
+  const float *e = fr + 12 * 14;  // right_gripper
+  const float *t = targets + (size_t)b * 16;
+  const float dx = e[9] - t[3], dy = e[10] - t[7], dz = e[11] - t[11];
+  const float err = sqrtf(mpx_fma(dz, dz, mpx_fma(dy, dy, dx * dx)));
+  float tr = 0.0f;
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) tr = mpx_fma(e[3 * r + c], t[4 * r + c], tr);
+  const float ca = (tr - 1.0f) * 0.5f;
+  if (pos_err) pos_err[b] = err;
+  if (cos_ang) cos_ang[b] = ca;
+  const int was = done[b];
+  if (steps && !was) steps[b] += 1;
+  if (err < pos_tol && ca > cos_tol) done[b] = 1;
+}
+
+MPX_EXPORT int mpx_franka_success(const float *q, const float *target_poses, int B, float finger, float pos_tol,
+                                  float cos_rot_tol, int32_t *done, int32_t *steps, float *pos_err,
+                                  float *cos_angle, mpx_stream_t stream) {
+  MPX_REQUIRE(B >= 0 && done != nullptr, "mpx_franka_success: bad arguments");
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(franka_success_kernel, dim3(cdiv(B, 64)), dim3(64), 0, mpx_s(stream), q, target_poses, B,
+                     finger, pos_tol, cos_rot_tol, done, steps, pos_err, cos_angle);
+  MPX_LAUNCH_CHECK("mpx_franka_success");
 }

@@ -1,0 +1,243 @@
+// scene.hip -- batched scene point clouds from cuboid / cylinder primitives, on the device.
+//
+// Replaces construct_mixed_point_cloud (/root/reference/mpinets/geometry.py:571-608) for batches of
+// environments (closed-loop re-rendering, BASELINE config 5; data_loader.py:237-260 per sample).
+// The reference: areas -> proportions; pool of n_i = int(p_i*N) + 500 surface samples per
+// obstacle (geometry.py:598-604); np.random.choice(sum n_i, N, replace=False) (:608); labels are a
+// shuffled 1..K (:594-595).  Its samples come from NumPy's global RNG inside geometrout, so only
+// the DISTRIBUTION can be matched.  This kernel draws from exactly that distribution with a counter
+// RNG (Philox4x32-10 keyed by (seed, environment)):
+//   * picking N of the pool slots without replacement in random order, and asking only which
+//     obstacle each slot belongs to, is an urn process: position j takes obstacle i with
+//     probability remaining_i / remaining_total.  One lane runs the urn of one environment
+//     (64 environments per wave) and writes obstacle ids [B,N] (uint16);
+//   * pool samples are i.i.d., so each output point is a fresh uniform sample on its obstacle's
+//     surface: one thread per point, written straight into the slab rows (x,y,z[,label]).
+// Zero-volume primitives are skipped exactly like data_loader.py:248,256 (is_zero_volume).
+// Obstacle order = cuboids then cylinders (data_loader.py:258 `cuboids + cylinders`).
+// The same algorithm is restated in oracle/mpn_oracle.c (orc_scene_*), bit-exact on the ids.
+#include "common.h"
+
+// ---- Philox4x32-10 ------------------------------------------------------------------------------
+struct Philox {
+  uint32_t c[4];
+};
+__host__ __device__ __forceinline__ Philox philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                      uint32_t k0, uint32_t k1) {
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return Philox{{c0, c1, c2, c3}};
+}
+// uniform in [0,1): top 24 bits
+__host__ __device__ __forceinline__ float u01(uint32_t x) { return (float)(x >> 8) * 5.9604644775390625e-08f; }
+
+constexpr int MAX_OBS = 96;
+enum { STREAM_URN = 1, STREAM_LABEL = 2, STREAM_POINT = 3 };
+
+// ---- kernel 1: per-environment allocation, label shuffle and urn ------------------------------------
+// block 64 (one wave), one environment per lane; per-lane state in LDS (remaining[MAX_OBS] uint16).
+__global__ void __launch_bounds__(64)
+    scene_assign_kernel(const float *__restrict__ cub_dims, int M1, const float *__restrict__ cyl_radii,
+                        const float *__restrict__ cyl_heights, int M2, int B, int N, uint32_t seed_lo,
+                        uint32_t seed_hi, uint16_t *__restrict__ assign, uint8_t *__restrict__ labels,
+                        int32_t *__restrict__ n_obstacles) {
+  __shared__ uint16_t rem_s[64 * MAX_OBS];
+  __shared__ uint8_t lab_s[64 * MAX_OBS];
+  const int lane = threadIdx.x;
+  const int b = blockIdx.x * 64 + lane;
+  if (b >= B) return;
+  uint16_t *rem = rem_s + lane * MAX_OBS;
+  uint8_t *lab = lab_s + lane * MAX_OBS;
+  const int M = M1 + M2;
+  // areas (double, like numpy) of the non-zero-volume obstacles; others get area 0 and pool 0
+  double total = 0.0;
+  int K = 0;
+  for (int m = 0; m < M; ++m) {
+    double a = 0.0;
+    if (m < M1) {
+      const float *d = cub_dims + ((size_t)b * M1 + m) * 3;
+      if (!(__builtin_fabsf(d[0]) <= 1e-8f || __builtin_fabsf(d[1]) <= 1e-8f || __builtin_fabsf(d[2]) <= 1e-8f))
+        a = 2.0 * ((double)d[0] * d[1] + (double)d[0] * d[2] + (double)d[1] * d[2]);
+    } else {
+      const float r = cyl_radii[(size_t)b * M2 + (m - M1)], h = cyl_heights[(size_t)b * M2 + (m - M1)];
+      if (!(__builtin_fabsf(r) <= 1e-8f || __builtin_fabsf(h) <= 1e-8f))
+        a = 2.0 * 3.14159265358979323846 * (double)r * (double)h + 2.0 * 3.14159265358979323846 * (double)r * (double)r;
+    }
+    total += a;
+    K += a > 0.0;
+  }
+  if (n_obstacles) n_obstacles[b] = K;
+  uint16_t *arow = assign + (size_t)b * N;
+  if (K == 0) {  // geometry.py:586-587 returns an empty cloud; ids 0xFFFF mark "no obstacle"
+    for (int j = 0; j < N; ++j) arow[j] = 0xFFFFu;
+    return;
+  }
+  uint32_t pool = 0;
+  for (int m = 0; m < M; ++m) {
+    double a = 0.0;
+    if (m < M1) {
+      const float *d = cub_dims + ((size_t)b * M1 + m) * 3;
+      if (!(__builtin_fabsf(d[0]) <= 1e-8f || __builtin_fabsf(d[1]) <= 1e-8f || __builtin_fabsf(d[2]) <= 1e-8f))
+        a = 2.0 * ((double)d[0] * d[1] + (double)d[0] * d[2] + (double)d[1] * d[2]);
+    } else {
+      const float r = cyl_radii[(size_t)b * M2 + (m - M1)], h = cyl_heights[(size_t)b * M2 + (m - M1)];
+      if (!(__builtin_fabsf(r) <= 1e-8f || __builtin_fabsf(h) <= 1e-8f))
+        a = 2.0 * 3.14159265358979323846 * (double)r * (double)h + 2.0 * 3.14159265358979323846 * (double)r * (double)r;
+    }
+    uint32_t n = 0;
+    if (a > 0.0) n = (uint32_t)(int)((a / total) * (double)N) + 500u;  // int(prop*num_points) + 500
+    rem[m] = (uint16_t)n;
+    pool += n;
+  }
+  // labels: Fisher-Yates shuffle of 1..K over the live obstacles (random.shuffle, geometry.py:594-595)
+  {
+    int live = 0;
+    for (int m = 0; m < M; ++m) lab[m] = rem[m] ? (uint8_t)(++live) : 0;
+    int i = K - 1;
+    uint32_t ctr = 0;
+    // walk live obstacles from the back
+    for (int m = M - 1; m >= 0 && i > 0; --m) {
+      if (!rem[m]) continue;
+      const Philox r = philox4x32(ctr++, (uint32_t)b, STREAM_LABEL, 0, seed_lo, seed_hi);
+      int jpos = (int)(((uint64_t)r.c[0] * (uint32_t)(i + 1)) >> 32);  // uniform in [0, i]
+      // find the jpos-th live obstacle
+      int t = -1;
+      for (int mm = 0; mm < M; ++mm)
+        if (rem[mm] && ++t == jpos) {
+          const uint8_t tmp = lab[m];
+          lab[m] = lab[mm];
+          lab[mm] = tmp;
+          break;
+        }
+      --i;
+    }
+    if (labels)
+      for (int m = 0; m < M; ++m) labels[(size_t)b * M + m] = lab[m];
+  }
+  // the urn: position j takes obstacle m with probability rem[m] / pool
+  for (int j0 = 0; j0 < N; j0 += 4) {
+    const Philox r = philox4x32((uint32_t)(j0 >> 2), (uint32_t)b, STREAM_URN, 0, seed_lo, seed_hi);
+    for (int u = 0; u < 4 && j0 + u < N; ++u) {
+      uint32_t pick = (uint32_t)(((uint64_t)r.c[u] * pool) >> 32);  // uniform in [0, pool)
+      int m = 0;
+      while (pick >= rem[m]) {
+        pick -= rem[m];
+        ++m;
+      }
+      rem[m] -= 1;
+      pool -= 1;
+      arow[j0 + u] = (uint16_t)m;
+    }
+  }
+}
+
+// ---- kernel 2: one uniform surface sample per output point ----------------------------------------------
+__device__ __forceinline__ void quat_rotate(const float *__restrict__ q, float x, float y, float z, float &ox,
+                                            float &oy, float &oz) {
+  // proper rotation by the normalised quaternion (w,x,y,z) -- poses of obstacles are true rigid
+  // poses (geometrout); the non-orthonormal matrix of geometry.py:209-216 only exists in the SDF classes.
+  const float n = sqrtf(mpx_fma(q[3], q[3], mpx_fma(q[2], q[2], mpx_fma(q[1], q[1], q[0] * q[0]))));
+  const float w = q[0] / n, a = q[1] / n, b = q[2] / n, c = q[3] / n;
+  const float r00 = 1.0f - 2.0f * (b * b + c * c), r01 = 2.0f * (a * b - w * c), r02 = 2.0f * (a * c + w * b);
+  const float r10 = 2.0f * (a * b + w * c), r11 = 1.0f - 2.0f * (a * a + c * c), r12 = 2.0f * (b * c - w * a);
+  const float r20 = 2.0f * (a * c - w * b), r21 = 2.0f * (b * c + w * a), r22 = 1.0f - 2.0f * (a * a + b * b);
+  ox = mpx_fma(r02, z, mpx_fma(r01, y, r00 * x));
+  oy = mpx_fma(r12, z, mpx_fma(r11, y, r10 * x));
+  oz = mpx_fma(r22, z, mpx_fma(r21, y, r20 * x));
+}
+
+__global__ void __launch_bounds__(256)
+    scene_points_kernel(const float *__restrict__ cub_c, const float *__restrict__ cub_d,
+                        const float *__restrict__ cub_q, int M1, const float *__restrict__ cyl_c,
+                        const float *__restrict__ cyl_r, const float *__restrict__ cyl_h,
+                        const float *__restrict__ cyl_q, int M2, int N, uint32_t seed_lo, uint32_t seed_hi,
+                        const uint16_t *__restrict__ assign, const uint8_t *__restrict__ labels,
+                        float *__restrict__ out, int64_t obs, int ops, int write_label) {
+  const int b = blockIdx.y;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= N) return;
+  const int m = assign[(size_t)b * N + j];
+  float *o = out + (int64_t)b * obs + (int64_t)j * ops;
+  if (m == 0xFFFF) {
+    o[0] = o[1] = o[2] = 0.0f;
+    if (write_label) o[3] = 0.0f;
+    return;
+  }
+  const Philox r = philox4x32((uint32_t)j, (uint32_t)b, STREAM_POINT, 0, seed_lo, seed_hi);
+  const float u0 = u01(r.c[0]), u1 = u01(r.c[1]), u2 = u01(r.c[2]), u3 = u01(r.c[3]);
+  float lx, ly, lz;
+  const float *ctr, *quat;
+  if (m < M1) {
+    const float *d = cub_d + ((size_t)b * M1 + m) * 3;
+    const float ax = d[1] * d[2], ay = d[0] * d[2], az = d[0] * d[1];
+    const float t = u0 * (ax + ay + az);
+    const float sgn = u1 < 0.5f ? -0.5f : 0.5f;
+    // face pair by area, side by sign, the two free coordinates uniform over the face
+    if (t < ax) {
+      lx = sgn * d[0];
+      ly = (u2 - 0.5f) * d[1];
+      lz = (u3 - 0.5f) * d[2];
+    } else if (t < ax + ay) {
+      lx = (u2 - 0.5f) * d[0];
+      ly = sgn * d[1];
+      lz = (u3 - 0.5f) * d[2];
+    } else {
+      lx = (u2 - 0.5f) * d[0];
+      ly = (u3 - 0.5f) * d[1];
+      lz = sgn * d[2];
+    }
+    ctr = cub_c + ((size_t)b * M1 + m) * 3;
+    quat = cub_q + ((size_t)b * M1 + m) * 4;
+  } else {
+    const int c = m - M1;
+    const float rad = cyl_r[(size_t)b * M2 + c], h = cyl_h[(size_t)b * M2 + c];
+    const float side = 2.0f * rad * h, cap = rad * rad;  // areas / pi
+    const float t = u0 * (side + 2.0f * cap);
+    float s, co;
+    mpx_sincos(u1 * 6.28318530717958647692f, s, co);
+    float rho = rad;
+    lz = (u2 - 0.5f) * h;
+    if (t >= side) {
+      rho = rad * sqrtf(u3);
+      lz = t < side + cap ? -0.5f * h : 0.5f * h;
+    }
+    lx = rho * co;
+    ly = rho * s;
+    ctr = cyl_c + ((size_t)b * M2 + c) * 3;
+    quat = cyl_q + ((size_t)b * M2 + c) * 4;
+  }
+  float wx, wy, wz;
+  quat_rotate(quat, lx, ly, lz, wx, wy, wz);
+  o[0] = wx + ctr[0];
+  o[1] = wy + ctr[1];
+  o[2] = wz + ctr[2];
+  if (write_label) o[3] = labels ? (float)labels[(size_t)b * (M1 + M2) + m] : 1.0f;
+}
+
+MPX_EXPORT int mpx_scene_cloud(const float *cub_centers, const float *cub_dims, const float *cub_quats, int M1,
+                               const float *cyl_centers, const float *cyl_radii, const float *cyl_heights,
+                               const float *cyl_quats, int M2, int B, int num_points, uint64_t seed,
+                               uint16_t *assign, uint8_t *labels, int32_t *n_obstacles, float *out,
+                               int64_t out_batch_stride, int out_point_stride, int write_label,
+                               mpx_stream_t stream) {
+  MPX_REQUIRE(B >= 0 && M1 >= 0 && M2 >= 0 && num_points >= 0, "mpx_scene_cloud: negative size");
+  MPX_REQUIRE(M1 + M2 <= MAX_OBS, "mpx_scene_cloud: more than %d primitives per environment", MAX_OBS);
+  MPX_REQUIRE(num_points <= 60000, "mpx_scene_cloud: num_points > 60000 (pool sizes are 16-bit)");
+  MPX_REQUIRE(B <= 65535, "mpx_scene_cloud: B > 65535 (slab the batch)");
+  MPX_REQUIRE(out_point_stride >= (write_label ? 4 : 3), "mpx_scene_cloud: out_point_stride too small");
+  MPX_REQUIRE(assign != nullptr, "mpx_scene_cloud: assign scratch [B,num_points] uint16 is required");
+  if (B == 0 || num_points == 0) return 0;
+  const uint32_t lo = (uint32_t)seed, hi = (uint32_t)(seed >> 32);
+  hipLaunchKernelGGL(scene_assign_kernel, dim3(cdiv(B, 64)), dim3(64), 0, mpx_s(stream), cub_dims, M1, cyl_radii,
+                     cyl_heights, M2, B, num_points, lo, hi, assign, labels, n_obstacles);
+  hipLaunchKernelGGL(scene_points_kernel, dim3(cdiv(num_points, 256), B), dim3(256), 0, mpx_s(stream), cub_centers,
+                     cub_dims, cub_quats, M1, cyl_centers, cyl_radii, cyl_heights, cyl_quats, M2, num_points, lo,
+                     hi, assign, labels, out, out_batch_stride, out_point_stride, write_label);
+  MPX_LAUNCH_CHECK("mpx_scene_cloud");
+}

@@ -44,6 +44,20 @@ class RolloutEngine:
         self.limits = torch.as_tensor(ft.JOINT_LIMITS_REAL, dtype=torch.float32, device=dev).contiguous()
         self.flags = torch.zeros(self.B, dtype=torch.int32, device=dev)
         self.steps_done = 0
+        # success tracking (rollout_until_success): target poses, done flags, per-env step counts
+        self.targets = None
+        self.done = None
+        self.steps = None
+
+    def track_success(self, target_poses: torch.Tensor, pos_tol: float = 0.01, rot_tol_deg: float = 15.0):
+        """Enable the on-device early-stop test of run_inference.py:180-187 against ``target_poses`` [B,4,4]
+        (``right_gripper`` frame).  Finished environments keep their last configuration."""
+        assert target_poses.shape == (self.B, 4, 4)
+        self.targets = _lib.f32c(target_poses)
+        self.done = torch.zeros(self.B, dtype=torch.int32, device=self.device)
+        self.steps = torch.zeros(self.B, dtype=torch.int32, device=self.device)
+        self.pos_tol = float(pos_tol)
+        self.cos_tol = float(np.cos(np.radians(rot_tol_deg)))
 
     @torch.no_grad()
     def step(self) -> torch.Tensor:
@@ -51,7 +65,10 @@ class RolloutEngine:
         lib = _lib
         dq = self.model(self.xyz, self.q_norm)
         lib.call("mpx_joint_step", lib.ptr(self.q_norm), lib.ptr(dq), lib.ptr(self.limits), self.B,
-                 lib.ptr(self.q_norm), lib.ptr(self.q))
+                 lib.ptr(self.q_norm), lib.ptr(self.q), lib.ptr(self.done))
+        if self.done is not None:
+            lib.call("mpx_franka_success", lib.ptr(self.q), lib.ptr(self.targets), self.B, self.sampler.finger,
+                     self.pos_tol, self.cos_tol, lib.ptr(self.done), lib.ptr(self.steps), None, None)
         self.sampler.sample_into(self.q, self.xyz, self.subset)
         c = self.collision
         lib.call("mpx_franka_collision", lib.ptr(self.q), self.B, 1, c.finger, lib.ptr(c.centers),
@@ -73,3 +90,46 @@ class RolloutEngine:
     @property
     def has_collision(self) -> torch.Tensor:
         return self.flags != 0
+
+    def rollout_until_success(self, max_steps: int = 150, check_every: int = 1):
+        """Batched ``rollout_until_success`` (run_inference.py:137-191): step until every environment is
+        within 1 cm / 15 deg of its target or ``max_steps`` is reached.  The host looks at the done
+        flags only every ``check_every`` steps (1 = the reference's per-step behaviour).
+
+        :returns: trajectory [B, L+1, 7] and lengths int32 [B] (number of valid waypoints per env,
+                  including the start configuration; later rows repeat the final configuration).
+        """
+        assert self.done is not None, "call track_success(target_poses) first"
+        lim = self.limits
+        traj = [(self.q_norm + 1) * (lim[:, 1] - lim[:, 0]) / 2 + lim[:, 0]]
+        for i in range(max_steps):
+            traj.append(self.step().clone())
+            if (i + 1) % check_every == 0 and bool(torch.all(self.done != 0)):
+                break
+        return torch.stack(traj, dim=1), self.steps + 1
+
+
+def rollout_until_success(mdl: MotionPolicyNetwork, q0, target, point_cloud: torch.Tensor, fk_sampler: FrankaSampler,
+                          max_rollout_length: int = 150) -> np.ndarray:
+    """Reference signature (run_inference.py:137-191) for one problem.
+
+    :param q0: start configuration [7]; :param target: pose of ``right_gripper`` -- a 4x4 matrix or
+        any object with ``.matrix``; :param point_cloud: [1, 2048+4096+128, 4] on the GPU (mutated in place).
+    :rtype np.ndarray: the trajectory [T, 7], T <= max_rollout_length + 1
+    """
+    assert point_cloud.ndim == 3 and point_cloud.size(0) == 1
+    dev = point_cloud.device
+    q = torch.as_tensor(np.asarray(q0, dtype=np.float32)).reshape(1, 7).to(dev)
+    lim = torch.as_tensor(ft.JOINT_LIMITS_REAL, dtype=torch.float32, device=dev)
+    tm = torch.as_tensor(np.asarray(getattr(target, "matrix", target), dtype=np.float32)).reshape(1, 4, 4).to(dev)
+    zeros = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+    prob = {"xyz": point_cloud, "q_norm": (q - lim[:, 0]) / (lim[:, 1] - lim[:, 0]) * 2 - 1,
+            "cuboid_centers": zeros(1, 1, 3), "cuboid_dims": zeros(1, 1, 3),
+            "cuboid_quats": torch.tensor([[[1.0, 0, 0, 0]]], device=dev), "cylinder_centers": zeros(1, 1, 3),
+            "cylinder_radii": zeros(1, 1, 1), "cylinder_heights": zeros(1, 1, 1),
+            "cylinder_quats": torch.tensor([[[1.0, 0, 0, 0]]], device=dev)}
+    eng = RolloutEngine(mdl, prob, robot_subset=fk_sampler.draw_subset(2048))
+    eng.sampler = fk_sampler
+    eng.track_success(tm)
+    traj, lengths = eng.rollout_until_success(max_rollout_length, check_every=1)
+    return traj[0, : int(lengths[0])].cpu().numpy()

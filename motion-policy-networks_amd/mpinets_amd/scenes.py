@@ -178,6 +178,42 @@ def sample_scene_clouds_host(scn: Dict[str, np.ndarray], num_points: int, seed: 
     return world.astype(np.float32)
 
 
+def sample_scene_clouds(prims: Dict[str, torch.Tensor], num_points: int, seed: int, out: Optional[torch.Tensor] = None,
+                        write_label: bool = False, return_aux: bool = False):
+    """Device-side batched ``construct_mixed_point_cloud`` (geometry.py:571-608; csrc/scene.hip).
+
+    ``prims``: cuboid_{centers,dims,quats} [B,M1,*], cylinder_{centers,radii,heights,quats} [B,M2,*] on the
+    GPU (zero-volume rows are skipped like data_loader.py:248,256).  Writes ``out[:, :num_points, :3]``
+    (``out`` may be a slab view ``xyz[:, 2048:6144]``; default: a fresh [B,N,3] tensor), plus the
+    shuffled obstacle label in column 3 when ``write_label``.  Deterministic in (seed, env index).
+    """
+    from . import _lib
+
+    cc, cd, cq = (_lib.f32c(prims[k]) for k in ("cuboid_centers", "cuboid_dims", "cuboid_quats"))
+    yc, yr, yh, yq = (_lib.f32c(prims[k]) for k in ("cylinder_centers", "cylinder_radii", "cylinder_heights",
+                                                    "cylinder_quats"))
+    _lib.require_cuda(cc, yc)
+    B, M1 = cd.shape[:2]
+    M2 = yr.shape[1]
+    dev = cc.device
+    if out is None:
+        out = torch.empty((B, num_points, 4 if write_label else 3), dtype=torch.float32, device=dev)
+    assert out.ndim == 3 and out.size(0) == B and out.size(1) >= num_points and out.stride(2) == 1
+    assign = torch.empty((B, num_points), dtype=torch.int16, device=dev)
+    labels = torch.zeros((B, M1 + M2), dtype=torch.uint8, device=dev)
+    nobs = torch.zeros(B, dtype=torch.int32, device=dev)
+    for b0 in range(0, B, 65535):
+        nb = min(65535, B - b0)
+        sl = slice(b0, b0 + nb)
+        _lib.call("mpx_scene_cloud", _lib.ptr(cc[sl]), _lib.ptr(cd[sl]), _lib.ptr(cq[sl]), M1, _lib.ptr(yc[sl]),
+                  _lib.ptr(yr[sl]), _lib.ptr(yh[sl]), _lib.ptr(yq[sl]), M2, nb, num_points, int(seed) + b0 * 0x9E3779B97F4A7C15 % (1 << 63),
+                  _lib.ptr(assign[sl]), _lib.ptr(labels[sl]), _lib.ptr(nobs[sl]), _lib.ptr(out[sl]), out.stride(0),
+                  out.stride(1), int(write_label))
+    if return_aux:
+        return out, assign, labels, nobs
+    return out
+
+
 def random_configurations(B: int, seed: int = 0) -> np.ndarray:
     """q ~ U(joint limits), float32 [B,7] (C2 of BASELINE.json)."""
     rng = np.random.default_rng(seed + 1000003)
@@ -193,7 +229,7 @@ def linear_trajectories(B: int, T: int, seed: int = 0) -> np.ndarray:
 
 
 def make_problem_batch(B: int, seed: int = 0, device="cuda:0", kinds=("tabletop",), M1: int = 16, M2: int = 16,
-                       scene_pool: Optional[int] = None) -> Dict[str, torch.Tensor]:
+                       scene_pool: Optional[int] = None, device_clouds: bool = False) -> Dict[str, torch.Tensor]:
     """A batch of planning problems on ``device``: primitives, start configuration, target pose and
     the ``[B, 2048+4096+128, 4]`` slab (robot | scene | target rows, label column 0/1/2 --
     ``mpinets/data_loader.py:261-278``).  ``scene_pool`` bounds the number of distinct scenes
@@ -203,7 +239,7 @@ def make_problem_batch(B: int, seed: int = 0, device="cuda:0", kinds=("tabletop"
     dev = torch.device(device)
     nscene = B if scene_pool is None else min(B, scene_pool)
     scn = make_scenes(nscene, seed, kinds, M1, M2)
-    cloud = sample_scene_clouds_host(scn, NUM_OBSTACLE_POINTS, seed)
+    cloud = None if device_clouds else sample_scene_clouds_host(scn, NUM_OBSTACLE_POINTS, seed)
     rep = (B + nscene - 1) // nscene
     tile = lambda a: np.tile(a, (rep,) + (1,) * (a.ndim - 1))[:B]
     out = {k: torch.from_numpy(tile(v)).to(dev) for k, v in scn.items()}
@@ -219,7 +255,10 @@ def make_problem_batch(B: int, seed: int = 0, device="cuda:0", kinds=("tabletop"
     xyz[:, NUM_ROBOT_POINTS + NUM_OBSTACLE_POINTS:, 3] = 2
     subset = sampler.draw_subset(NUM_ROBOT_POINTS)
     sampler.sample_into(q, xyz, subset)
-    xyz[:, NUM_ROBOT_POINTS:NUM_ROBOT_POINTS + NUM_OBSTACLE_POINTS, :3] = torch.from_numpy(tile(cloud)).to(dev)
+    if device_clouds:  # every environment gets its own draw, even when the primitives are tiled
+        sample_scene_clouds(out, NUM_OBSTACLE_POINTS, seed, out=xyz[:, NUM_ROBOT_POINTS:NUM_ROBOT_POINTS + NUM_OBSTACLE_POINTS])
+    else:
+        xyz[:, NUM_ROBOT_POINTS:NUM_ROBOT_POINTS + NUM_OBSTACLE_POINTS, :3] = torch.from_numpy(tile(cloud)).to(dev)
     target_pose = frames_to_matrix(franka_fk(q_target)[:, ft.LINK_ID["right_gripper"]])
     xyz[:, NUM_ROBOT_POINTS + NUM_OBSTACLE_POINTS:, :3] = sampler.sample_end_effector(target_pose, NUM_TARGET_POINTS)
     np.random.set_state(state)

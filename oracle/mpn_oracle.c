@@ -442,3 +442,189 @@ ORC_API void orc_group_points(const float *xyz, int stride, const float *new_xyz
           o[(3 + c) * plane] = feat[((size_t)b * C + c) * N + k];
       }
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Batched scene clouds.  The reference (mpinets/geometry.py:571-608) draws from NumPy's global
+ * RNG inside geometrout, so only its DISTRIBUTION is defined: pools of int(p_i*N)+500 i.i.d.
+ * surface samples per obstacle (:598-604), N pool slots without replacement in random order
+ * (:608), labels a shuffled 1..K (:594-595).  The engine samples that distribution with
+ * Philox4x32-10 (csrc/scene.hip); this is the same procedure restated for bit-exact checks of
+ * the obstacle ids / labels and ulp-level checks of the coordinates.  Distributional agreement
+ * with the reference's own function is tested separately (tests/test_scene_cloud.py).
+ * ---------------------------------------------------------------------------------------- */
+static void orc_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                       uint32_t out[4]) {
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+ORC_API void orc_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+  orc_philox(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1], out);
+}
+
+static float orc_u01(uint32_t x) { return (float)(x >> 8) * 5.9604644775390625e-08f; }
+
+static double obstacle_area(int m, int M1, const float *cd, const float *yr, const float *yh) {
+  const double PI = 3.14159265358979323846;
+  if (m < M1) {
+    const float *d = cd + 3 * m;
+    if (is_zero(d[0]) || is_zero(d[1]) || is_zero(d[2])) return 0.0;
+    return 2.0 * ((double)d[0] * d[1] + (double)d[0] * d[2] + (double)d[1] * d[2]);
+  }
+  float r = yr[m - M1], h = yh[m - M1];
+  if (is_zero(r) || is_zero(h)) return 0.0;
+  return 2.0 * PI * (double)r * (double)h + 2.0 * PI * (double)r * (double)r;
+}
+
+/* assign uint16 [B,N]; labels uint8 [B,M1+M2]; n_obstacles int32 [B] */
+ORC_API void orc_scene_assign(const float *cub_dims, int M1, const float *cyl_radii, const float *cyl_heights,
+                              int M2, int B, int N, uint64_t seed, uint16_t *assign, uint8_t *labels,
+                              int32_t *n_obstacles) {
+  const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+  const int M = M1 + M2;
+  uint32_t *rem = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(M > 0 ? M : 1));
+  for (int b = 0; b < B; ++b) {
+    const float *cd = cub_dims + (size_t)b * M1 * 3, *yr = cyl_radii + (size_t)b * M2, *yh = cyl_heights + (size_t)b * M2;
+    double total = 0.0;
+    int K = 0;
+    for (int m = 0; m < M; ++m) {
+      double a = obstacle_area(m, M1, cd, yr, yh);
+      total += a;
+      K += a > 0.0;
+    }
+    n_obstacles[b] = K;
+    uint16_t *arow = assign + (size_t)b * N;
+    uint8_t *lab = labels + (size_t)b * M;
+    if (K == 0) {
+      for (int j = 0; j < N; ++j) arow[j] = 0xFFFF;
+      for (int m = 0; m < M; ++m) lab[m] = 0;
+      continue;
+    }
+    uint32_t pool = 0;
+    for (int m = 0; m < M; ++m) {
+      double a = obstacle_area(m, M1, cd, yr, yh);
+      rem[m] = a > 0.0 ? (uint32_t)(int)((a / total) * (double)N) + 500u : 0u;
+      pool += rem[m];
+    }
+    int live = 0;
+    for (int m = 0; m < M; ++m) lab[m] = rem[m] ? (uint8_t)(++live) : 0;
+    int i = K - 1;
+    uint32_t ctr = 0;
+    for (int m = M - 1; m >= 0 && i > 0; --m) {
+      if (!rem[m]) continue;
+      uint32_t r[4];
+      orc_philox(ctr++, (uint32_t)b, 2u, 0u, k0, k1, r);
+      int jpos = (int)(((uint64_t)r[0] * (uint32_t)(i + 1)) >> 32);
+      int t = -1;
+      for (int mm = 0; mm < M; ++mm)
+        if (rem[mm] && ++t == jpos) {
+          uint8_t tmp = lab[m];
+          lab[m] = lab[mm];
+          lab[mm] = tmp;
+          break;
+        }
+      --i;
+    }
+    for (int j0 = 0; j0 < N; j0 += 4) {
+      uint32_t r[4];
+      orc_philox((uint32_t)(j0 >> 2), (uint32_t)b, 1u, 0u, k0, k1, r);
+      for (int u = 0; u < 4 && j0 + u < N; ++u) {
+        uint32_t pick = (uint32_t)(((uint64_t)r[u] * pool) >> 32);
+        int m = 0;
+        while (pick >= rem[m]) {
+          pick -= rem[m];
+          ++m;
+        }
+        rem[m] -= 1;
+        pool -= 1;
+        arow[j0 + u] = (uint16_t)m;
+      }
+    }
+  }
+  free(rem);
+}
+
+/* out [B,N,3]: one uniform surface sample per assigned obstacle id */
+ORC_API void orc_scene_points(const float *cub_c, const float *cub_d, const float *cub_q, int M1,
+                              const float *cyl_c, const float *cyl_r, const float *cyl_h, const float *cyl_q,
+                              int M2, int B, int N, uint64_t seed, const uint16_t *assign, float *out) {
+  const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+  for (int b = 0; b < B; ++b)
+    for (int j = 0; j < N; ++j) {
+      float *o = out + ((size_t)b * N + j) * 3;
+      int m = assign[(size_t)b * N + j];
+      if (m == 0xFFFF) {
+        o[0] = o[1] = o[2] = 0.0f;
+        continue;
+      }
+      uint32_t r[4];
+      orc_philox((uint32_t)j, (uint32_t)b, 3u, 0u, k0, k1, r);
+      float u0 = orc_u01(r[0]), u1 = orc_u01(r[1]), u2 = orc_u01(r[2]), u3 = orc_u01(r[3]);
+      float lx, ly, lz;
+      const float *ctr, *q;
+      if (m < M1) {
+        const float *d = cub_d + ((size_t)b * M1 + m) * 3;
+        float ax = d[1] * d[2], ay = d[0] * d[2], az = d[0] * d[1];
+        float t = u0 * (ax + ay + az);
+        float sgn = u1 < 0.5f ? -0.5f : 0.5f;
+        if (t < ax) {
+          lx = sgn * d[0]; ly = (u2 - 0.5f) * d[1]; lz = (u3 - 0.5f) * d[2];
+        } else if (t < ax + ay) {
+          lx = (u2 - 0.5f) * d[0]; ly = sgn * d[1]; lz = (u3 - 0.5f) * d[2];
+        } else {
+          lx = (u2 - 0.5f) * d[0]; ly = (u3 - 0.5f) * d[1]; lz = sgn * d[2];
+        }
+        ctr = cub_c + ((size_t)b * M1 + m) * 3;
+        q = cub_q + ((size_t)b * M1 + m) * 4;
+      } else {
+        int c = m - M1;
+        float rad = cyl_r[(size_t)b * M2 + c], h = cyl_h[(size_t)b * M2 + c];
+        float side = 2.0f * rad * h, cap = rad * rad;
+        float t = u0 * (side + 2.0f * cap);
+        float s, co;
+        orc_sincosf(u1 * 6.28318530717958647692f, &s, &co);
+        float rho = rad;
+        lz = (u2 - 0.5f) * h;
+        if (t >= side) {
+          rho = rad * sqrtf(u3);
+          lz = t < side + cap ? -0.5f * h : 0.5f * h;
+        }
+        lx = rho * co;
+        ly = rho * s;
+        ctr = cyl_c + ((size_t)b * M2 + c) * 3;
+        q = cyl_q + ((size_t)b * M2 + c) * 4;
+      }
+      float n = sqrtf(fmaf(q[3], q[3], fmaf(q[2], q[2], fmaf(q[1], q[1], q[0] * q[0]))));
+      float w = q[0] / n, a = q[1] / n, bb = q[2] / n, c = q[3] / n;
+      float r00 = 1.0f - 2.0f * (bb * bb + c * c), r01 = 2.0f * (a * bb - w * c), r02 = 2.0f * (a * c + w * bb);
+      float r10 = 2.0f * (a * bb + w * c), r11 = 1.0f - 2.0f * (a * a + c * c), r12 = 2.0f * (bb * c - w * a);
+      float r20 = 2.0f * (a * c - w * bb), r21 = 2.0f * (bb * c + w * a), r22 = 1.0f - 2.0f * (a * a + bb * bb);
+      o[0] = fmaf(r02, lz, fmaf(r01, ly, r00 * lx)) + ctr[0];
+      o[1] = fmaf(r12, lz, fmaf(r11, ly, r10 * lx)) + ctr[1];
+      o[2] = fmaf(r22, lz, fmaf(r21, ly, r20 * lx)) + ctr[2];
+    }
+}
+
+/* run_inference.py:176-187 success test on given end-effector frames (R row-major + t) */
+ORC_API void orc_success(const float *eff_frames, const float *targets, int B, float pos_tol, float cos_tol,
+                         uint8_t *ok, float *pos_err, float *cos_ang) {
+  for (int b = 0; b < B; ++b) {
+    const float *e = eff_frames + (size_t)b * 12, *t = targets + (size_t)b * 16;
+    float dx = e[9] - t[3], dy = e[10] - t[7], dz = e[11] - t[11];
+    float err = sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
+    float tr = 0.0f;
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) tr = fmaf(e[3 * r + c], t[4 * r + c], tr);
+    float ca = (tr - 1.0f) * 0.5f;
+    pos_err[b] = err;
+    cos_ang[b] = ca;
+    ok[b] = err < pos_tol && ca > cos_tol;
+  }
+}

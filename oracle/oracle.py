@@ -159,6 +159,43 @@ def frames_to_4x4(T) -> np.ndarray:
     return out
 
 
+# ---------------------------------------------------------------- scene clouds (distribution only)
+def philox4x32(ctr, key) -> np.ndarray:
+    c = np.ascontiguousarray(ctr, dtype=np.uint32)
+    k = np.ascontiguousarray(key, dtype=np.uint32)
+    out = np.empty(4, np.uint32)
+    lib().orc_philox4x32(_p(c), _p(k), _p(out))
+    return out
+
+
+def scene_cloud(scn: dict, num_points: int, seed: int):
+    """Restatement of csrc/scene.hip.  scn: cuboid_{centers,dims,quats}, cylinder_{centers,radii,heights,quats}.
+    -> points float32 [B,N,3], assign uint16 [B,N], labels uint8 [B,M1+M2], n_obstacles int32 [B]."""
+    cc, cd, cq = _f(scn["cuboid_centers"]), _f(scn["cuboid_dims"]), _f(scn["cuboid_quats"])
+    yc, yr, yh, yq = (_f(scn["cylinder_centers"]), _f(scn["cylinder_radii"]), _f(scn["cylinder_heights"]),
+                      _f(scn["cylinder_quats"]))
+    B, M1 = cd.shape[:2]
+    M2 = yr.shape[1]
+    assign = np.empty((B, num_points), np.uint16)
+    labels = np.zeros((B, M1 + M2), np.uint8)
+    nobs = np.zeros(B, np.int32)
+    lib().orc_scene_assign(_p(cd), M1, _p(yr), _p(yh), M2, B, num_points, ctypes.c_uint64(seed), _p(assign),
+                           _p(labels), _p(nobs))
+    pts = np.empty((B, num_points, 3), np.float32)
+    lib().orc_scene_points(_p(cc), _p(cd), _p(cq), M1, _p(yc), _p(yr), _p(yh), _p(yq), M2, B, num_points,
+                           ctypes.c_uint64(seed), _p(assign), _p(pts))
+    return pts, assign, labels, nobs
+
+
+def success(eff_frames, targets, pos_tol=0.01, cos_tol=float(np.cos(np.radians(15.0)))):
+    e, t = _f(eff_frames), _f(targets)
+    B = e.shape[0]
+    ok = np.zeros(B, np.uint8)
+    pe, ca = np.empty(B, np.float32), np.empty(B, np.float32)
+    lib().orc_success(_p(e), _p(t), B, ctypes.c_float(pos_tol), ctypes.c_float(cos_tol), _p(ok), _p(pe), _p(ca))
+    return ok.astype(bool), pe, ca
+
+
 # ---------------------------------------------------------------- pointnet2_ops (unpinned)
 def opt_n_threads(n: int) -> int:
     return int(lib().orc_opt_n_threads(ctypes.c_int(n)))

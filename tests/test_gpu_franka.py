@@ -137,7 +137,7 @@ def test_joint_step(oracle):
     lim = T(ft.JOINT_LIMITS_REAL.astype(np.float32))
     a, b = torch.empty(100, 7, device=dev()), torch.empty(100, 7, device=dev())
     tq, td = T(qn), T(dq)
-    _lib.call("mpx_joint_step", _lib.ptr(tq), _lib.ptr(td), _lib.ptr(lim), 100, _lib.ptr(a), _lib.ptr(b))
+    _lib.call("mpx_joint_step", _lib.ptr(tq), _lib.ptr(td), _lib.ptr(lim), 100, _lib.ptr(a), _lib.ptr(b), None)
     ref_n = np.clip(qn + dq, -1, 1)
     np.testing.assert_array_equal(a.cpu().numpy(), ref_n)
     np.testing.assert_allclose(b.cpu().numpy(), oracle.unnormalize(ref_n, ft.JOINT_LIMITS_REAL), atol=1e-6)
