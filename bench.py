@@ -79,7 +79,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--envs", type=int, default=8192, help="environments per GPU")
     ap.add_argument("--cpu-envs", type=int, default=8, help="env-steps in the CPU baseline sample (0 = skip)")
-    ap.add_argument("--scene-pool", type=int, default=256, help="distinct host-generated scenes tiled over the batch")
+    ap.add_argument("--scene-pool", type=int, default=1024, help="distinct host-generated primitive sets tiled over the batch (clouds are drawn per env on the device)")
     args = ap.parse_args()
 
     from mpinets_amd import _lib, shard
@@ -100,7 +100,7 @@ def main():
     model = MotionPolicyNetwork().to(dev).eval()
     envs = shard.env_range(rank, n_gpus, B)
     prob = make_problem_batch(B, seed=1000 + rank, device=dev, kinds=("tabletop",), M1=16, M2=16,
-                              scene_pool=args.scene_pool)
+                              scene_pool=args.scene_pool, device_clouds=True)
     eng = RolloutEngine(model, prob)
 
     for _ in range(args.warmup):
