@@ -1,0 +1,424 @@
+// sa_mlp_bf16.hip -- split-bf16 ("bf16x3") variant of the fused QueryAndGroup + shared MLP + max-pool.
+//
+// Same role, register-chaining scheme and outputs as sa_mlp.hip (PointnetSAModule.forward body,
+// /root/reference/mpinets/model.py:366-382), but every fp32 product x*w is evaluated as
+//     x_hi*w_hi + x_hi*w_lo + x_lo*w_hi        (x = x_hi + x_lo, w = w_hi + w_lo, all four bf16)
+// on v_mfma_f32_32x32x16_bf16 with fp32 accumulation: 3 MFMAs of 32 cycles per 16 k-values instead
+// of 8 fp32 MFMAs of 64 cycles -- 5.3x fewer matrix-pipe cycles.  The dropped x_lo*w_lo term and the
+// split residuals are O(2^-16) relative; measured against the fp32 oracle the policy output moves
+// by ~3e-7 (tolerance 1e-5), FPS / ball-query indices are untouched (they never see features).
+//
+// At this rate the weight stream is too wide to be fetched per wave from L2 (85 B/clk/CU), so the
+// 8 waves of a workgroup walk the stream in lockstep: chunks of 4 step-tiles (8 KB: a 1 KB w_hi and a
+// 1 KB w_lo operand block each) are staged global -> registers -> LDS by all waves together through
+// a 2-deep ring, one barrier per chunk, and every wave reads its MFMA operands from LDS
+// (16 B/lane ds_read_b128, lane-linear -> conflict free).  L2 traffic per workgroup drops 8x.
+// Activations never leave registers: layer outputs (fp32 accumulators, point on the lane axis) are
+// split into packed bf16 hi/lo pairs in place and are the next layer's B operand as they are.
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+#define PAD_CH (-1)
+constexpr int G = 4;                      // step-tiles per chunk
+constexpr int TILE_BYTES = 2048;          // w_hi (64 lanes x 16 B) + w_lo
+constexpr int CHUNK_BYTES = G * TILE_BYTES;
+constexpr int WAVES = 8;
+
+template <int CF, int C1, int C2, int C3>
+struct BCfg {
+  static_assert(CF == 1 || CF % 16 == 0, "feature channels: 1 or a multiple of 16");
+  static_assert(C1 % 32 == 0 && C2 % 32 == 0 && C3 % 32 == 0, "layer widths must be multiples of 32");
+  static constexpr int CIN = 3 + CF;
+  static constexpr int HALF0 = CF == 1 ? 2 : 2 + CF / 2;           // layer-1 inputs held per lane-half
+  static constexpr int KS0 = (HALF0 + 7) / 8;                       // K16 steps of layer 1
+  static constexpr int KS1 = C1 / 16, KS2 = C2 / 16;                // K16 steps of layers 2, 3
+  static constexpr int OT1 = C1 / 32, OT2 = C2 / 32, OT3 = C3 / 32;
+  static constexpr int ST1 = KS0 * OT1, ST2 = KS1 * OT2, ST3 = OT3 * KS2;  // real step-tiles per layer
+  // every layer is padded to whole chunks (zero-weight dummies) so that layer boundaries -- where
+  // accumulators are turned into the next layer's operands -- coincide with chunk boundaries
+  static constexpr int ST1P = (ST1 + G - 1) / G * G, ST2P = (ST2 + G - 1) / G * G, ST3P = (ST3 + G - 1) / G * G;
+  static constexpr int O2 = ST1P, O3 = ST1P + ST2P;                 // first step-tile of layers 2 and 3
+  static constexpr int STP = ST1P + ST2P + ST3P;
+  static constexpr int NCH = STP / G;
+  static_assert(KS2 % G == 0, "a chunk of layer 3 must stay inside one output tile");
+  __host__ __device__ static constexpr int layer_of(int st) { return st < O2 ? 1 : (st < O3 ? 2 : 3); }
+  __host__ __device__ static constexpr bool is_real(int st) {
+    return st < O2 ? st < ST1 : (st < O3 ? st - O2 < ST2 : st - O3 < ST3);
+  }
+  static constexpr int64_t W_BYTES = (int64_t)STP * TILE_BYTES;
+  static constexpr int64_t B1_OFF = W_BYTES, B2_OFF = B1_OFF + 4 * C1, B3_OFF = B2_OFF + 4 * C2;
+  static constexpr int64_t TOTAL_BYTES = B3_OFF + 4 * C3;
+
+  // layer-1 input channel held by lane-half h at position i (0..8*KS0-1)
+  __host__ __device__ static int chan0(int i, int h) {
+    if (CF == 1) return i == 0 ? (h ? 1 : 0) : (i == 1 ? (h ? 3 : 2) : PAD_CH);  // (dx|dy), (dz|label)
+    if (i == 0) return h ? 1 : 0;
+    if (i == 1) return h ? PAD_CH : 2;
+    if (i < 2 + CF / 2) return 3 + h * (CF / 2) + (i - 2);
+    return PAD_CH;
+  }
+  // layers 2/3: K16 step s, element e of lane-half h  ->  channel of the previous layer
+  __host__ __device__ static int chan_tile(int s, int e, int h) {
+    const int it = s >> 1, r = 8 * (s & 1) + e;
+    return it * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+  }
+};
+
+__device__ __forceinline__ unsigned short f2bf(float x) {  // round-to-nearest-even, like (__bf16)x
+  __bf16 b = (__bf16)x;
+  return __builtin_bit_cast(unsigned short, b);
+}
+__device__ __forceinline__ float bf2f(unsigned short u) { return __uint_as_float((unsigned)u << 16); }
+
+// ---- weight packing: [step-tile][hi|lo][lane][8 x bf16], then the three fp32 bias vectors ------------------
+template <class Cfg>
+__global__ void __launch_bounds__(256)
+    sa_pack_bf16_kernel(const float *__restrict__ w1, const float *__restrict__ b1, const float *__restrict__ w2,
+                        const float *__restrict__ b2, const float *__restrict__ w3, const float *__restrict__ b3,
+                        int c1, int c2, int c3, unsigned char *__restrict__ wpack) {
+  const int64_t e_id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t n_w = (int64_t)Cfg::STP * 64 * 8;  // one thread per (step-tile, lane, element): writes hi and lo
+  if (e_id < n_w) {
+    const int e = (int)(e_id & 7), lane = (int)((e_id >> 3) & 63), st = (int)(e_id >> 9);
+    const int h = lane >> 5, o32 = lane & 31;
+    float v = 0.0f;
+    if (Cfg::is_real(st)) {
+      int in, cin, ot;
+      const float *w;
+      if (st < Cfg::O2) {
+        const int s = st / Cfg::OT1;
+        ot = st % Cfg::OT1;
+        in = Cfg::chan0(8 * s + e, h);
+        cin = Cfg::CIN;
+        w = w1;
+      } else if (st < Cfg::O3) {
+        const int q = st - Cfg::O2, s = q / Cfg::OT2;
+        ot = q % Cfg::OT2;
+        in = Cfg::chan_tile(s, e, h);
+        cin = c1;
+        w = w2;
+      } else {
+        const int q = st - Cfg::O3, s = q % Cfg::KS2;
+        ot = q / Cfg::KS2;
+        in = Cfg::chan_tile(s, e, h);
+        cin = c2;
+        w = w3;
+      }
+      if (in != PAD_CH) v = w[(size_t)(ot * 32 + o32) * cin + in];
+    }
+    const unsigned short hi = f2bf(v);
+    const unsigned short lo = f2bf(v - bf2f(hi));
+    unsigned short *dst = reinterpret_cast<unsigned short *>(wpack + (int64_t)st * TILE_BYTES);
+    dst[lane * 8 + e] = hi;
+    dst[512 + lane * 8 + e] = lo;
+  }
+  const int64_t b_id = e_id - n_w;
+  if (b_id >= 0 && b_id < c1 + c2 + c3) {
+    float *bd = reinterpret_cast<float *>(wpack + Cfg::B1_OFF);
+    bd[b_id] = b_id < c1 ? b1[b_id] : (b_id < c1 + c2 ? b2[b_id - c1] : b3[b_id - c1 - c2]);
+  }
+}
+
+// ---- device helpers -------------------------------------------------------------------------------------------
+__device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ void split8(const float (&v)[8], bf16x8 &hi, bf16x8 &lo) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const __bf16 h = (__bf16)v[e];
+    hi[e] = h;
+    lo[e] = (__bf16)(v[e] - (float)h);
+  }
+}
+
+__device__ __forceinline__ float4 bload16(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff) {
+  const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
+  return make_float4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w));
+}
+
+__device__ __forceinline__ f32x16 bias_tile(__amdgpu_buffer_rsrc_t rsrc, int bias_off_bytes, int ot, int half) {
+  f32x16 v;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const float4 q = bload16(rsrc, half * 16, bias_off_bytes + (ot * 32 + 8 * g) * 4);
+    v[4 * g + 0] = q.x;
+    v[4 * g + 1] = q.y;
+    v[4 * g + 2] = q.z;
+    v[4 * g + 3] = q.w;
+  }
+  return v;
+}
+
+// relu + split one accumulator tile into the two K16 operand pairs of the next layer
+__device__ __forceinline__ void relu_split_tile(const f32x16 &acc, bf16x8 (&hi)[2], bf16x8 (&lo)[2]) {
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = fmaxf(acc[8 * u + e], 0.0f);
+    split8(v, hi[u], lo[u]);
+  }
+}
+
+// The lockstep weight stream of one workgroup.
+struct Stream {
+  const unsigned char *gsrc;   // this lane's slice of chunk 0 in global memory
+  unsigned char *lds;          // ring base
+  int lds_slice;               // this lane's byte offset inside a chunk
+  int lds_lane;                // lane * 16
+  int cur;                     // ring slot holding the chunk being consumed (0/1)
+  int next_cc;                 // cyclic index of the chunk to fetch next
+  int nch;
+  uint4 stage;                 // chunk (current + 1), in flight or landed
+
+  __device__ __forceinline__ void fetch() {
+    stage = *reinterpret_cast<const uint4 *>(gsrc + (size_t)next_cc * CHUNK_BYTES);
+    next_cc = next_cc + 1 == nch ? 0 : next_cc + 1;
+  }
+  __device__ __forceinline__ void start() {  // chunk 0 -> slot 0, chunk 1 -> stage
+    fetch();
+    *reinterpret_cast<uint4 *>(lds + lds_slice) = stage;
+    fetch();
+    cur = 0;
+    __syncthreads();
+  }
+  // call after the last operand read of the current chunk
+  __device__ __forceinline__ void advance() {
+    *reinterpret_cast<uint4 *>(lds + (cur ^ 1) * CHUNK_BYTES + lds_slice) = stage;
+    fetch();
+    __syncthreads();
+    cur ^= 1;
+  }
+  __device__ __forceinline__ void operands(int j, bf16x8 &hi, bf16x8 &lo) const {
+    const unsigned char *p = lds + cur * CHUNK_BYTES + j * TILE_BYTES + lds_lane;
+    hi = *reinterpret_cast<const bf16x8 *>(p);
+    lo = *reinterpret_cast<const bf16x8 *>(p + 1024);
+  }
+};
+
+template <int CF, int C1, int C2, int C3>
+__global__ void __launch_bounds__(512, 2)
+    sa_mlp_bf16_kernel(const float *__restrict__ xyz, int stride, const float *__restrict__ new_xyz, int new_stride,
+                       const float *__restrict__ feat, int feat_stride, const int32_t *__restrict__ idx,
+                       int64_t n_query, int N, int npoint, int nsample, const unsigned char *__restrict__ wpack,
+                       float *__restrict__ out, int out_stride) {
+  using Cfg = BCfg<CF, C1, C2, C3>;
+  __shared__ __attribute__((aligned(16))) unsigned char ring[2 * CHUNK_BYTES];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int half = lane >> 5, col = lane & 31;
+  int64_t qid = (int64_t)blockIdx.x * WAVES + wave;
+  const bool live = qid < n_query;  // wave-uniform; dead waves still walk the stream (barriers)
+  if (!live) qid = n_query - 1;
+  const int64_t b = qid / npoint;
+
+  Stream ws;
+  ws.gsrc = wpack + threadIdx.x * 16;
+  ws.lds = ring;
+  ws.lds_slice = threadIdx.x * 16;
+  ws.lds_lane = lane * 16;
+  ws.next_cc = 0;
+  ws.nch = Cfg::NCH;
+  ws.start();
+
+  const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<unsigned char *>(wpack), 0, (int)Cfg::TOTAL_BYTES, 0x00020000);
+  const float *bias3 = reinterpret_cast<const float *>(wpack + Cfg::B3_OFF);
+
+  const float *ctr = new_xyz + qid * new_stride;
+  const float cx = ctr[0], cy = ctr[1], cz = ctr[2];
+  const int32_t *nbr = idx + qid * nsample;
+  const float *cloud = xyz + b * N * (int64_t)stride;
+  const float *fbase = feat + b * N * (int64_t)feat_stride;
+
+  float omax[Cfg::OT3];
+#pragma unroll
+  for (int ot = 0; ot < Cfg::OT3; ++ot) omax[ot] = -__builtin_inff();
+
+  for (int rt = 0; rt < nsample; rt += 32) {
+    int b1o = (int)Cfg::B1_OFF, b2o = (int)Cfg::B2_OFF;
+    asm volatile("" : "+s"(b1o), "+s"(b2o));  // keep the (loop-invariant) bias loads inside the loop
+    const int k = nbr[rt + col];
+    const float *p = cloud + (int64_t)k * stride;
+    const float *f = fbase + (int64_t)k * feat_stride;
+
+    // ---- layer-1 operands: this lane's half of its point's input vector, split hi/lo -------------------------
+    bf16x8 xh[Cfg::KS0], xl[Cfg::KS0];
+    {
+      float v[8 * Cfg::KS0];
+#pragma unroll
+      for (int i = 0; i < 8 * Cfg::KS0; ++i) v[i] = 0.0f;
+      const float dx = p[0] - cx, dy = p[1] - cy, dz = p[2] - cz;
+      v[0] = half ? dy : dx;
+      if (CF == 1) {
+        v[1] = half ? f[0] : dz;
+      } else {
+        v[1] = half ? 0.0f : dz;
+        const float4 *fr = reinterpret_cast<const float4 *>(f + half * (CF / 2));
+#pragma unroll
+        for (int i = 0; i < CF / 8; ++i) {
+          const float4 q = fr[i];
+          v[2 + 4 * i + 0] = q.x;
+          v[2 + 4 * i + 1] = q.y;
+          v[2 + 4 * i + 2] = q.z;
+          v[2 + 4 * i + 3] = q.w;
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < Cfg::KS0; ++s) {
+        float t8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t8[e] = v[8 * s + e];
+        split8(t8, xh[s], xl[s]);
+      }
+    }
+
+    // The whole neighbourhood tile is one unrolled walk over the STP step-tiles of the weight stream,
+    // G at a time.  `st` is a compile-time constant in every use below.
+    f32x16 a1[Cfg::OT1], a2[Cfg::OT2];
+    bf16x8 h1[Cfg::OT1][2], l1[Cfg::OT1][2], h2[Cfg::OT2][2], l2[Cfg::OT2][2];
+    f32x16 a3[2];
+#pragma unroll
+    for (int ot = 0; ot < Cfg::OT1; ++ot) a1[ot] = bias_tile(brsrc, b1o, ot, half);
+
+#pragma unroll
+    for (int c = 0; c < Cfg::NCH; ++c) {
+      bf16x8 wh[G], wl[G];
+#pragma unroll
+      for (int j = 0; j < G; ++j)
+        if (Cfg::is_real(c * G + j)) ws.operands(j, wh[j], wl[j]);
+      // three passes (hi*hi, lo*hi, hi*lo) over the chunk's step-tiles: consecutive MFMAs hit
+      // different accumulators
+#pragma unroll
+      for (int pass = 0; pass < 3; ++pass) {
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+          const int st = c * G + j;
+          if (!Cfg::is_real(st)) continue;
+          const bf16x8 w = pass == 1 ? wl[j] : wh[j];
+          if (st < Cfg::O2) {
+            const int s = st / Cfg::OT1, ot = st % Cfg::OT1;
+            a1[ot] = mfma_bf16(w, pass == 2 ? xl[s] : xh[s], a1[ot]);
+          } else if (st < Cfg::O3) {
+            const int q = st - Cfg::O2, s = q / Cfg::OT2, ot = q % Cfg::OT2;
+            a2[ot] = mfma_bf16(w, pass == 2 ? l1[s >> 1][s & 1] : h1[s >> 1][s & 1], a2[ot]);
+          } else {
+            const int q = st - Cfg::O3, s = q % Cfg::KS2;
+            // roles flipped: activations are the A operand, weights the B operand
+            a3[s & 1] = mfma_bf16(pass == 2 ? l2[s >> 1][s & 1] : h2[s >> 1][s & 1], w, a3[s & 1]);
+          }
+        }
+      }
+      ws.advance();
+      // ---- layer boundaries that fall on this chunk's end ------------------------------------------------
+      const int done_st = (c + 1) * G;  // (padded) step-tiles consumed so far
+      if (done_st == Cfg::O2) {
+#pragma unroll
+        for (int ot = 0; ot < Cfg::OT1; ++ot) relu_split_tile(a1[ot], h1[ot], l1[ot]);
+#pragma unroll
+        for (int ot = 0; ot < Cfg::OT2; ++ot) a2[ot] = bias_tile(brsrc, b2o, ot, half);
+      }
+      if (done_st == Cfg::O3) {
+#pragma unroll
+        for (int ot = 0; ot < Cfg::OT2; ++ot) relu_split_tile(a2[ot], h2[ot], l2[ot]);
+        a3[0] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        a3[1] = a3[0];
+      }
+      // end of an output tile of layer 3: pool its 32 points
+#pragma unroll
+      for (int j = 0; j < G; ++j) {
+        const int st = c * G + j;
+        if (st < Cfg::O3 || !Cfg::is_real(st)) continue;
+        const int q = st - Cfg::O3;
+        if (q % Cfg::KS2 == Cfg::KS2 - 1) {
+          const int ot = q / Cfg::KS2;
+          float m = a3[0][0] + a3[1][0];
+#pragma unroll
+          for (int r = 1; r < 16; ++r) m = fmaxf(m, a3[0][r] + a3[1][r]);
+          omax[ot] = fmaxf(omax[ot], m);
+          a3[0] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+          a3[1] = a3[0];
+        }
+      }
+    }
+  }
+
+  if (live) {
+    float *orow = out + qid * out_stride;
+#pragma unroll
+    for (int ot = 0; ot < Cfg::OT3; ++ot) {
+      float v = omax[ot];
+      v = fmaxf(v, __shfl_xor(v, 32));
+      const int ch = ot * 32 + col;
+      v = fmaxf(v + bias3[ch], 0.0f);
+      if (half == 0) orow[ch] = v;
+    }
+  }
+}
+
+// ---- host entry points --------------------------------------------------------------------------------------------
+#define SA_DISPATCH(CALL)                                                                   \
+  if (C == 1 && c1 == 64 && c2 == 64 && c3 == 64) { CALL(1, 64, 64, 64); }                  \
+  else if (C == 64 && c1 == 128 && c2 == 128 && c3 == 256) { CALL(64, 128, 128, 256); }     \
+  else {                                                                                    \
+    mpx_set_error("mpx_sa (bf16x3): unsupported MLP (C=%d, %d, %d, %d)", C, c1, c2, c3);    \
+    return 1;                                                                               \
+  }
+
+template <int CF, int C1, int C2, int C3>
+static int launch_sa_bf16(const float *xyz, int stride, const float *new_xyz, int new_stride, const float *feat,
+                          int feat_stride, const int32_t *idx, int B, int N, int npoint, int nsample,
+                          const void *wpack, float *out, int out_stride, mpx_stream_t stream) {
+  const int64_t nq = (int64_t)B * npoint;
+  MPX_REQUIRE(nq / WAVES + 1 < ((int64_t)1 << 31), "mpx_sa_mlp_bf16x3: too many query points");
+  hipLaunchKernelGGL((sa_mlp_bf16_kernel<CF, C1, C2, C3>), dim3((unsigned)((nq + WAVES - 1) / WAVES)), dim3(64 * WAVES),
+                     0, mpx_s(stream), xyz, stride, new_xyz, new_stride, feat, feat_stride, idx, nq, N, npoint, nsample,
+                     static_cast<const unsigned char *>(wpack), out, out_stride);
+  MPX_LAUNCH_CHECK("mpx_sa_mlp_bf16x3");
+}
+
+MPX_EXPORT int mpx_sa_mlp_bf16x3(const float *xyz, int stride, const float *new_xyz, int new_stride,
+                                 const float *feat, int feat_stride, int C, const int32_t *idx, int B, int N,
+                                 int npoint, int nsample, const void *wpack, int c1, int c2, int c3, float *out,
+                                 int out_stride, mpx_stream_t stream) {
+  MPX_REQUIRE(B >= 0 && N >= 1 && npoint >= 0, "mpx_sa_mlp_bf16x3: bad size");
+  MPX_REQUIRE(nsample > 0 && nsample % 32 == 0, "mpx_sa_mlp_bf16x3: nsample must be a positive multiple of 32");
+  MPX_REQUIRE(stride >= 3 && new_stride >= 3 && out_stride >= c3, "mpx_sa_mlp_bf16x3: bad stride");
+  MPX_REQUIRE(C == 1 || (feat_stride % 4 == 0 && ((uintptr_t)feat & 15) == 0),
+              "mpx_sa_mlp_bf16x3: feature rows must be 16-byte aligned");
+  MPX_REQUIRE(((uintptr_t)wpack & 15) == 0, "mpx_sa_mlp_bf16x3: wpack must be 16-byte aligned");
+  if (B == 0 || npoint == 0) return 0;
+#define CALL(a, b, c, d) \
+  return launch_sa_bf16<a, b, c, d>(xyz, stride, new_xyz, new_stride, feat, feat_stride, idx, B, N, npoint, nsample, wpack, out, out_stride, stream)
+  SA_DISPATCH(CALL)
+#undef CALL
+}
+
+MPX_EXPORT int64_t mpx_sa_pack_bf16x3_size(int C, int c1, int c2, int c3) {
+  if (C == 1 && c1 == 64 && c2 == 64 && c3 == 64) return BCfg<1, 64, 64, 64>::TOTAL_BYTES;
+  if (C == 64 && c1 == 128 && c2 == 128 && c3 == 256) return BCfg<64, 128, 128, 256>::TOTAL_BYTES;
+  return -1;
+}
+
+template <int CF, int C1, int C2, int C3>
+static int launch_pack_bf16(const float *w1, const float *b1, const float *w2, const float *b2, const float *w3,
+                            const float *b3, void *wpack, mpx_stream_t stream) {
+  using Cfg = BCfg<CF, C1, C2, C3>;
+  const int64_t n = (int64_t)Cfg::STP * 512 + C1 + C2 + C3;
+  hipLaunchKernelGGL(sa_pack_bf16_kernel<Cfg>, dim3(cdiv(n, 256)), dim3(256), 0, mpx_s(stream), w1, b1, w2, b2, w3, b3,
+                     C1, C2, C3, static_cast<unsigned char *>(wpack));
+  MPX_LAUNCH_CHECK("mpx_sa_pack_bf16x3");
+}
+
+MPX_EXPORT int mpx_sa_pack_bf16x3(const float *w1, const float *b1, const float *w2, const float *b2,
+                                  const float *w3, const float *b3, int C, int c1, int c2, int c3, void *wpack,
+                                  mpx_stream_t stream) {
+#define CALL(a, b, c, d) return launch_pack_bf16<a, b, c, d>(w1, b1, w2, b2, w3, b3, wpack, stream)
+  SA_DISPATCH(CALL)
+#undef CALL
+}

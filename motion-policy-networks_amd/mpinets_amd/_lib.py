@@ -40,11 +40,14 @@ PROTOTYPES = {
     "mpx_sa_mlp": [P, I, P, I, P, I, I, P, I, I, I, I, P, I, I, I, P, I, P],
     "mpx_sa_pack_size": [I, I, I, I],
     "mpx_sa_pack_weights": [P, P, P, P, P, P, I, I, I, I, P, P],
+    "mpx_sa_mlp_bf16x3": [P, I, P, I, P, I, I, P, I, I, I, I, P, I, I, I, P, I, P],
+    "mpx_sa_pack_bf16x3_size": [I, I, I, I],
+    "mpx_sa_pack_bf16x3": [P, P, P, P, P, P, I, I, I, I, P, P],
     "mpx_linear": [P, I, P, P, I, I, I, I, P, I, P],
     "mpx_groupnorm_leaky": [P, P, P, I, I, I, F, P, P],
     "mpx_rowmax": [P, I, I, I, I, P, I, P],
 }
-RESTYPES = {"mpx_last_error": c_char_p, "mpx_sa_pack_size": c_int64}
+RESTYPES = {"mpx_last_error": c_char_p, "mpx_sa_pack_size": c_int64, "mpx_sa_pack_bf16x3_size": c_int64}
 
 _lib: Optional[ctypes.CDLL] = None
 

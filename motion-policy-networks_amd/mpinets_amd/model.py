@@ -19,7 +19,7 @@ import torch
 from torch import nn
 
 from . import _lib
-from .pointnet2 import PointnetSAModule, SAWeights, groupnorm_leaky, linear, sa_mlp_fused
+from .pointnet2 import PRECISIONS, SA_KERNEL, PointnetSAModule, SAWeights, groupnorm_leaky, linear, sa_mlp_fused
 from .utils import unnormalize_franka_joints
 
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
@@ -103,9 +103,9 @@ class MPiNetsPointNet(nn.Module):
         lib.call("mpx_ball_query", lib.ptr(xyz1), 3, lib.ptr(pc), 4, B, N, sa1.npoint, float(sa1.radius),
                  sa1.nsample, lib.ptr(nbr1))
         c1 = sa1.convs()
-        w1 = sa1._packed.get(c1, 1)
+        w1 = sa1._packed.get(c1, 1, sa1.precision)
         f1 = torch.empty((B, sa1.npoint, c1[-1].out_channels), dtype=torch.float32, device=dev)
-        lib.call("mpx_sa_mlp", lib.ptr(pc), 4, lib.ptr(xyz1), 3, lib.ptr(pc) + 12, 4, 1, lib.ptr(nbr1), B, N,
+        lib.call(SA_KERNEL[sa1.precision], lib.ptr(pc), 4, lib.ptr(xyz1), 3, lib.ptr(pc) + 12, 4, 1, lib.ptr(nbr1), B, N,
                  sa1.npoint, sa1.nsample, lib.ptr(w1), c1[0].out_channels, c1[1].out_channels,
                  c1[2].out_channels, lib.ptr(f1), f1.stride(1))
         # ---- SA2 (writes into the group-all input rows [xyz2 | f2 | 0]) ----------------------------
@@ -118,8 +118,8 @@ class MPiNetsPointNet(nn.Module):
         nbr2 = torch.empty((B, sa2.npoint, sa2.nsample), dtype=torch.int32, device=dev)
         lib.call("mpx_ball_query", lib.ptr(sa3_in), K3, lib.ptr(xyz1), 3, B, sa1.npoint, sa2.npoint,
                  float(sa2.radius), sa2.nsample, lib.ptr(nbr2))
-        w2 = sa2._packed.get(c2, f1.size(2))
-        lib.call("mpx_sa_mlp", lib.ptr(xyz1), 3, lib.ptr(sa3_in), K3, lib.ptr(f1), f1.stride(1), f1.size(2),
+        w2 = sa2._packed.get(c2, f1.size(2), sa2.precision)
+        lib.call(SA_KERNEL[sa2.precision], lib.ptr(xyz1), 3, lib.ptr(sa3_in), K3, lib.ptr(f1), f1.stride(1), f1.size(2),
                  lib.ptr(nbr2), B, sa1.npoint, sa2.npoint, sa2.nsample, lib.ptr(w2), c2[0].out_channels,
                  c2[1].out_channels, C2o, lib.ptr(sa3_in) + 12, K3)
         # ---- SA3 (group-all): three GEMMs over B*128 rows + max over each environment's rows ------------
@@ -158,6 +158,16 @@ class MotionPolicyNetwork(nn.Module):
     @property
     def device(self):
         return next(self.parameters()).device
+
+    def set_precision(self, precision: str) -> "MotionPolicyNetwork":
+        """Arithmetic of the two grouped MLPs (96 % of the FLOPs): ``"fp32"`` = exact fp32 MFMA (default,
+        the parity path) or ``"bf16x3"`` = split-bf16 on the bf16 matrix cores (each product as
+        hi*hi + hi*lo + lo*hi, fp32 accumulate; policy output within ~3e-7 of fp32).  Everything else
+        (FPS, ball query, dense layers, FK, SDF) is fp32 in both modes."""
+        assert precision in PRECISIONS, precision
+        for sa in self.point_cloud_encoder.SA_modules:
+            sa.precision = precision
+        return self
 
     def configure_optimizers(self):
         return torch.optim.Adam(self.parameters(), lr=1e-4)

@@ -90,33 +90,48 @@ def groupnorm_leaky(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, g
     return out
 
 
+PRECISIONS = ("fp32", "bf16x3")
+SA_KERNEL = {"fp32": "mpx_sa_mlp", "bf16x3": "mpx_sa_mlp_bf16x3"}
+
+
 class SAWeights:
-    """Packed (MFMA-stream order) weights of one shared MLP, refreshed when parameters change."""
+    """Packed (MFMA-stream order) weights of one shared MLP, refreshed when parameters change.
+    One pack per precision mode: ``fp32`` (exact fp32 MFMA, the parity default) or ``bf16x3``
+    (split-bf16: hi/lo bf16 operand blocks for the bf16 matrix cores)."""
 
     def __init__(self):
-        self.pack = None
-        self.versions = None
+        self.packs = {}
 
-    def get(self, convs: List[nn.Conv2d], C: int) -> torch.Tensor:
+    def get(self, convs: List[nn.Conv2d], C: int, precision: str = "fp32") -> torch.Tensor:
+        assert precision in PRECISIONS, precision
         ver = tuple((c.weight._version, c.bias._version, c.weight.data_ptr()) for c in convs)
-        if self.pack is None or ver != self.versions:
+        hit = self.packs.get(precision)
+        if hit is None or hit[0] != ver:
             c1, c2, c3 = (c.out_channels for c in convs)
-            n = _lib.load().mpx_sa_pack_size(C, c1, c2, c3)
-            if n < 0:
-                raise _lib.MpxError(f"unsupported shared-MLP shape C={C} mlp=({c1},{c2},{c3})")
+            lib = _lib.load()
             dev = convs[0].weight.device
-            self.pack = torch.empty(n, dtype=torch.float32, device=dev)
             w = [_lib.f32c(c.weight.detach().reshape(c.out_channels, -1)) for c in convs]
             b = [_lib.f32c(c.bias.detach()) for c in convs]
-            _lib.call("mpx_sa_pack_weights", _lib.ptr(w[0]), _lib.ptr(b[0]), _lib.ptr(w[1]), _lib.ptr(b[1]),
-                      _lib.ptr(w[2]), _lib.ptr(b[2]), C, c1, c2, c3, _lib.ptr(self.pack))
-            self.versions = ver
-        return self.pack
+            if precision == "fp32":
+                n = lib.mpx_sa_pack_size(C, c1, c2, c3)
+                pack = torch.empty(max(n, 0), dtype=torch.float32, device=dev)
+                fn = "mpx_sa_pack_weights"
+            else:
+                n = lib.mpx_sa_pack_bf16x3_size(C, c1, c2, c3)
+                pack = torch.empty(max(n, 0), dtype=torch.uint8, device=dev)
+                fn = "mpx_sa_pack_bf16x3"
+            if n < 0:
+                raise _lib.MpxError(f"unsupported shared-MLP shape C={C} mlp=({c1},{c2},{c3})")
+            _lib.call(fn, _lib.ptr(w[0]), _lib.ptr(b[0]), _lib.ptr(w[1]), _lib.ptr(b[1]), _lib.ptr(w[2]),
+                      _lib.ptr(b[2]), C, c1, c2, c3, _lib.ptr(pack))
+            self.packs[precision] = (ver, pack)
+            hit = self.packs[precision]
+        return hit[1]
 
 
 def sa_mlp_fused(xyz: torch.Tensor, new_xyz: torch.Tensor, feat: torch.Tensor, feat_stride: int, C: int,
                  idx: torch.Tensor, wpack: torch.Tensor, widths: Tuple[int, int, int],
-                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                 out: Optional[torch.Tensor] = None, precision: str = "fp32") -> torch.Tensor:
     """Fused group + MLP + max-pool.  xyz [B,N,S]; new_xyz [B,npoint,S']; feat: tensor whose
     ``data_ptr`` is the first feature of point 0 with ``feat_stride`` floats between points;
     -> out [B,npoint,c3] point-major (``out`` may be a column slice of a wider buffer)."""
@@ -126,7 +141,7 @@ def sa_mlp_fused(xyz: torch.Tensor, new_xyz: torch.Tensor, feat: torch.Tensor, f
     if out is None:
         out = torch.empty((B, npoint, c3), dtype=torch.float32, device=xyz.device)
     assert out.stride(2) == 1 and out.stride(0) == npoint * out.stride(1)
-    _lib.call("mpx_sa_mlp", _lib.ptr(xyz), S, _lib.ptr(new_xyz), new_xyz.stride(1), _lib.ptr(feat), feat_stride, C,
+    _lib.call(SA_KERNEL[precision], _lib.ptr(xyz), S, _lib.ptr(new_xyz), new_xyz.stride(1), _lib.ptr(feat), feat_stride, C,
               _lib.ptr(idx), B, N, npoint, nsample, _lib.ptr(wpack), c1, c2, c3, _lib.ptr(out), out.stride(1))
     return out
 
@@ -139,8 +154,10 @@ class PointnetSAModule(nn.Module):
     """
 
     def __init__(self, *, mlp: List[int], npoint: Optional[int] = None, radius: Optional[float] = None,
-                 nsample: Optional[int] = None, bn: bool = False, use_xyz: bool = True):
+                 nsample: Optional[int] = None, bn: bool = False, use_xyz: bool = True, precision: str = "fp32"):
         super().__init__()
+        assert precision in PRECISIONS
+        self.precision = precision  # "fp32" (exact) | "bf16x3" (split-bf16 matrix cores, ~3e-7 on the policy output)
         if bn:
             raise NotImplementedError("bn=True is not used by the reference (model.py:366-383)")
         assert use_xyz, "the reference relies on use_xyz=True (3 extra input channels)"
@@ -170,8 +187,9 @@ class PointnetSAModule(nn.Module):
             feat_pm = _lib.f32c(features).transpose(1, 2).contiguous()  # [B,N,C] point-major
             idx, new_xyz = furthest_point_sample(xyz, self.npoint, return_xyz=True)
             nbr = ball_query(self.radius, self.nsample, xyz, new_xyz)
-            wpack = self._packed.get(convs, C)
-            out = sa_mlp_fused(xyz, new_xyz, feat_pm, C, C, nbr, wpack, tuple(c.out_channels for c in convs))
+            wpack = self._packed.get(convs, C, self.precision)
+            out = sa_mlp_fused(xyz, new_xyz, feat_pm, C, C, nbr, wpack, tuple(c.out_channels for c in convs),
+                               precision=self.precision)
             return new_xyz, out.transpose(1, 2).contiguous()
         # group-all: one "neighbourhood" holding every point, xyz NOT re-centred
         parts = [xyz]

@@ -195,3 +195,47 @@ def test_rollout_matches_oracle_and_mutates_slab(oracle):
                                                  smp.table_link.cpu().numpy(), subset.cpu().numpy())
     for a, b in zip(traj, otraj):
         np.testing.assert_allclose(a.cpu().numpy(), b, rtol=0, atol=5e-5)
+
+
+# ---- split-bf16 ("bf16x3") fast mode: same interfaces, products on the bf16 matrix cores ---------------------------
+@pytest.mark.parametrize("cfg", [dict(C=1, mlp=[1, 64, 64, 64], N=3000, npoint=70, radius=0.12),
+                                 dict(C=64, mlp=[64, 128, 128, 256], N=512, npoint=37, radius=0.3)])
+def test_sa_module_bf16x3_close_to_fp32_oracle(oracle, cfg):
+    from mpinets_amd.pointnet2 import PointnetSAModule
+
+    torch.manual_seed(7)
+    mod = PointnetSAModule(npoint=cfg["npoint"], radius=cfg["radius"], nsample=128, mlp=list(cfg["mlp"]), bn=False,
+                           precision="bf16x3").to(dev())
+    xyz, feat = _sa_inputs(2, cfg["N"], cfg["C"], cfg["npoint"], cfg["radius"], 3)
+    with torch.no_grad():
+        nx, nf = mod(T(xyz), T(feat))
+        mod.precision = "fp32"
+        _, nf32 = mod(T(xyz), T(feat))
+    layers = [(c.weight.detach().cpu().numpy(), c.bias.detach().cpu().numpy()) for c in mod.convs()]
+    onx, onf, _ = oracle.sa_module(xyz, feat, cfg["npoint"], cfg["radius"], 128, layers)
+    np.testing.assert_array_equal(nx.cpu().numpy(), onx)  # indices / centres never depend on the MLP precision
+    err = np.abs(nf.cpu().numpy() - onf).max()
+    print("bf16x3 SA features: max abs err %.3e (fp32 kernel: %.3e), |f| max %.2f" % (
+        err, np.abs(nf32.cpu().numpy() - onf).max(), np.abs(onf).max()))
+    np.testing.assert_allclose(nf.cpu().numpy(), onf, rtol=1e-4, atol=1e-4)
+
+
+def test_policy_forward_bf16x3_within_tolerance(oracle):
+    """The fast mode must still meet the north-star bar: bit-exact indices, policy deltas within 1e-5."""
+    from mpinets_amd.model import MotionPolicyNetwork
+    from mpinets_amd.scenes import make_problem_batch
+
+    torch.manual_seed(0)
+    mdl = MotionPolicyNetwork().to(dev()).eval().set_precision("bf16x3")
+    prob = make_problem_batch(3, seed=1, device=dev(), kinds=("tabletop", "cubby", "dresser"), M1=40)
+    aux = {}
+    with torch.no_grad():
+        dq = mdl(prob["xyz"], prob["q_norm"], aux=aux)
+        dq32 = mdl.set_precision("fp32")(prob["xyz"], prob["q_norm"])
+    odq, oaux = oracle.policy_forward(_state(mdl), prob["xyz"].cpu().numpy(), prob["q_norm"].cpu().numpy())
+    np.testing.assert_array_equal(aux["fps_idx2"].cpu().numpy(), oaux["sa2"]["fps_idx"])
+    np.testing.assert_array_equal(aux["ball_idx2"].cpu().numpy(), oaux["sa2"]["ball_idx"])
+    err = np.abs(dq.cpu().numpy() - odq).max()
+    print("bf16x3 policy delta max abs err vs fp32 oracle: %.3e (fp32 kernels: %.3e)" % (
+        err, np.abs(dq32.cpu().numpy() - odq).max()))
+    assert err <= TOL

@@ -59,8 +59,15 @@ def main():
     r["fps2"] = timeit(lambda: lib.call("mpx_fps", lib.ptr(xyz1), B, 512, 3, 128, lib.ptr(idx2), lib.ptr(xyz2), 3))
     r["ball2"] = timeit(lambda: lib.call("mpx_ball_query", lib.ptr(xyz2), 3, lib.ptr(xyz1), 3, B, 512, 128, 0.3, 128, lib.ptr(nbr2)))
     r["sa2_mlp"] = timeit(lambda: lib.call("mpx_sa_mlp", lib.ptr(xyz1), 3, lib.ptr(xyz2), 3, lib.ptr(f1), 64, 64, lib.ptr(nbr2), B, 512, 128, 128, lib.ptr(w2), 128, 128, 256, lib.ptr(f2), 256))
+    wb1 = sa1._packed.get(sa1.convs(), 1, "bf16x3")
+    wb2 = sa2._packed.get(sa2.convs(), 64, "bf16x3")
+    r["sa1_bf16x3"] = timeit(lambda: lib.call("mpx_sa_mlp_bf16x3", lib.ptr(xyz), 4, lib.ptr(xyz1), 3, lib.ptr(xyz) + 12, 4, 1, lib.ptr(nbr1), B, N, 512, 128, lib.ptr(wb1), 64, 64, 64, lib.ptr(f1), 64))
+    r["sa2_bf16x3"] = timeit(lambda: lib.call("mpx_sa_mlp_bf16x3", lib.ptr(xyz1), 3, lib.ptr(xyz2), 3, lib.ptr(f1), 64, 64, lib.ptr(nbr2), B, 512, 128, 128, lib.ptr(wb2), 128, 128, 256, lib.ptr(f2), 256))
     with torch.no_grad():
         r["forward"] = timeit(lambda: mdl(xyz, qn), n=3, warm=1)
+        mdl.set_precision("bf16x3")
+        r["forward_bf16x3"] = timeit(lambda: mdl(xyz, qn), n=3, warm=1)
+        mdl.set_precision("fp32")
     smp = FrankaSampler(dev)
     sub = smp.draw_subset(2048)
     r["fk_cloud"] = timeit(lambda: smp.sample_into(prob["q"], xyz, sub))
@@ -70,7 +77,8 @@ def main():
     traj = torch.from_numpy(linear_trajectories(B, 50, 0)).to(dev)
     r["collision_T50"] = timeit(lambda: cs.check(traj, cub, cyl))
     r["collision_T1"] = timeit(lambda: cs.check(prob["q"], cub, cyl))
-    flops = {"sa1_mlp": 1.107e9, "sa2_mlp": 1.892e9, "forward": 3.27e9}
+    flops = {"sa1_mlp": 1.107e9, "sa2_mlp": 1.892e9, "forward": 3.27e9, "sa1_bf16x3": 1.107e9, "sa2_bf16x3": 1.892e9,
+             "forward_bf16x3": 3.27e9}
     for k, v in r.items():
         extra = f"  {flops[k]*B/v/1e9:8.1f} TFLOP/s" if k in flops else ""
         print(f"{k:14s} {v:10.3f} ms  ({v/B*1e3:8.2f} us/env){extra}")
