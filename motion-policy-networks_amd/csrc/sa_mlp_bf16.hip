@@ -22,7 +22,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 #define PAD_CH (-1)
-constexpr int G = 4;                      // step-tiles per chunk
+constexpr int G = 8;                      // step-tiles per chunk
 constexpr int TILE_BYTES = 2048;          // w_hi (64 lanes x 16 B) + w_lo
 constexpr int CHUNK_BYTES = G * TILE_BYTES;
 constexpr int WAVES = 8;
@@ -43,7 +43,8 @@ struct BCfg {
   static constexpr int O2 = ST1P, O3 = ST1P + ST2P;                 // first step-tile of layers 2 and 3
   static constexpr int STP = ST1P + ST2P + ST3P;
   static constexpr int NCH = STP / G;
-  static_assert(KS2 % G == 0, "a chunk of layer 3 must stay inside one output tile");
+  static_assert(KS2 % G == 0 || G % KS2 == 0, "layer-3 chunks must align with output tiles");
+  static constexpr int OPC = G > KS2 ? G / KS2 : 1;                 // layer-3 output tiles touched by one chunk
   __host__ __device__ static constexpr int layer_of(int st) { return st < O2 ? 1 : (st < O3 ? 2 : 3); }
   __host__ __device__ static constexpr bool is_real(int st) {
     return st < O2 ? st < ST1 : (st < O3 ? st - O2 < ST2 : st - O3 < ST3);
@@ -167,29 +168,41 @@ __device__ __forceinline__ void relu_split_tile(const f32x16 &acc, bf16x8 (&hi)[
 
 // The lockstep weight stream of one workgroup.
 struct Stream {
-  const unsigned char *gsrc;   // this lane's slice of chunk 0 in global memory
+  __amdgpu_buffer_rsrc_t rsrc; // the packed weights as a buffer: chunk addresses are scalar offsets
+  int voff;                    // this thread's byte offset inside a chunk
   unsigned char *lds;          // ring base
   int lds_slice;               // this lane's byte offset inside a chunk
   int lds_lane;                // lane * 16
   int cur;                     // ring slot holding the chunk being consumed (0/1)
   int next_cc;                 // cyclic index of the chunk to fetch next
   int nch;
-  uint4 stage;                 // chunk (current + 1), in flight or landed
+  static_assert(CHUNK_BYTES == 2 * 64 * WAVES * 16, "two 16-byte pieces per thread per chunk");
+  uint4 stage0, stage1;        // chunk (current + 1), in flight or landed (named members: an array
+                               // member is not promoted to registers and lands in scratch)
 
   __device__ __forceinline__ void fetch() {
-    stage = *reinterpret_cast<const uint4 *>(gsrc + (size_t)next_cc * CHUNK_BYTES);
+    const int soff = next_cc * CHUNK_BYTES;
+    const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
+    const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff + 64 * WAVES * 16, 0);
+    stage0 = make_uint4(a.x, a.y, a.z, a.w);
+    stage1 = make_uint4(b.x, b.y, b.z, b.w);
     next_cc = next_cc + 1 == nch ? 0 : next_cc + 1;
+  }
+  __device__ __forceinline__ void put(int slot) {
+    unsigned char *p = lds + slot * CHUNK_BYTES + lds_slice;
+    *reinterpret_cast<uint4 *>(p) = stage0;
+    *reinterpret_cast<uint4 *>(p + 64 * WAVES * 16) = stage1;
   }
   __device__ __forceinline__ void start() {  // chunk 0 -> slot 0, chunk 1 -> stage
     fetch();
-    *reinterpret_cast<uint4 *>(lds + lds_slice) = stage;
+    put(0);
     fetch();
     cur = 0;
     __syncthreads();
   }
   // call after the last operand read of the current chunk
   __device__ __forceinline__ void advance() {
-    *reinterpret_cast<uint4 *>(lds + (cur ^ 1) * CHUNK_BYTES + lds_slice) = stage;
+    put(cur ^ 1);
     fetch();
     __syncthreads();
     cur ^= 1;
@@ -201,14 +214,53 @@ struct Stream {
   }
 };
 
+// raw (fp32) layer-1 inputs of one neighbour, as fetched from memory
+template <int CF>
+struct RawIn {
+  float px, py, pz;
+  float f[CF == 1 ? 1 : CF / 2];
+  __device__ __forceinline__ void load(const float *__restrict__ p, const float *__restrict__ fr, int half) {
+    px = p[0];
+    py = p[1];
+    pz = p[2];
+    if (CF == 1) {
+      f[0] = fr[0];
+    } else {
+      const float4 *q4 = reinterpret_cast<const float4 *>(fr + half * (CF / 2));
+#pragma unroll
+      for (int i = 0; i < CF / 8; ++i) {
+        const float4 q = q4[i];
+        f[4 * i + 0] = q.x;
+        f[4 * i + 1] = q.y;
+        f[4 * i + 2] = q.z;
+        f[4 * i + 3] = q.w;
+      }
+    }
+  }
+};
+
+__device__ __forceinline__ f32x16 bias_tile_lds(const float *bias_lds, int ot, int half) {
+  f32x16 v;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const float4 q = *reinterpret_cast<const float4 *>(bias_lds + ot * 32 + 8 * g + 4 * half);
+    v[4 * g + 0] = q.x;
+    v[4 * g + 1] = q.y;
+    v[4 * g + 2] = q.z;
+    v[4 * g + 3] = q.w;
+  }
+  return v;
+}
+
 template <int CF, int C1, int C2, int C3>
-__global__ void __launch_bounds__(512, 2)
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
     sa_mlp_bf16_kernel(const float *__restrict__ xyz, int stride, const float *__restrict__ new_xyz, int new_stride,
                        const float *__restrict__ feat, int feat_stride, const int32_t *__restrict__ idx,
                        int64_t n_query, int N, int npoint, int nsample, const unsigned char *__restrict__ wpack,
                        float *__restrict__ out, int out_stride) {
   using Cfg = BCfg<CF, C1, C2, C3>;
-  __shared__ __attribute__((aligned(16))) unsigned char ring[2 * CHUNK_BYTES];
+  __shared__ __attribute__((aligned(16))) unsigned char ring[2 * CHUNK_BYTES + 4 * (C1 + C2)];
+  float *bias_lds = reinterpret_cast<float *>(ring + 2 * CHUNK_BYTES);  // [b1 | b2]
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int half = lane >> 5, col = lane & 31;
@@ -217,17 +269,17 @@ __global__ void __launch_bounds__(512, 2)
   if (!live) qid = n_query - 1;
   const int64_t b = qid / npoint;
 
+  for (int i = threadIdx.x; i < C1 + C2; i += 64 * WAVES)
+    bias_lds[i] = reinterpret_cast<const float *>(wpack + Cfg::B1_OFF)[i];
   Stream ws;
-  ws.gsrc = wpack + threadIdx.x * 16;
+  ws.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(wpack), 0, (int)Cfg::TOTAL_BYTES, 0x00020000);
+  ws.voff = threadIdx.x * 16;
   ws.lds = ring;
   ws.lds_slice = threadIdx.x * 16;
   ws.lds_lane = lane * 16;
   ws.next_cc = 0;
   ws.nch = Cfg::NCH;
-  ws.start();
-
-  const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<unsigned char *>(wpack), 0, (int)Cfg::TOTAL_BYTES, 0x00020000);
+  ws.start();  // (its barrier also publishes the biases)
   const float *bias3 = reinterpret_cast<const float *>(wpack + Cfg::B3_OFF);
 
   const float *ctr = new_xyz + qid * new_stride;
@@ -240,34 +292,29 @@ __global__ void __launch_bounds__(512, 2)
 #pragma unroll
   for (int ot = 0; ot < Cfg::OT3; ++ot) omax[ot] = -__builtin_inff();
 
-  for (int rt = 0; rt < nsample; rt += 32) {
-    int b1o = (int)Cfg::B1_OFF, b2o = (int)Cfg::B2_OFF;
-    asm volatile("" : "+s"(b1o), "+s"(b2o));  // keep the (loop-invariant) bias loads inside the loop
-    const int k = nbr[rt + col];
-    const float *p = cloud + (int64_t)k * stride;
-    const float *f = fbase + (int64_t)k * feat_stride;
+  // gather pipeline: neighbour index two tiles ahead, neighbour data one tile ahead
+  RawIn<CF> raw;
+  int k_next = nsample > 32 ? nbr[32 + col] : 0;
+  {
+    const int k0 = nbr[col];
+    raw.load(cloud + (int64_t)k0 * stride, fbase + (int64_t)k0 * feat_stride, half);
+  }
 
-    // ---- layer-1 operands: this lane's half of its point's input vector, split hi/lo -------------------------
+  for (int rt = 0; rt < nsample; rt += 32) {
+    // ---- layer-1 operands from the prefetched neighbour, split hi/lo -------------------------------------------
     bf16x8 xh[Cfg::KS0], xl[Cfg::KS0];
     {
       float v[8 * Cfg::KS0];
 #pragma unroll
       for (int i = 0; i < 8 * Cfg::KS0; ++i) v[i] = 0.0f;
-      const float dx = p[0] - cx, dy = p[1] - cy, dz = p[2] - cz;
+      const float dx = raw.px - cx, dy = raw.py - cy, dz = raw.pz - cz;
       v[0] = half ? dy : dx;
       if (CF == 1) {
-        v[1] = half ? f[0] : dz;
+        v[1] = half ? raw.f[0] : dz;
       } else {
         v[1] = half ? 0.0f : dz;
-        const float4 *fr = reinterpret_cast<const float4 *>(f + half * (CF / 2));
 #pragma unroll
-        for (int i = 0; i < CF / 8; ++i) {
-          const float4 q = fr[i];
-          v[2 + 4 * i + 0] = q.x;
-          v[2 + 4 * i + 1] = q.y;
-          v[2 + 4 * i + 2] = q.z;
-          v[2 + 4 * i + 3] = q.w;
-        }
+        for (int i = 0; i < CF / 2; ++i) v[2 + i] = raw.f[i];
       }
 #pragma unroll
       for (int s = 0; s < Cfg::KS0; ++s) {
@@ -277,59 +324,78 @@ __global__ void __launch_bounds__(512, 2)
         split8(t8, xh[s], xl[s]);
       }
     }
+    // The next tile's gather is issued inside the chunk walk below, at the first chunk of layer 3
+    // (register pressure peaks in layer 2; layer 3 is long enough to cover the latency).
+    constexpr int GATHER_CHUNK = Cfg::O3 / G;
 
-    // The whole neighbourhood tile is one unrolled walk over the STP step-tiles of the weight stream,
-    // G at a time.  `st` is a compile-time constant in every use below.
+    // The neighbourhood tile is one unrolled walk over the STP step-tiles of the weight stream, G at a
+    // time; `st` is a compile-time constant in every use below.
     f32x16 a1[Cfg::OT1], a2[Cfg::OT2];
     bf16x8 h1[Cfg::OT1][2], l1[Cfg::OT1][2], h2[Cfg::OT2][2], l2[Cfg::OT2][2];
-    f32x16 a3[2];
+    f32x16 a3[Cfg::OPC][2];
 #pragma unroll
-    for (int ot = 0; ot < Cfg::OT1; ++ot) a1[ot] = bias_tile(brsrc, b1o, ot, half);
+    for (int ot = 0; ot < Cfg::OT1; ++ot) a1[ot] = bias_tile_lds(bias_lds, ot, half);
 
 #pragma unroll
     for (int c = 0; c < Cfg::NCH; ++c) {
-      bf16x8 wh[G], wl[G];
+      if (c == GATHER_CHUNK && rt + 32 < nsample) {
+        raw.load(cloud + (int64_t)k_next * stride, fbase + (int64_t)k_next * feat_stride, half);
+        if (rt + 64 < nsample) k_next = nbr[rt + 64 + col];
+      }
+      // ---- operands that become available / are first needed in this chunk ---------------------------------
+      if (c * G == Cfg::O2) {
 #pragma unroll
-      for (int j = 0; j < G; ++j)
-        if (Cfg::is_real(c * G + j)) ws.operands(j, wh[j], wl[j]);
-      // three passes (hi*hi, lo*hi, hi*lo) over the chunk's step-tiles: consecutive MFMAs hit
-      // different accumulators
+        for (int ot = 0; ot < Cfg::OT2; ++ot) a2[ot] = bias_tile_lds(bias_lds + C1, ot, half);
+      }
 #pragma unroll
-      for (int pass = 0; pass < 3; ++pass) {
+      for (int j = 0; j < G; ++j) {
+        const int st = c * G + j;
+        if (!Cfg::is_real(st)) continue;
+        if (st >= Cfg::O2 && st < Cfg::O3) {  // layer 2, first use of input tile s>>1 (ot == 0, even s)
+          const int q = st - Cfg::O2, s = q / Cfg::OT2, ot = q % Cfg::OT2;
+          if (ot == 0 && (s & 1) == 0) relu_split_tile(a1[s >> 1], h1[s >> 1], l1[s >> 1]);
+        } else if (st >= Cfg::O3) {            // layer 3, first output tile walks the input tiles in order
+          const int q = st - Cfg::O3, s = q % Cfg::KS2, ot = q / Cfg::KS2;
+          if (ot == 0 && (s & 1) == 0) relu_split_tile(a2[s >> 1], h2[s >> 1], l2[s >> 1]);
+          if (s == 0) {
+            a3[ot % Cfg::OPC][0] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            a3[ot % Cfg::OPC][1] = a3[ot % Cfg::OPC][0];
+          }
+        }
+      }
+      // operands are fetched SUB step-tiles at a time (register budget); within a sub-group three passes
+      // (hi*hi, lo*hi, hi*lo) so that consecutive MFMAs hit different accumulators
+      constexpr int SUB = 4;
 #pragma unroll
-        for (int j = 0; j < G; ++j) {
-          const int st = c * G + j;
-          if (!Cfg::is_real(st)) continue;
-          const bf16x8 w = pass == 1 ? wl[j] : wh[j];
-          if (st < Cfg::O2) {
-            const int s = st / Cfg::OT1, ot = st % Cfg::OT1;
-            a1[ot] = mfma_bf16(w, pass == 2 ? xl[s] : xh[s], a1[ot]);
-          } else if (st < Cfg::O3) {
-            const int q = st - Cfg::O2, s = q / Cfg::OT2, ot = q % Cfg::OT2;
-            a2[ot] = mfma_bf16(w, pass == 2 ? l1[s >> 1][s & 1] : h1[s >> 1][s & 1], a2[ot]);
-          } else {
-            const int q = st - Cfg::O3, s = q % Cfg::KS2;
-            // roles flipped: activations are the A operand, weights the B operand
-            a3[s & 1] = mfma_bf16(pass == 2 ? l2[s >> 1][s & 1] : h2[s >> 1][s & 1], w, a3[s & 1]);
+      for (int g0 = 0; g0 < G; g0 += SUB) {
+        bf16x8 wh[SUB], wl[SUB];
+#pragma unroll
+        for (int j = 0; j < SUB; ++j)
+          if (Cfg::is_real(c * G + g0 + j)) ws.operands(g0 + j, wh[j], wl[j]);
+#pragma unroll
+        for (int pass = 0; pass < 3; ++pass) {
+#pragma unroll
+          for (int j = 0; j < SUB; ++j) {
+            const int st = c * G + g0 + j;
+            if (!Cfg::is_real(st)) continue;
+            const bf16x8 w = pass == 1 ? wl[j] : wh[j];
+            if (st < Cfg::O2) {
+              const int s = st / Cfg::OT1, ot = st % Cfg::OT1;
+              a1[ot] = mfma_bf16(w, pass == 2 ? xl[s] : xh[s], a1[ot]);
+            } else if (st < Cfg::O3) {
+              const int q = st - Cfg::O2, s = q / Cfg::OT2, ot = q % Cfg::OT2;
+              a2[ot] = mfma_bf16(w, pass == 2 ? l1[s >> 1][s & 1] : h1[s >> 1][s & 1], a2[ot]);
+            } else {
+              const int q = st - Cfg::O3, s = q % Cfg::KS2, ot = q / Cfg::KS2;
+              // roles flipped: activations are the A operand, weights the B operand
+              a3[ot % Cfg::OPC][s & 1] =
+                  mfma_bf16(pass == 2 ? l2[s >> 1][s & 1] : h2[s >> 1][s & 1], w, a3[ot % Cfg::OPC][s & 1]);
+            }
           }
         }
       }
       ws.advance();
-      // ---- layer boundaries that fall on this chunk's end ------------------------------------------------
-      const int done_st = (c + 1) * G;  // (padded) step-tiles consumed so far
-      if (done_st == Cfg::O2) {
-#pragma unroll
-        for (int ot = 0; ot < Cfg::OT1; ++ot) relu_split_tile(a1[ot], h1[ot], l1[ot]);
-#pragma unroll
-        for (int ot = 0; ot < Cfg::OT2; ++ot) a2[ot] = bias_tile(brsrc, b2o, ot, half);
-      }
-      if (done_st == Cfg::O3) {
-#pragma unroll
-        for (int ot = 0; ot < Cfg::OT2; ++ot) relu_split_tile(a2[ot], h2[ot], l2[ot]);
-        a3[0] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        a3[1] = a3[0];
-      }
-      // end of an output tile of layer 3: pool its 32 points
+      // ---- end of an output tile of layer 3: pool its 32 points -------------------------------------------
 #pragma unroll
       for (int j = 0; j < G; ++j) {
         const int st = c * G + j;
@@ -337,12 +403,11 @@ __global__ void __launch_bounds__(512, 2)
         const int q = st - Cfg::O3;
         if (q % Cfg::KS2 == Cfg::KS2 - 1) {
           const int ot = q / Cfg::KS2;
-          float m = a3[0][0] + a3[1][0];
+          const f32x16 &u0 = a3[ot % Cfg::OPC][0], &u1 = a3[ot % Cfg::OPC][1];
+          float m = u0[0] + u1[0];
 #pragma unroll
-          for (int r = 1; r < 16; ++r) m = fmaxf(m, a3[0][r] + a3[1][r]);
+          for (int r = 1; r < 16; ++r) m = fmaxf(m, u0[r] + u1[r]);
           omax[ot] = fmaxf(omax[ot], m);
-          a3[0] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-          a3[1] = a3[0];
         }
       }
     }
