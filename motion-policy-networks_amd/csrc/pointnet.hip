@@ -21,6 +21,8 @@
 // is the 12 (or 16) bytes per point read once.
 #include "common.h"
 
+#include <stdlib.h>
+
 typedef unsigned long long u64;
 
 // ---- DPP helpers --------------------------------------------------------------------------------
@@ -31,7 +33,19 @@ __device__ __forceinline__ u64 dpp_mov64(u64 v) {
   hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)hi, CTRL, 0xf, 0xf, true);
   return ((u64)hi << 32) | lo;
 }
-__device__ __forceinline__ u64 umax64(u64 a, u64 b) { return a > b ? a : b; }
+// Keys are {float bits of d2 (non-negative, finite), 32-bit tie rank}: as IEEE doubles such patterns
+// are positive and finite (or subnormal -- f64 denormals are preserved in the kernel mode), and
+// positive doubles order like their bit patterns, so one v_max_f64 replaces the three-instruction
+// 64-bit integer compare-and-select.
+struct U32Pair {
+  unsigned lo, hi;
+};
+__device__ __forceinline__ u64 pack64(unsigned lo, unsigned hi) { return __builtin_bit_cast(u64, U32Pair{lo, hi}); }
+__device__ __forceinline__ u64 umax64(u64 a, u64 b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(__builtin_bit_cast(double, a)), "v"(__builtin_bit_cast(double, b)));
+  return __builtin_bit_cast(u64, r);
+}
 
 // max over each 16-lane row, result in every lane of the row
 __device__ __forceinline__ u64 row_max64(u64 v) {
@@ -54,9 +68,11 @@ __device__ __forceinline__ u64 wave_max64(u64 v) {
 }
 
 // ---- farthest point sampling --------------------------------------------------------------------
-// grid B, block = min(1024, roundup64(N)); dynamic LDS = 3*N floats + 2*16 u64 slots.
+// grid B, block = min(512, roundup64(N)) (MPX_FPS_BLOCK overrides, tuning only); dynamic LDS = 3*N floats + slots.
+// Two workgroups must share a CU (their serial pick chains interleave): 1024-thread blocks need
+// <= 64 VGPRs (8 waves/SIMD), 512-thread blocks with up to 16 points per lane <= 128.
 template <int PTS>
-__global__ void __launch_bounds__(1024)
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PTS <= 8 ? 8 : 4, PTS <= 8 ? 8 : 4)))
     fps_kernel(const float *__restrict__ xyz, int N, int stride, int npoint, int log2bs,
                int32_t *__restrict__ idx, float *__restrict__ new_xyz, int new_stride) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -119,11 +135,11 @@ __global__ void __launch_bounds__(1024)
     for (int i = 0; i < PTS; ++i) {
       const float dx = x[i] - x1, dy = y[i] - y1, dz = z[i] - z1;
       const float d = mpx_fma(dz, dz, mpx_fma(dy, dy, dx * dx));
-      const float d2 = fminf(d, dist[i]);
+      float d2;  // min(d, temp[k]) as one v_min_f32 (fminf() adds a canonicalising v_max per call)
+      asm("v_min_f32 %0, %1, %2" : "=v"(d2) : "v"(d), "v"(dist[i]));
       dist[i] = d2;
-      const u64 key = ((u64)__float_as_uint(d2) << 32) | keylo[i];
-      // keylo == 0 marks "not a candidate" (its dist stays +0, so the whole key is 0)
-      best = umax64(best, keylo[i] ? key : 0);
+      // a point that is not a candidate has keylo == 0 and dist == +0, so its whole key is 0
+      best = umax64(best, pack64(keylo[i], __float_as_uint(d2)));
     }
     best = wave_max64(best);
     u64 *slot = slots + (j & 1) * 16;
@@ -162,7 +178,8 @@ MPX_EXPORT int mpx_fps(const float *xyz, int B, int N, int stride, int npoint, i
   if (B == 0 || npoint == 0) return 0;
   const int log2bs = opt_n_threads_log2(N);
   int block = ((N + 63) / 64) * 64;
-  if (block > 1024) block = 1024;
+  static const int block_cap = getenv("MPX_FPS_BLOCK") ? atoi(getenv("MPX_FPS_BLOCK")) : 512;  // measured: 512 x 13 pts beats 1024 x 7
+  if (block > block_cap) block = block_cap;
   const int pts = (N + block - 1) / block;
   const size_t lds = 256 + (size_t)3 * N * sizeof(float);
   dim3 g(B), t(block);
@@ -184,7 +201,13 @@ MPX_EXPORT int mpx_fps(const float *xyz, int B, int N, int stride, int npoint, i
     case 5: FPS_LAUNCH(5); break;
     case 6: FPS_LAUNCH(6); break;
     case 7: FPS_LAUNCH(7); break;
-    default: FPS_LAUNCH(8); break;
+    case 8: FPS_LAUNCH(8); break;
+    case 9: case 10: FPS_LAUNCH(10); break;
+    case 11: case 12: case 13: FPS_LAUNCH(13); break;
+    case 14: case 15: case 16: FPS_LAUNCH(16); break;
+    default:
+      mpx_set_error("mpx_fps: %d points per thread unsupported (N=%d, block=%d)", pts, N, block);
+      return 1;
   }
 #undef FPS_LAUNCH
   MPX_LAUNCH_CHECK("mpx_fps");
