@@ -135,10 +135,17 @@ int mpx_fps(const float *xyz, int B, int N, int stride, int npoint, int32_t *idx
             int new_stride, mpx_stream_t stream);
 
 /* ball_query: first `nsample` indices (ascending) with d2 < radius^2, padded with the first
- * hit, zero when there is none.  idx int32 [B,npoint,nsample].                              */
+ * hit, zero when there is none.  idx int32 [B,npoint,nsample].  cnt (optional, int32
+ * [B,npoint]) receives the number of real hits (<= nsample): slots [cnt, nsample) are padding. */
 int mpx_ball_query(const float *new_xyz, int new_stride, const float *xyz, int stride, int B,
-                   int N, int npoint, float radius, int nsample, int32_t *idx,
+                   int N, int npoint, float radius, int nsample, int32_t *idx, int32_t *cnt,
                    mpx_stream_t stream);
+
+/* order[i] = query ids (0..n-1) sorted by DEcreasing number of 32-neighbour tiles
+ * ceil(cnt/32) (ties in unspecified order).  scratch: int32[32] device words (zeroed by the
+ * call).  Used to give the lockstep waves of mpx_sa_mlp_bf16x3 equal work.                  */
+int mpx_sort_queries(const int32_t *cnt, int64_t n, int nsample, int32_t *order, int32_t *scratch,
+                     mpx_stream_t stream);
 
 /* QueryAndGroup (use_xyz=True) materialised like the reference does:
  * out [B, 3+C, npoint, nsample]; feat point-major rows at feat + (b*N+k)*feat_stride.       */
@@ -151,11 +158,14 @@ int mpx_group_points(const float *xyz, int stride, const float *new_xyz, int new
  * Channel order of the MLP input is [dx,dy,dz, feat...] like the reference.
  * wpack: weights + biases packed by mpx_sa_pack_weights for this (C, c1, c2, c3).
  * out rows at out + (b*npoint + j)*out_stride, c3 floats each.
- * Supported: (C,c1,c2,c3) = (1,64,64,64) and (64,128,128,256); nsample % 32 == 0.          */
+ * Supported: (C,c1,c2,c3) = (1,64,64,64) and (64,128,128,256); nsample % 32 == 0.
+ * cnt (optional, from mpx_ball_query): neighbourhood tiles that hold only padding (repeats of
+ * the first neighbour) are skipped -- the MLP is per point and max-pooling is idempotent, so
+ * the output is bit-identical to walking all nsample slots (cnt == NULL).                   */
 int mpx_sa_mlp(const float *xyz, int stride, const float *new_xyz, int new_stride,
-               const float *feat, int feat_stride, int C, const int32_t *idx, int B, int N,
-               int npoint, int nsample, const float *wpack, int c1, int c2, int c3, float *out,
-               int out_stride, mpx_stream_t stream);
+               const float *feat, int feat_stride, int C, const int32_t *idx, const int32_t *cnt,
+               int B, int N, int npoint, int nsample, const float *wpack, int c1, int c2, int c3,
+               float *out, int out_stride, mpx_stream_t stream);
 /* number of floats mpx_sa_pack_weights writes for this configuration (host call)            */
 int64_t mpx_sa_pack_size(int C, int c1, int c2, int c3);
 /* w1 [c1,3+C], w2 [c2,c1], w3 [c3,c2] row-major (Conv2d 1x1 weights), b* biases -> wpack    */
@@ -167,11 +177,14 @@ int mpx_sa_pack_weights(const float *w1, const float *b1, const float *w2, const
  * x_hi*w_hi + x_hi*w_lo + x_lo*w_hi on the bf16 matrix cores with fp32 accumulation (5.3x fewer
  * MFMA cycles; |error| ~ 2^-16 relative per product, ~3e-7 on the policy output).  Same arguments
  * and outputs as mpx_sa_mlp; wpack comes from mpx_sa_pack_bf16x3 (size in BYTES from
- * mpx_sa_pack_bf16x3_size).  Opt-in: the fp32 kernel is the parity default.                  */
+ * mpx_sa_pack_bf16x3_size).  Opt-in: the fp32 kernel is the parity default.  `order` (optional,
+ * from mpx_sort_queries) assigns queries to workgroups by tile count (the 8 waves of a workgroup
+ * run max(tiles) of their queries).                                                         */
 int mpx_sa_mlp_bf16x3(const float *xyz, int stride, const float *new_xyz, int new_stride,
-                      const float *feat, int feat_stride, int C, const int32_t *idx, int B, int N,
-                      int npoint, int nsample, const void *wpack, int c1, int c2, int c3,
-                      float *out, int out_stride, mpx_stream_t stream);
+                      const float *feat, int feat_stride, int C, const int32_t *idx,
+                      const int32_t *cnt, const int32_t *order, int B, int N, int npoint,
+                      int nsample, const void *wpack, int c1, int c2, int c3, float *out,
+                      int out_stride, mpx_stream_t stream);
 int64_t mpx_sa_pack_bf16x3_size(int C, int c1, int c2, int c3);
 int mpx_sa_pack_bf16x3(const float *w1, const float *b1, const float *w2, const float *b2,
                        const float *w3, const float *b3, int C, int c1, int c2, int c3, void *wpack,

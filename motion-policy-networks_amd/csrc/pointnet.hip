@@ -225,7 +225,8 @@ MPX_EXPORT int mpx_fps(const float *xyz, int B, int N, int stride, int npoint, i
 template <int STRIDE, bool ALIGNED64>
 __global__ void __launch_bounds__(256)
     ball_query_kernel(const float *__restrict__ new_xyz, int new_stride, const float *__restrict__ xyz,
-                      int stride_rt, int N, int npoint, float radius2, int nsample, int32_t *__restrict__ idx) {
+                      int stride_rt, int N, int npoint, float radius2, int nsample, int32_t *__restrict__ idx,
+                      int32_t *__restrict__ cnt_out) {
   const int stride = STRIDE > 0 ? STRIDE : stride_rt;
   const int b = blockIdx.y;
   const int lane = threadIdx.x & 63;
@@ -283,6 +284,7 @@ __global__ void __launch_bounds__(256)
   }
   if (!__all(cnt >= nsample))
     for (; k < N; ++k) test_point(k, pts[(size_t)k * stride + 0], pts[(size_t)k * stride + 1], pts[(size_t)k * stride + 2]);
+  if (cnt_out && live) cnt_out[(size_t)b * npoint + j] = cnt < nsample ? cnt : nsample;
   // cooperative, coalesced padding: row q of this wave gets `first_q` in slots [cnt_q, nsample)
   const int jw = j - lane;  // first query of this wave
   for (int q = 0; q < 64; ++q) {
@@ -294,7 +296,8 @@ __global__ void __launch_bounds__(256)
 }
 
 MPX_EXPORT int mpx_ball_query(const float *new_xyz, int new_stride, const float *xyz, int stride, int B, int N,
-                              int npoint, float radius, int nsample, int32_t *idx, mpx_stream_t stream) {
+                              int npoint, float radius, int nsample, int32_t *idx, int32_t *cnt,
+                              mpx_stream_t stream) {
   MPX_REQUIRE(B >= 0 && N >= 0 && npoint >= 0 && nsample >= 0, "mpx_ball_query: negative size");
   MPX_REQUIRE(stride >= 3 && new_stride >= 3, "mpx_ball_query: stride < 3");
   MPX_REQUIRE(B <= 65535, "mpx_ball_query: B > 65535 (slab the batch)");
@@ -304,16 +307,16 @@ MPX_EXPORT int mpx_ball_query(const float *new_xyz, int new_stride, const float 
   const bool al64 = stride == 4 && ((uintptr_t)xyz & 63) == 0 && N % 4 == 0;
   if (al64)
     hipLaunchKernelGGL((ball_query_kernel<4, true>), g, t, 0, mpx_s(stream), new_xyz, new_stride, xyz, stride, N, npoint,
-                       r2, nsample, idx);
+                       r2, nsample, idx, cnt);
   else if (stride == 4)
     hipLaunchKernelGGL((ball_query_kernel<4, false>), g, t, 0, mpx_s(stream), new_xyz, new_stride, xyz, stride, N, npoint,
-                       r2, nsample, idx);
+                       r2, nsample, idx, cnt);
   else if (stride == 3)
     hipLaunchKernelGGL((ball_query_kernel<3, false>), g, t, 0, mpx_s(stream), new_xyz, new_stride, xyz, stride, N, npoint,
-                       r2, nsample, idx);
+                       r2, nsample, idx, cnt);
   else
     hipLaunchKernelGGL((ball_query_kernel<0, false>), g, t, 0, mpx_s(stream), new_xyz, new_stride, xyz, stride, N, npoint,
-                       r2, nsample, idx);
+                       r2, nsample, idx, cnt);
   MPX_LAUNCH_CHECK("mpx_ball_query");
 }
 
@@ -350,4 +353,45 @@ MPX_EXPORT int mpx_group_points(const float *xyz, int stride, const float *new_x
                      mpx_s(stream), xyz, stride, new_xyz, new_stride, feat, feat_stride, C, idx, N, npoint,
                      nsample, out);
   MPX_LAUNCH_CHECK("mpx_group_points");
+}
+
+// ---- queries sorted by neighbourhood tile count (counting sort, <= 8 bins) ---------------------------
+__global__ void __launch_bounds__(256)
+    tile_hist_kernel(const int32_t *__restrict__ cnt, int64_t n, int nsample, int32_t *__restrict__ hist) {
+  __shared__ int lh[8];
+  if (threadIdx.x < 8) lh[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) {
+    const int c = cnt[i];
+    const int t = c <= 0 ? 1 : ((c >= nsample ? nsample : c) + 31) / 32;
+    atomicAdd(&lh[t - 1], 1);
+  }
+  __syncthreads();
+  if (threadIdx.x < 8 && lh[threadIdx.x]) atomicAdd(hist + threadIdx.x, lh[threadIdx.x]);
+}
+
+__global__ void __launch_bounds__(256)
+    tile_scatter_kernel(const int32_t *__restrict__ cnt, int64_t n, int nsample, const int32_t *__restrict__ hist,
+                        int32_t *__restrict__ cursor, int32_t *__restrict__ order) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int c = cnt[i];
+  const int t = c <= 0 ? 1 : ((c >= nsample ? nsample : c) + 31) / 32;
+  int base = 0;  // bins in decreasing tile count
+  for (int b = 7; b > t - 1; --b) base += hist[b];
+  order[base + atomicAdd(cursor + (t - 1), 1)] = (int32_t)i;
+}
+
+MPX_EXPORT int mpx_sort_queries(const int32_t *cnt, int64_t n, int nsample, int32_t *order, int32_t *scratch,
+                                mpx_stream_t stream) {
+  MPX_REQUIRE(n >= 0 && n < ((int64_t)1 << 31), "mpx_sort_queries: bad n");
+  MPX_REQUIRE(nsample > 0 && nsample <= 256, "mpx_sort_queries: nsample must be in (0, 256]");
+  if (n == 0) return 0;
+  hipError_t e = hipMemsetAsync(scratch, 0, 32 * sizeof(int32_t), mpx_s(stream));
+  MPX_REQUIRE(e == hipSuccess, "mpx_sort_queries: memset failed: %s", hipGetErrorString(e));
+  hipLaunchKernelGGL(tile_hist_kernel, dim3(cdiv(n, 256)), dim3(256), 0, mpx_s(stream), cnt, n, nsample, scratch);
+  hipLaunchKernelGGL(tile_scatter_kernel, dim3(cdiv(n, 256)), dim3(256), 0, mpx_s(stream), cnt, n, nsample, scratch,
+                     scratch + 16, order);
+  MPX_LAUNCH_CHECK("mpx_sort_queries");
 }

@@ -151,8 +151,8 @@ template <int CF, int C1, int C2, int C3>
 __global__ void __launch_bounds__(256, 2)
     sa_mlp_kernel(const float *__restrict__ xyz, int stride, const float *__restrict__ new_xyz, int new_stride,
                   const float *__restrict__ feat, int feat_stride, const int32_t *__restrict__ idx,
-                  int64_t n_query, int N, int npoint, int nsample, const float *__restrict__ wpack,
-                  float *__restrict__ out, int out_stride) {
+                  const int32_t *__restrict__ cnt, int64_t n_query, int N, int npoint, int nsample,
+                  const float *__restrict__ wpack, float *__restrict__ out, int out_stride) {
   using Cfg = SaCfg<CF, C1, C2, C3>;
   const int lane = threadIdx.x & 63;
   const int half = lane >> 5, col = lane & 31;
@@ -175,7 +175,15 @@ __global__ void __launch_bounds__(256, 2)
 #pragma unroll
   for (int ot = 0; ot < Cfg::OT3; ++ot) omax[ot] = -__builtin_inff();
 
-  for (int rt = 0; rt < nsample; rt += 32) {
+  // Slots [cnt, nsample) of a neighbourhood repeat its first member (ball-query padding); the MLP is
+  // per point and max-pooling is idempotent, so tiles that hold nothing but repeats change nothing:
+  // walk only the tiles that contain distinct neighbours (bit-identical result, less work).
+  int n_rows = nsample;
+  if (cnt) {
+    const int c = __builtin_amdgcn_readfirstlane(cnt[qid]);
+    n_rows = c <= 0 ? 32 : (c >= nsample ? nsample : ((c + 31) & ~31));
+  }
+  for (int rt = 0; rt < n_rows; rt += 32) {
     // Loop-invariant buffer offsets are laundered through an empty asm each iteration: otherwise LICM
     // hoists the (invariant) bias and first-chunk weight loads out of the loop and they are spilled.
     int w1o = (int)Cfg::W1_OFF * 4, w2o = (int)Cfg::W2_OFF * 4, w3o = (int)Cfg::W3_OFF * 4;
@@ -275,12 +283,12 @@ __global__ void __launch_bounds__(256, 2)
 // ---- host entry points -----------------------------------------------------------------------------------
 template <int CF, int C1, int C2, int C3>
 static int launch_sa(const float *xyz, int stride, const float *new_xyz, int new_stride, const float *feat,
-                     int feat_stride, const int32_t *idx, int B, int N, int npoint, int nsample,
+                     int feat_stride, const int32_t *idx, const int32_t *cnt, int B, int N, int npoint, int nsample,
                      const float *wpack, float *out, int out_stride, mpx_stream_t stream) {
   const int64_t nq = (int64_t)B * npoint;
   MPX_REQUIRE(nq / 4 + 1 < ((int64_t)1 << 31), "mpx_sa_mlp: too many query points");
   hipLaunchKernelGGL((sa_mlp_kernel<CF, C1, C2, C3>), dim3((unsigned)((nq + 3) / 4)), dim3(256), 0,
-                     mpx_s(stream), xyz, stride, new_xyz, new_stride, feat, feat_stride, idx, nq, N, npoint,
+                     mpx_s(stream), xyz, stride, new_xyz, new_stride, feat, feat_stride, idx, cnt, nq, N, npoint,
                      nsample, wpack, out, out_stride);
   MPX_LAUNCH_CHECK("mpx_sa_mlp");
 }
@@ -294,8 +302,8 @@ static int launch_sa(const float *xyz, int stride, const float *new_xyz, int new
   }
 
 MPX_EXPORT int mpx_sa_mlp(const float *xyz, int stride, const float *new_xyz, int new_stride,
-                          const float *feat, int feat_stride, int C, const int32_t *idx, int B, int N,
-                          int npoint, int nsample, const float *wpack, int c1, int c2, int c3, float *out,
+                          const float *feat, int feat_stride, int C, const int32_t *idx, const int32_t *cnt, int B,
+                          int N, int npoint, int nsample, const float *wpack, int c1, int c2, int c3, float *out,
                           int out_stride, mpx_stream_t stream) {
   MPX_REQUIRE(B >= 0 && N >= 1 && npoint >= 0, "mpx_sa_mlp: bad size");
   MPX_REQUIRE(nsample > 0 && nsample % 32 == 0, "mpx_sa_mlp: nsample must be a positive multiple of 32");
@@ -305,7 +313,7 @@ MPX_EXPORT int mpx_sa_mlp(const float *xyz, int stride, const float *new_xyz, in
   MPX_REQUIRE(((uintptr_t)wpack & 15) == 0, "mpx_sa_mlp: wpack must be 16-byte aligned");
   if (B == 0 || npoint == 0) return 0;
 #define CALL(a, b, c, d) \
-  return launch_sa<a, b, c, d>(xyz, stride, new_xyz, new_stride, feat, feat_stride, idx, B, N, npoint, nsample, wpack, out, out_stride, stream)
+  return launch_sa<a, b, c, d>(xyz, stride, new_xyz, new_stride, feat, feat_stride, idx, cnt, B, N, npoint, nsample, wpack, out, out_stride, stream)
   SA_DISPATCH(CALL)
 #undef CALL
 }

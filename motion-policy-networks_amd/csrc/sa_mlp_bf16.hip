@@ -256,10 +256,11 @@ template <int CF, int C1, int C2, int C3>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
     sa_mlp_bf16_kernel(const float *__restrict__ xyz, int stride, const float *__restrict__ new_xyz, int new_stride,
                        const float *__restrict__ feat, int feat_stride, const int32_t *__restrict__ idx,
-                       int64_t n_query, int N, int npoint, int nsample, const unsigned char *__restrict__ wpack,
-                       float *__restrict__ out, int out_stride) {
+                       const int32_t *__restrict__ cnt, const int32_t *__restrict__ order, int64_t n_query, int N,
+                       int npoint, int nsample, const unsigned char *__restrict__ wpack, float *__restrict__ out,
+                       int out_stride) {
   using Cfg = BCfg<CF, C1, C2, C3>;
-  __shared__ __attribute__((aligned(16))) unsigned char ring[2 * CHUNK_BYTES + 4 * (C1 + C2)];
+  __shared__ __attribute__((aligned(16))) unsigned char ring[2 * CHUNK_BYTES + 4 * (C1 + C2) + 64];
   float *bias_lds = reinterpret_cast<float *>(ring + 2 * CHUNK_BYTES);  // [b1 | b2]
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -267,8 +268,23 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
   int64_t qid = (int64_t)blockIdx.x * WAVES + wave;
   const bool live = qid < n_query;  // wave-uniform; dead waves still walk the stream (barriers)
   if (!live) qid = n_query - 1;
+  // `order` (optional) lists the queries sorted by their number of neighbourhood tiles, so that the 8
+  // lockstep waves of a workgroup have (nearly) the same amount of work
+  if (order) qid = __builtin_amdgcn_readfirstlane(order[qid]);
   const int64_t b = qid / npoint;
 
+  // Tiles that hold nothing but ball-query padding (repeats of the first neighbour) are skipped: the
+  // MLP is per point and max-pooling is idempotent, so the result is bit-identical.  The workgroup
+  // walks the weight stream in lockstep, so it runs max(tiles) over its waves.
+  int *tiles_lds = reinterpret_cast<int *>(ring + 2 * CHUNK_BYTES + 4 * (C1 + C2));
+  {
+    int rows = nsample;
+    if (cnt) {
+      const int c = __builtin_amdgcn_readfirstlane(cnt[qid]);
+      rows = c <= 0 ? 32 : (c >= nsample ? nsample : ((c + 31) & ~31));
+    }
+    if (lane == 0) tiles_lds[wave] = rows;
+  }
   for (int i = threadIdx.x; i < C1 + C2; i += 64 * WAVES)
     bias_lds[i] = reinterpret_cast<const float *>(wpack + Cfg::B1_OFF)[i];
   Stream ws;
@@ -279,7 +295,10 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
   ws.lds_lane = lane * 16;
   ws.next_cc = 0;
   ws.nch = Cfg::NCH;
-  ws.start();  // (its barrier also publishes the biases)
+  ws.start();  // (its barrier also publishes the biases and the per-wave tile counts)
+  int n_rows = 0;
+#pragma unroll
+  for (int w = 0; w < WAVES; ++w) n_rows = max(n_rows, tiles_lds[w]);
   const float *bias3 = reinterpret_cast<const float *>(wpack + Cfg::B3_OFF);
 
   const float *ctr = new_xyz + qid * new_stride;
@@ -294,13 +313,13 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 
   // gather pipeline: neighbour index two tiles ahead, neighbour data one tile ahead
   RawIn<CF> raw;
-  int k_next = nsample > 32 ? nbr[32 + col] : 0;
+  int k_next = n_rows > 32 ? nbr[32 + col] : 0;
   {
     const int k0 = nbr[col];
     raw.load(cloud + (int64_t)k0 * stride, fbase + (int64_t)k0 * feat_stride, half);
   }
 
-  for (int rt = 0; rt < nsample; rt += 32) {
+  for (int rt = 0; rt < n_rows; rt += 32) {
     // ---- layer-1 operands from the prefetched neighbour, split hi/lo -------------------------------------------
     bf16x8 xh[Cfg::KS0], xl[Cfg::KS0];
     {
@@ -338,9 +357,9 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 
 #pragma unroll
     for (int c = 0; c < Cfg::NCH; ++c) {
-      if (c == GATHER_CHUNK && rt + 32 < nsample) {
+      if (c == GATHER_CHUNK && rt + 32 < n_rows) {
         raw.load(cloud + (int64_t)k_next * stride, fbase + (int64_t)k_next * feat_stride, half);
-        if (rt + 64 < nsample) k_next = nbr[rt + 64 + col];
+        if (rt + 64 < n_rows) k_next = nbr[rt + 64 + col];
       }
       // ---- operands that become available / are first needed in this chunk ---------------------------------
       if (c * G == Cfg::O2) {
@@ -437,20 +456,21 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 
 template <int CF, int C1, int C2, int C3>
 static int launch_sa_bf16(const float *xyz, int stride, const float *new_xyz, int new_stride, const float *feat,
-                          int feat_stride, const int32_t *idx, int B, int N, int npoint, int nsample,
+                          int feat_stride, const int32_t *idx, const int32_t *cnt, const int32_t *order, int B, int N,
+                          int npoint, int nsample,
                           const void *wpack, float *out, int out_stride, mpx_stream_t stream) {
   const int64_t nq = (int64_t)B * npoint;
   MPX_REQUIRE(nq / WAVES + 1 < ((int64_t)1 << 31), "mpx_sa_mlp_bf16x3: too many query points");
   hipLaunchKernelGGL((sa_mlp_bf16_kernel<CF, C1, C2, C3>), dim3((unsigned)((nq + WAVES - 1) / WAVES)), dim3(64 * WAVES),
-                     0, mpx_s(stream), xyz, stride, new_xyz, new_stride, feat, feat_stride, idx, nq, N, npoint, nsample,
+                     0, mpx_s(stream), xyz, stride, new_xyz, new_stride, feat, feat_stride, idx, cnt, order, nq, N, npoint, nsample,
                      static_cast<const unsigned char *>(wpack), out, out_stride);
   MPX_LAUNCH_CHECK("mpx_sa_mlp_bf16x3");
 }
 
 MPX_EXPORT int mpx_sa_mlp_bf16x3(const float *xyz, int stride, const float *new_xyz, int new_stride,
-                                 const float *feat, int feat_stride, int C, const int32_t *idx, int B, int N,
-                                 int npoint, int nsample, const void *wpack, int c1, int c2, int c3, float *out,
-                                 int out_stride, mpx_stream_t stream) {
+                                 const float *feat, int feat_stride, int C, const int32_t *idx, const int32_t *cnt,
+                                 const int32_t *order, int B, int N, int npoint, int nsample, const void *wpack, int c1,
+                                 int c2, int c3, float *out, int out_stride, mpx_stream_t stream) {
   MPX_REQUIRE(B >= 0 && N >= 1 && npoint >= 0, "mpx_sa_mlp_bf16x3: bad size");
   MPX_REQUIRE(nsample > 0 && nsample % 32 == 0, "mpx_sa_mlp_bf16x3: nsample must be a positive multiple of 32");
   MPX_REQUIRE(stride >= 3 && new_stride >= 3 && out_stride >= c3, "mpx_sa_mlp_bf16x3: bad stride");
@@ -459,7 +479,7 @@ MPX_EXPORT int mpx_sa_mlp_bf16x3(const float *xyz, int stride, const float *new_
   MPX_REQUIRE(((uintptr_t)wpack & 15) == 0, "mpx_sa_mlp_bf16x3: wpack must be 16-byte aligned");
   if (B == 0 || npoint == 0) return 0;
 #define CALL(a, b, c, d) \
-  return launch_sa_bf16<a, b, c, d>(xyz, stride, new_xyz, new_stride, feat, feat_stride, idx, B, N, npoint, nsample, wpack, out, out_stride, stream)
+  return launch_sa_bf16<a, b, c, d>(xyz, stride, new_xyz, new_stride, feat, feat_stride, idx, cnt, order, B, N, npoint, nsample, wpack, out, out_stride, stream)
   SA_DISPATCH(CALL)
 #undef CALL
 }

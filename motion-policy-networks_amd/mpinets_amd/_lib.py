@@ -35,12 +35,13 @@ PROTOTYPES = {
     "mpx_franka_success": [P, P, I, F, F, F, P, P, P, P, P],
     "mpx_scene_cloud": [P, P, P, I, P, P, P, P, I, I, I, ctypes.c_uint64, P, P, P, P, L, I, I, P],
     "mpx_fps": [P, I, I, I, I, P, P, I, P],
-    "mpx_ball_query": [P, I, P, I, I, I, I, F, I, P, P],
+    "mpx_ball_query": [P, I, P, I, I, I, I, F, I, P, P, P],
+    "mpx_sort_queries": [P, L, I, P, P, P],
     "mpx_group_points": [P, I, P, I, P, I, I, P, I, I, I, I, P, P],
-    "mpx_sa_mlp": [P, I, P, I, P, I, I, P, I, I, I, I, P, I, I, I, P, I, P],
+    "mpx_sa_mlp": [P, I, P, I, P, I, I, P, P, I, I, I, I, P, I, I, I, P, I, P],
     "mpx_sa_pack_size": [I, I, I, I],
     "mpx_sa_pack_weights": [P, P, P, P, P, P, I, I, I, I, P, P],
-    "mpx_sa_mlp_bf16x3": [P, I, P, I, P, I, I, P, I, I, I, I, P, I, I, I, P, I, P],
+    "mpx_sa_mlp_bf16x3": [P, I, P, I, P, I, I, P, P, P, I, I, I, I, P, I, I, I, P, I, P],
     "mpx_sa_pack_bf16x3_size": [I, I, I, I],
     "mpx_sa_pack_bf16x3": [P, P, P, P, P, P, I, I, I, I, P, P],
     "mpx_linear": [P, I, P, P, I, I, I, I, P, I, P],

@@ -19,7 +19,7 @@ import torch
 from torch import nn
 
 from . import _lib
-from .pointnet2 import PRECISIONS, SA_KERNEL, PointnetSAModule, SAWeights, groupnorm_leaky, linear, sa_mlp_fused
+from .pointnet2 import PRECISIONS, PointnetSAModule, SAWeights, groupnorm_leaky, launch_sa, linear, sa_mlp_fused
 from .utils import unnormalize_franka_joints
 
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
@@ -100,14 +100,15 @@ class MPiNetsPointNet(nn.Module):
         xyz1 = torch.empty((B, sa1.npoint, 3), dtype=torch.float32, device=dev)
         lib.call("mpx_fps", lib.ptr(pc), B, N, 4, sa1.npoint, lib.ptr(idx1), lib.ptr(xyz1), 3)
         nbr1 = torch.empty((B, sa1.npoint, sa1.nsample), dtype=torch.int32, device=dev)
+        cnt1 = torch.empty((B, sa1.npoint), dtype=torch.int32, device=dev)
         lib.call("mpx_ball_query", lib.ptr(xyz1), 3, lib.ptr(pc), 4, B, N, sa1.npoint, float(sa1.radius),
-                 sa1.nsample, lib.ptr(nbr1))
+                 sa1.nsample, lib.ptr(nbr1), lib.ptr(cnt1))
         c1 = sa1.convs()
         w1 = sa1._packed.get(c1, 1, sa1.precision)
         f1 = torch.empty((B, sa1.npoint, c1[-1].out_channels), dtype=torch.float32, device=dev)
-        lib.call(SA_KERNEL[sa1.precision], lib.ptr(pc), 4, lib.ptr(xyz1), 3, lib.ptr(pc) + 12, 4, 1, lib.ptr(nbr1), B, N,
-                 sa1.npoint, sa1.nsample, lib.ptr(w1), c1[0].out_channels, c1[1].out_channels,
-                 c1[2].out_channels, lib.ptr(f1), f1.stride(1))
+        launch_sa(sa1.precision, lib.ptr(pc), 4, lib.ptr(xyz1), 3, lib.ptr(pc) + 12, 4, 1, nbr1,
+                  cnt1 if sa1.elide_padding else None, B, N, sa1.npoint, sa1.nsample, w1,
+                  tuple(c.out_channels for c in c1), lib.ptr(f1), f1.stride(1))
         # ---- SA2 (writes into the group-all input rows [xyz2 | f2 | 0]) ----------------------------
         c2 = sa2.convs()
         C2o = c2[-1].out_channels
@@ -116,12 +117,13 @@ class MPiNetsPointNet(nn.Module):
         idx2 = torch.empty((B, sa2.npoint), dtype=torch.int32, device=dev)
         lib.call("mpx_fps", lib.ptr(xyz1), B, sa1.npoint, 3, sa2.npoint, lib.ptr(idx2), lib.ptr(sa3_in), K3)
         nbr2 = torch.empty((B, sa2.npoint, sa2.nsample), dtype=torch.int32, device=dev)
+        cnt2 = torch.empty((B, sa2.npoint), dtype=torch.int32, device=dev)
         lib.call("mpx_ball_query", lib.ptr(sa3_in), K3, lib.ptr(xyz1), 3, B, sa1.npoint, sa2.npoint,
-                 float(sa2.radius), sa2.nsample, lib.ptr(nbr2))
+                 float(sa2.radius), sa2.nsample, lib.ptr(nbr2), lib.ptr(cnt2))
         w2 = sa2._packed.get(c2, f1.size(2), sa2.precision)
-        lib.call(SA_KERNEL[sa2.precision], lib.ptr(xyz1), 3, lib.ptr(sa3_in), K3, lib.ptr(f1), f1.stride(1), f1.size(2),
-                 lib.ptr(nbr2), B, sa1.npoint, sa2.npoint, sa2.nsample, lib.ptr(w2), c2[0].out_channels,
-                 c2[1].out_channels, C2o, lib.ptr(sa3_in) + 12, K3)
+        launch_sa(sa2.precision, lib.ptr(xyz1), 3, lib.ptr(sa3_in), K3, lib.ptr(f1), f1.stride(1), f1.size(2), nbr2,
+                  cnt2 if sa2.elide_padding else None, B, sa1.npoint, sa2.npoint, sa2.nsample, w2,
+                  tuple(c.out_channels for c in c2), lib.ptr(sa3_in) + 12, K3)
         # ---- SA3 (group-all): three GEMMs over B*128 rows + max over each environment's rows ------------
         c3 = sa3.convs()
         h = sa3_in.view(B * sa2.npoint, K3)
@@ -134,8 +136,8 @@ class MPiNetsPointNet(nn.Module):
             lib.call("mpx_rowmax", lib.ptr(h[b0 * sa2.npoint:]), h.stride(0), nb, sa2.npoint, h.size(1),
                      lib.ptr(pooled[b0:]), pooled.stride(0))
         if aux is not None:
-            aux.update(fps_idx1=idx1, xyz1=xyz1, ball_idx1=nbr1, f1=f1, fps_idx2=idx2, ball_idx2=nbr2,
-                       sa3_in=sa3_in, f3=pooled)
+            aux.update(fps_idx1=idx1, xyz1=xyz1, ball_idx1=nbr1, ball_cnt1=cnt1, f1=f1, fps_idx2=idx2, ball_idx2=nbr2,
+                       ball_cnt2=cnt2, sa3_in=sa3_in, f3=pooled)
         return self._fc(pooled, out=out)
 
 
@@ -167,6 +169,12 @@ class MotionPolicyNetwork(nn.Module):
         assert precision in PRECISIONS, precision
         for sa in self.point_cloud_encoder.SA_modules:
             sa.precision = precision
+        return self
+
+    def set_elide_padding(self, on: bool) -> "MotionPolicyNetwork":
+        """Skip neighbourhood tiles made only of ball-query padding (default on; output bit-identical)."""
+        for sa in self.point_cloud_encoder.SA_modules:
+            sa.elide_padding = bool(on)
         return self
 
     def configure_optimizers(self):

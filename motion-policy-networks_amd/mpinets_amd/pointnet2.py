@@ -38,16 +38,18 @@ def gather_operation(features: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     return torch.gather(features, 2, idx.long().unsqueeze(1).expand(-1, features.size(1), -1))
 
 
-def ball_query(radius: float, nsample: int, xyz: torch.Tensor, new_xyz: torch.Tensor) -> torch.Tensor:
-    """-> idx int32 [B,npoint,nsample] (argument order of pointnet2_utils.ball_query)."""
+def ball_query(radius: float, nsample: int, xyz: torch.Tensor, new_xyz: torch.Tensor, return_counts: bool = False):
+    """-> idx int32 [B,npoint,nsample] (argument order of pointnet2_utils.ball_query); with
+    ``return_counts`` also the number of real hits per query (slots beyond it are padding)."""
     _lib.require_cuda(xyz, new_xyz)
     assert xyz.is_contiguous() and new_xyz.is_contiguous()
     B, N, S = xyz.shape
     npoint = new_xyz.size(1)
     idx = torch.empty((B, npoint, nsample), dtype=torch.int32, device=xyz.device)
+    cnt = torch.empty((B, npoint), dtype=torch.int32, device=xyz.device) if return_counts else None
     _lib.call("mpx_ball_query", _lib.ptr(new_xyz), new_xyz.size(2), _lib.ptr(xyz), S, B, N, npoint,
-              float(radius), nsample, _lib.ptr(idx))
-    return idx
+              float(radius), nsample, _lib.ptr(idx), _lib.ptr(cnt))
+    return (idx, cnt) if return_counts else idx
 
 
 def query_and_group(xyz: torch.Tensor, new_xyz: torch.Tensor, features_pm: Optional[torch.Tensor],
@@ -129,9 +131,30 @@ class SAWeights:
         return hit[1]
 
 
+def launch_sa(precision: str, xyz_ptr: int, stride: int, new_xyz_ptr: int, new_stride: int, feat_ptr: int,
+              feat_stride: int, C: int, idx: torch.Tensor, cnt: Optional[torch.Tensor], B: int, N: int, npoint: int,
+              nsample: int, wpack: torch.Tensor, widths: Tuple[int, int, int], out_ptr: int, out_stride: int) -> None:
+    """One fused group + MLP + max-pool launch in either precision (raw pointers: slab views welcome).
+    ``cnt`` (from the ball query) lets the kernel skip neighbourhood tiles that hold only padding --
+    bit-identical output; for the lockstep bf16x3 kernel the queries are first ordered by tile count."""
+    c1, c2, c3 = widths
+    if precision == "fp32":
+        _lib.call("mpx_sa_mlp", xyz_ptr, stride, new_xyz_ptr, new_stride, feat_ptr, feat_stride, C, _lib.ptr(idx),
+                  _lib.ptr(cnt), B, N, npoint, nsample, _lib.ptr(wpack), c1, c2, c3, out_ptr, out_stride)
+        return
+    order = None
+    if cnt is not None:
+        order = torch.empty(B * npoint, dtype=torch.int32, device=idx.device)
+        scratch = torch.empty(32, dtype=torch.int32, device=idx.device)
+        _lib.call("mpx_sort_queries", _lib.ptr(cnt), B * npoint, nsample, _lib.ptr(order), _lib.ptr(scratch))
+    _lib.call("mpx_sa_mlp_bf16x3", xyz_ptr, stride, new_xyz_ptr, new_stride, feat_ptr, feat_stride, C, _lib.ptr(idx),
+              _lib.ptr(cnt), _lib.ptr(order), B, N, npoint, nsample, _lib.ptr(wpack), c1, c2, c3, out_ptr, out_stride)
+
+
 def sa_mlp_fused(xyz: torch.Tensor, new_xyz: torch.Tensor, feat: torch.Tensor, feat_stride: int, C: int,
                  idx: torch.Tensor, wpack: torch.Tensor, widths: Tuple[int, int, int],
-                 out: Optional[torch.Tensor] = None, precision: str = "fp32") -> torch.Tensor:
+                 out: Optional[torch.Tensor] = None, precision: str = "fp32",
+                 cnt: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Fused group + MLP + max-pool.  xyz [B,N,S]; new_xyz [B,npoint,S']; feat: tensor whose
     ``data_ptr`` is the first feature of point 0 with ``feat_stride`` floats between points;
     -> out [B,npoint,c3] point-major (``out`` may be a column slice of a wider buffer)."""
@@ -141,8 +164,8 @@ def sa_mlp_fused(xyz: torch.Tensor, new_xyz: torch.Tensor, feat: torch.Tensor, f
     if out is None:
         out = torch.empty((B, npoint, c3), dtype=torch.float32, device=xyz.device)
     assert out.stride(2) == 1 and out.stride(0) == npoint * out.stride(1)
-    _lib.call(SA_KERNEL[precision], _lib.ptr(xyz), S, _lib.ptr(new_xyz), new_xyz.stride(1), _lib.ptr(feat), feat_stride, C,
-              _lib.ptr(idx), B, N, npoint, nsample, _lib.ptr(wpack), c1, c2, c3, _lib.ptr(out), out.stride(1))
+    launch_sa(precision, _lib.ptr(xyz), S, _lib.ptr(new_xyz), new_xyz.stride(1), _lib.ptr(feat), feat_stride, C, idx, cnt,
+              B, N, npoint, nsample, wpack, widths, _lib.ptr(out), out.stride(1))
     return out
 
 
@@ -158,6 +181,8 @@ class PointnetSAModule(nn.Module):
         super().__init__()
         assert precision in PRECISIONS
         self.precision = precision  # "fp32" (exact) | "bf16x3" (split-bf16 matrix cores, ~3e-7 on the policy output)
+        # skip neighbourhood tiles that hold only ball-query padding (bit-identical output, see launch_sa)
+        self.elide_padding = True
         if bn:
             raise NotImplementedError("bn=True is not used by the reference (model.py:366-383)")
         assert use_xyz, "the reference relies on use_xyz=True (3 extra input channels)"
@@ -186,10 +211,10 @@ class PointnetSAModule(nn.Module):
             C = features.size(1)
             feat_pm = _lib.f32c(features).transpose(1, 2).contiguous()  # [B,N,C] point-major
             idx, new_xyz = furthest_point_sample(xyz, self.npoint, return_xyz=True)
-            nbr = ball_query(self.radius, self.nsample, xyz, new_xyz)
+            nbr, cnt = ball_query(self.radius, self.nsample, xyz, new_xyz, return_counts=True)
             wpack = self._packed.get(convs, C, self.precision)
             out = sa_mlp_fused(xyz, new_xyz, feat_pm, C, C, nbr, wpack, tuple(c.out_channels for c in convs),
-                               precision=self.precision)
+                               precision=self.precision, cnt=cnt if self.elide_padding else None)
             return new_xyz, out.transpose(1, 2).contiguous()
         # group-all: one "neighbourhood" holding every point, xyz NOT re-centred
         parts = [xyz]

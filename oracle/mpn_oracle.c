@@ -401,7 +401,7 @@ ORC_API void orc_gather_points(const float *xyz, int B, int N, int stride, const
 /* query_ball_point_kernel: first `nsample` indices k (ascending) with d2 < r*r; all slots
  * pre-filled with the first hit; output zero-initialised.                                */
 ORC_API void orc_ball_query(const float *new_xyz, const float *xyz, int B, int N, int stride,
-                            int npoint, float radius, int nsample, int32_t *idx) {
+                            int npoint, float radius, int nsample, int32_t *idx, int32_t *cnt_out) {
   float r2 = radius * radius;
   memset(idx, 0, sizeof(int32_t) * (size_t)B * npoint * nsample);
   for (int b = 0; b < B; ++b)
@@ -420,6 +420,7 @@ ORC_API void orc_ball_query(const float *new_xyz, const float *xyz, int B, int N
           ++cnt;
         }
       }
+      if (cnt_out) cnt_out[(size_t)b * npoint + j] = cnt; /* hits found (<= nsample) */
     }
 }
 

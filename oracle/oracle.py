@@ -218,13 +218,14 @@ def gather_points(xyz, idx) -> np.ndarray:
     return out
 
 
-def ball_query(new_xyz, xyz, radius: float, nsample: int) -> np.ndarray:
+def ball_query(new_xyz, xyz, radius: float, nsample: int, return_counts: bool = False):
     nx, x = _f(new_xyz), _f(xyz)
     B, N, C = x.shape
     npoint = nx.shape[1]
     out = np.empty((B, npoint, nsample), np.int32)
-    lib().orc_ball_query(_p(nx), _p(x), B, N, C, npoint, ctypes.c_float(radius), nsample, _p(out))
-    return out
+    cnt = np.empty((B, npoint), np.int32)
+    lib().orc_ball_query(_p(nx), _p(x), B, N, C, npoint, ctypes.c_float(radius), nsample, _p(out), _p(cnt))
+    return (out, cnt) if return_counts else out
 
 
 def group_points(xyz, new_xyz, feat, idx) -> np.ndarray:

@@ -74,10 +74,11 @@ def test_ball_query_bit_exact(oracle, B, N, npoint, radius, nsample, stride):
     x[..., :3] *= 0.5
     centres = np.ascontiguousarray(x[:, :npoint, :3]).copy()
     centres[:, -1] = 50.0  # a query with no neighbour at all -> zeros
-    idx = ball_query(radius, nsample, T(x), T(centres))
-    ref = oracle.ball_query(centres, x, radius, nsample)
+    idx, cnt = ball_query(radius, nsample, T(x), T(centres), return_counts=True)
+    ref, rcnt = oracle.ball_query(centres, x, radius, nsample, return_counts=True)
     np.testing.assert_array_equal(idx.cpu().numpy(), ref)
-    assert (ref[:, -1] == 0).all()
+    np.testing.assert_array_equal(cnt.cpu().numpy(), rcnt)
+    assert (ref[:, -1] == 0).all() and (rcnt[:, -1] == 0).all()
 
 
 def test_group_points_matches_oracle(oracle):
@@ -90,3 +91,18 @@ def test_group_points_matches_oracle(oracle):
     got = query_and_group(T(x), nx, T(np.ascontiguousarray(feat.transpose(0, 2, 1))), nbr)
     ref = oracle.group_points(x, nx.cpu().numpy(), feat, nbr.cpu().numpy())
     np.testing.assert_array_equal(got.cpu().numpy(), ref)
+
+
+def test_sort_queries_by_tiles():
+    from mpinets_amd import _lib
+
+    rng = np.random.default_rng(0)
+    cnt = rng.integers(0, 140, 5000).astype(np.int32)
+    tc = T(cnt)
+    order = torch.empty(5000, dtype=torch.int32, device=dev())
+    scratch = torch.empty(32, dtype=torch.int32, device=dev())
+    _lib.call("mpx_sort_queries", _lib.ptr(tc), 5000, 128, _lib.ptr(order), _lib.ptr(scratch))
+    o = order.cpu().numpy()
+    assert sorted(o.tolist()) == list(range(5000))  # a permutation
+    tiles = np.where(cnt <= 0, 1, (np.minimum(cnt, 128) + 31) // 32)
+    assert (np.diff(tiles[o]) <= 0).all()  # non-increasing tile count

@@ -239,3 +239,22 @@ def test_policy_forward_bf16x3_within_tolerance(oracle):
     print("bf16x3 policy delta max abs err vs fp32 oracle: %.3e (fp32 kernels: %.3e)" % (
         err, np.abs(dq32.cpu().numpy() - odq).max()))
     assert err <= TOL
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_padding_elision_is_bit_identical(precision):
+    """Skipping neighbourhood tiles that hold only ball-query padding must not change a single bit."""
+    from mpinets_amd.model import MotionPolicyNetwork
+    from mpinets_amd.scenes import make_problem_batch
+
+    torch.manual_seed(5)
+    mdl = MotionPolicyNetwork().to(dev()).eval().set_precision(precision)
+    prob = make_problem_batch(5, seed=9, device=dev(), kinds=("tabletop", "cubby", "dresser"), M1=40, device_clouds=True)
+    a, b = {}, {}
+    with torch.no_grad():
+        dq_on = mdl.set_elide_padding(True)(prob["xyz"], prob["q_norm"], aux=a)
+        dq_off = mdl.set_elide_padding(False)(prob["xyz"], prob["q_norm"], aux=b)
+    assert torch.equal(a["f1"], b["f1"]) and torch.equal(a["sa3_in"], b["sa3_in"]) and torch.equal(dq_on, dq_off)
+    c1, c2 = a["ball_cnt1"].float(), a["ball_cnt2"].float()
+    print("mean distinct neighbours: SA1 %.1f, SA2 %.1f of 128" % (c1.mean(), c2.mean()))
+    assert c1.min() >= 1 and c2.max() <= 128
