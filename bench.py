@@ -145,7 +145,14 @@ def main():
     if rank == 0:
         sa = prof["mpx_sa_mlp"]
         sa1_ms, sa2_ms = float(np.mean(sa[0::2])), float(np.mean(sa[1::2]))
-        achieved = SA2_FLOPS * B / (sa2_ms * 1e-3) / 1e12
+        # Executed work: a neighbourhood is walked in 32-point tiles and tiles that hold only ball-query
+        # padding (repeats of the first neighbour) are skipped -- bit-identical output.  The roofline uses
+        # the FLOPs of the tiles actually walked (counts of the last timed step), not the nominal 128 slots.
+        cnt1, cnt2 = model.point_cloud_encoder.last_counts
+        tiles = lambda c: int(((c.clamp(1, 128) + 31) // 32).sum().item())
+        t1, t2 = tiles(cnt1), tiles(cnt2)
+        sa1_exec, sa2_exec = t1 * 32 * 8448 * 2, t2 * 32 * 57728 * 2
+        achieved = sa2_exec / (sa2_ms * 1e-3) / 1e12
         total_envsteps = B * n_gpus * args.steps
         out = {
             "metric": "env-steps/sec (FK+SDF+PointNet++)",
@@ -172,11 +179,16 @@ def main():
                 "kernel": "sa_mlp_kernel<64,128,128,256> (SA2 fused group+MLP+maxpool)",
                 "bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
-                "ms_per_launch": sa2_ms, "flops_per_launch": SA2_FLOPS * B,
+                "ms_per_launch": sa2_ms, "flops_per_launch": sa2_exec,
+                "note": "achieved = FLOPs of the neighbourhood tiles actually walked / time; padding-only tiles "
+                        "are skipped (bit-identical result)",
+                "tiles_walked": t2, "tiles_nominal": B * 128 * 4, "nominal_flops_per_launch": SA2_FLOPS * B,
+                "nominal_equivalent_tflops": SA2_FLOPS * B / (sa2_ms * 1e-3) / 1e12,
             },
             "kernels_ms": {
                 "sa2_mlp": sa2_ms, "sa1_mlp": sa1_ms,
-                "sa1_tflops": SA1_FLOPS * B / (sa1_ms * 1e-3) / 1e12,
+                "sa1_tflops_executed": sa1_exec / (sa1_ms * 1e-3) / 1e12, "sa1_tiles_walked": t1,
+                "sa1_tiles_nominal": B * 512 * 4,
                 "fps": float(np.sum(prof["mpx_fps"])) / args.steps,
                 "ball_query": float(np.sum(prof["mpx_ball_query"])) / args.steps,
                 "linear_all": float(np.sum(prof["mpx_linear"])) / args.steps,
@@ -192,10 +204,8 @@ def main():
                 "dtype": "bf16x3", "value": B * n_gpus * args.fast_steps / fel, "unit": "env-steps/s",
                 "steps": args.fast_steps, "ms_per_step": fel / args.fast_steps * 1e3,
                 "sa1_ms": f1_ms, "sa2_ms": f2_ms,
-                "sa2_algorithmic_tflops": SA2_FLOPS * B / (f2_ms * 1e-3) / 1e12,
-                "sa2_frac_of_bf16_peak_2500": SA2_FLOPS * B / (f2_ms * 1e-3) / 1e12 / 2500.0,
-                # executed MFMA work: 348 bf16 MFMAs (32x32x16) per 32-neighbour tile = 3 x padded-K flops
-                "sa2_mfma_pipe_busy_est": 348 * 32768 * 512 * B / (f2_ms * 1e-3) / 1e12 / 2500.0,
+                "sa2_executed_tflops": sa2_exec / (f2_ms * 1e-3) / 1e12,
+                "sa2_frac_of_bf16_peak_2500": sa2_exec / (f2_ms * 1e-3) / 1e12 / 2500.0,
             }
         if args.cpu_envs > 0:
             out["cpu_baseline"] = cpu_baseline(prob, model, args.cpu_envs)

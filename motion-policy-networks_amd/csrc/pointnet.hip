@@ -374,13 +374,25 @@ __global__ void __launch_bounds__(256)
 __global__ void __launch_bounds__(256)
     tile_scatter_kernel(const int32_t *__restrict__ cnt, int64_t n, int nsample, const int32_t *__restrict__ hist,
                         int32_t *__restrict__ cursor, int32_t *__restrict__ order) {
+  // block-local ranking in LDS, then ONE global atomic per (block, bin) to reserve a range
+  __shared__ int lh[8], lbase[8];
+  if (threadIdx.x < 8) lh[threadIdx.x] = 0;
+  __syncthreads();
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  const int c = cnt[i];
-  const int t = c <= 0 ? 1 : ((c >= nsample ? nsample : c) + 31) / 32;
-  int base = 0;  // bins in decreasing tile count
-  for (int b = 7; b > t - 1; --b) base += hist[b];
-  order[base + atomicAdd(cursor + (t - 1), 1)] = (int32_t)i;
+  int t = 0, rank = 0;
+  if (i < n) {
+    const int c = cnt[i];
+    t = c <= 0 ? 1 : ((c >= nsample ? nsample : c) + 31) / 32;
+    rank = atomicAdd(&lh[t - 1], 1);
+  }
+  __syncthreads();
+  if (threadIdx.x < 8) {
+    int base = 0;  // bins in decreasing tile count
+    for (int b = 7; b > (int)threadIdx.x; --b) base += hist[b];
+    lbase[threadIdx.x] = base + (lh[threadIdx.x] ? atomicAdd(cursor + threadIdx.x, lh[threadIdx.x]) : 0);
+  }
+  __syncthreads();
+  if (i < n) order[lbase[t - 1] + rank] = (int32_t)i;
 }
 
 MPX_EXPORT int mpx_sort_queries(const int32_t *cnt, int64_t n, int nsample, int32_t *order, int32_t *scratch,

@@ -151,13 +151,17 @@ template <int CF, int C1, int C2, int C3>
 __global__ void __launch_bounds__(256, 2)
     sa_mlp_kernel(const float *__restrict__ xyz, int stride, const float *__restrict__ new_xyz, int new_stride,
                   const float *__restrict__ feat, int feat_stride, const int32_t *__restrict__ idx,
-                  const int32_t *__restrict__ cnt, int64_t n_query, int N, int npoint, int nsample,
-                  const float *__restrict__ wpack, float *__restrict__ out, int out_stride) {
+                  const int32_t *__restrict__ cnt, const int32_t *__restrict__ order, int64_t n_query, int N,
+                  int npoint, int nsample, const float *__restrict__ wpack, float *__restrict__ out,
+                  int out_stride) {
   using Cfg = SaCfg<CF, C1, C2, C3>;
   const int lane = threadIdx.x & 63;
   const int half = lane >> 5, col = lane & 31;
-  const int64_t qid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  int64_t qid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (qid >= n_query) return;  // wave-uniform
+  // `order` (optional): queries sorted by tile count, longest first -- the 4 waves of a workgroup then
+  // finish together and the tail of the launch is made of the short ones
+  if (order) qid = __builtin_amdgcn_readfirstlane(order[qid]);
   const int64_t b = qid / npoint;
 
   const __amdgpu_buffer_rsrc_t wrsrc =
@@ -283,13 +287,14 @@ __global__ void __launch_bounds__(256, 2)
 // ---- host entry points -----------------------------------------------------------------------------------
 template <int CF, int C1, int C2, int C3>
 static int launch_sa(const float *xyz, int stride, const float *new_xyz, int new_stride, const float *feat,
-                     int feat_stride, const int32_t *idx, const int32_t *cnt, int B, int N, int npoint, int nsample,
+                     int feat_stride, const int32_t *idx, const int32_t *cnt, const int32_t *order, int B, int N,
+                     int npoint, int nsample,
                      const float *wpack, float *out, int out_stride, mpx_stream_t stream) {
   const int64_t nq = (int64_t)B * npoint;
   MPX_REQUIRE(nq / 4 + 1 < ((int64_t)1 << 31), "mpx_sa_mlp: too many query points");
   hipLaunchKernelGGL((sa_mlp_kernel<CF, C1, C2, C3>), dim3((unsigned)((nq + 3) / 4)), dim3(256), 0,
-                     mpx_s(stream), xyz, stride, new_xyz, new_stride, feat, feat_stride, idx, cnt, nq, N, npoint,
-                     nsample, wpack, out, out_stride);
+                     mpx_s(stream), xyz, stride, new_xyz, new_stride, feat, feat_stride, idx, cnt, order, nq, N,
+                     npoint, nsample, wpack, out, out_stride);
   MPX_LAUNCH_CHECK("mpx_sa_mlp");
 }
 
@@ -302,9 +307,9 @@ static int launch_sa(const float *xyz, int stride, const float *new_xyz, int new
   }
 
 MPX_EXPORT int mpx_sa_mlp(const float *xyz, int stride, const float *new_xyz, int new_stride,
-                          const float *feat, int feat_stride, int C, const int32_t *idx, const int32_t *cnt, int B,
-                          int N, int npoint, int nsample, const float *wpack, int c1, int c2, int c3, float *out,
-                          int out_stride, mpx_stream_t stream) {
+                          const float *feat, int feat_stride, int C, const int32_t *idx, const int32_t *cnt,
+                          const int32_t *order, int B, int N, int npoint, int nsample, const float *wpack, int c1,
+                          int c2, int c3, float *out, int out_stride, mpx_stream_t stream) {
   MPX_REQUIRE(B >= 0 && N >= 1 && npoint >= 0, "mpx_sa_mlp: bad size");
   MPX_REQUIRE(nsample > 0 && nsample % 32 == 0, "mpx_sa_mlp: nsample must be a positive multiple of 32");
   MPX_REQUIRE(stride >= 3 && new_stride >= 3 && out_stride >= c3, "mpx_sa_mlp: bad stride");
@@ -313,7 +318,7 @@ MPX_EXPORT int mpx_sa_mlp(const float *xyz, int stride, const float *new_xyz, in
   MPX_REQUIRE(((uintptr_t)wpack & 15) == 0, "mpx_sa_mlp: wpack must be 16-byte aligned");
   if (B == 0 || npoint == 0) return 0;
 #define CALL(a, b, c, d) \
-  return launch_sa<a, b, c, d>(xyz, stride, new_xyz, new_stride, feat, feat_stride, idx, cnt, B, N, npoint, nsample, wpack, out, out_stride, stream)
+  return launch_sa<a, b, c, d>(xyz, stride, new_xyz, new_stride, feat, feat_stride, idx, cnt, order, B, N, npoint, nsample, wpack, out, out_stride, stream)
   SA_DISPATCH(CALL)
 #undef CALL
 }

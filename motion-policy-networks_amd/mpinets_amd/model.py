@@ -135,6 +135,7 @@ class MPiNetsPointNet(nn.Module):
             nb = min(65535, B - b0)
             lib.call("mpx_rowmax", lib.ptr(h[b0 * sa2.npoint:]), h.stride(0), nb, sa2.npoint, h.size(1),
                      lib.ptr(pooled[b0:]), pooled.stride(0))
+        self.last_counts = (cnt1, cnt2)  # distinct-neighbour counts of the latest forward (bench accounting)
         if aux is not None:
             aux.update(fps_idx1=idx1, xyz1=xyz1, ball_idx1=nbr1, ball_cnt1=cnt1, f1=f1, fps_idx2=idx2, ball_idx2=nbr2,
                        ball_cnt2=cnt2, sa3_in=sa3_in, f3=pooled)
