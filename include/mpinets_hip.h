@@ -202,6 +202,12 @@ int mpx_sa_pack_bf16x3(const float *w1, const float *b1, const float *w2, const 
 int mpx_linear(const float *x, int ldx, const float *w, const float *bias, int M, int N, int K,
                int act, float *y, int ldy, mpx_stream_t stream);
 
+/* Last layer of the group-all SA module with its max-pool fused (model.py:383):
+ *   y[g, n] = max over the `rows` rows of group g of relu(x[g*rows + r, :] . w[n, :] + bias[n])
+ * rows must be 128 (one workgroup tile) and divide M; y [M/rows, N] is written (zeroed first).  */
+int mpx_linear_rowmax(const float *x, int ldx, const float *w, const float *bias, int M, int N,
+                      int K, int rows, float *y, int ldy, mpx_stream_t stream);
+
 /* nn.GroupNorm(groups, C) (eps 1e-5, biased variance) followed by LeakyReLU(0.01), in place
  * allowed.  x,y [M,C].                                                                       */
 int mpx_groupnorm_leaky(const float *x, const float *gamma, const float *beta, int M, int C,

@@ -16,9 +16,11 @@
 // an fmaf chain in this k order): bound by the 157 TFLOP/s fp32 MFMA pipe.
 #include "common.h"
 
+#include <stdlib.h>
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128, BN = 128, BK = 16, LDT = BK + 4;
+constexpr int BM = 128, BN = 128;
 
 __device__ __forceinline__ float act_apply(float v, int act) {
   if (act == MPX_ACT_RELU) return fmaxf(v, 0.0f);
@@ -26,9 +28,16 @@ __device__ __forceinline__ float act_apply(float v, int act) {
   return v;
 }
 
+// POOL: instead of storing the [M,N] result, max-pool it over each workgroup's BM = 128 rows (one
+// environment of the group-all module) into y[blockIdx.y][n] with atomicMax on the float bits -- valid
+// because the pooled values are post-ReLU (>= 0) and y is zero-initialised by the launcher.
+template <int BK, bool POOL>
 __global__ void __launch_bounds__(256)
     linear_kernel(const float *__restrict__ x, int ldx, const float *__restrict__ w,
                   const float *__restrict__ bias, int M, int N, int K, int act, float *__restrict__ y, int ldy) {
+  constexpr int LDT = BK + 4;       // padded row: conflict-free 16-byte fragment reads
+  constexpr int HK = BK / 2;        // k-values per lane-half per slab
+  constexpr int NLD = BK / 8;       // float4 staged per thread per matrix per slab
   __shared__ __attribute__((aligned(16))) float As[2][BM * LDT];
   __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDT];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -36,13 +45,14 @@ __global__ void __launch_bounds__(256)
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
 
-  // staging map: thread -> (row, 4-float column chunk), two rows (r, r+64) per matrix
-  const int srow = tid >> 2, scol = (tid & 3) * 4;
-  float4 pa[2], pb[2];
+  // staging map: thread -> (row, 4-float column chunk); BK/4 chunks per row, NLD rows per thread
+  constexpr int CPR = BK / 4, RPP = 256 / CPR;  // chunks per row, rows per pass
+  const int srow = tid / CPR, scol = (tid % CPR) * 4;
+  float4 pa[NLD], pb[NLD];
   auto gload = [&](int k0) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int r = srow + 64 * i;
+    for (int i = 0; i < NLD; ++i) {
+      const int r = srow + RPP * i;
       const int kk = k0 + scol;
       pa[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       pb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -52,8 +62,8 @@ __global__ void __launch_bounds__(256)
   };
   auto sstore = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int r = srow + 64 * i;
+    for (int i = 0; i < NLD; ++i) {
+      const int r = srow + RPP * i;
       *reinterpret_cast<float4 *>(&As[buf][r * LDT + scol]) = pa[i];
       *reinterpret_cast<float4 *>(&Bs[buf][r * LDT + scol]) = pb[i];
     }
@@ -65,23 +75,23 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
-  const int nk = (K + BK - 1) / BK;
+  const int nk = (K + BK - 1) / BK;  // the k-guards zero-fill a partial last slab
   gload(0);
   sstore(0);
   __syncthreads();
   for (int kb = 0; kb < nk; ++kb) {
     const int buf = kb & 1;
     if (kb + 1 < nk) gload((kb + 1) * BK);
-    float4 a[2][2], b[2][2];
+    float4 a[2][HK / 4], b[2][HK / 4];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int v = 0; v < 2; ++v) {
-        a[t][v] = *reinterpret_cast<const float4 *>(&As[buf][(wm * 64 + t * 32 + l31) * LDT + 8 * half + 4 * v]);
-        b[t][v] = *reinterpret_cast<const float4 *>(&Bs[buf][(wn * 64 + t * 32 + l31) * LDT + 8 * half + 4 * v]);
+      for (int v = 0; v < HK / 4; ++v) {
+        a[t][v] = *reinterpret_cast<const float4 *>(&As[buf][(wm * 64 + t * 32 + l31) * LDT + HK * half + 4 * v]);
+        b[t][v] = *reinterpret_cast<const float4 *>(&Bs[buf][(wn * 64 + t * 32 + l31) * LDT + HK * half + 4 * v]);
       }
 #pragma unroll
-    for (int v = 0; v < 2; ++v)
+    for (int v = 0; v < HK / 4; ++v)
 #pragma unroll
       for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -102,13 +112,26 @@ __global__ void __launch_bounds__(256)
     const int col = n0 + wn * 64 + j * 32 + l31;
     if (col >= N) continue;
     const float bv = bias ? bias[col] : 0.0f;
+    if (POOL) {
+      float m = 0.0f;  // post-ReLU values are >= 0
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (row < M) y[(size_t)row * ldy + col] = act_apply(acc[i][j][r] + bv, act);
-      }
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (row < M) m = fmaxf(m, act_apply(acc[i][j][r] + bv, act));
+        }
+      m = fmaxf(m, __shfl_xor(m, 32));
+      if (half == 0) atomicMax(reinterpret_cast<int *>(y + (size_t)blockIdx.y * ldy + col), __float_as_int(m));
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          if (row < M) y[(size_t)row * ldy + col] = act_apply(acc[i][j][r] + bv, act);
+        }
+    }
   }
 }
 
@@ -121,9 +144,36 @@ MPX_EXPORT int mpx_linear(const float *x, int ldx, const float *w, const float *
   MPX_REQUIRE(act >= 0 && act <= 2, "mpx_linear: unknown activation %d", act);
   if (M == 0) return 0;
   MPX_REQUIRE(cdiv(M, BM) <= 65535, "mpx_linear: M too large");
-  hipLaunchKernelGGL(linear_kernel, dim3(cdiv(N, BN), cdiv(M, BM)), dim3(256), 0, mpx_s(stream), x, ldx, w, bias,
-                     M, N, K, act, y, ldy);
+  static const int bk = getenv("MPX_GEMM_BK") ? atoi(getenv("MPX_GEMM_BK")) : 16;  // tuning override
+  if (bk == 32 && K >= 64)
+    hipLaunchKernelGGL((linear_kernel<32, false>), dim3(cdiv(N, BN), cdiv(M, BM)), dim3(256), 0, mpx_s(stream), x, ldx,
+                       w, bias, M, N, K, act, y, ldy);
+  else
+    hipLaunchKernelGGL((linear_kernel<16, false>), dim3(cdiv(N, BN), cdiv(M, BM)), dim3(256), 0, mpx_s(stream), x, ldx,
+                       w, bias, M, N, K, act, y, ldy);
   MPX_LAUNCH_CHECK("mpx_linear");
+}
+
+MPX_EXPORT int mpx_linear_rowmax(const float *x, int ldx, const float *w, const float *bias, int M, int N, int K,
+                                 int rows, float *y, int ldy, mpx_stream_t stream) {
+  MPX_REQUIRE(M >= 0 && N >= 1 && K >= 1, "mpx_linear_rowmax: bad size");
+  MPX_REQUIRE(rows == BM && M % BM == 0, "mpx_linear_rowmax: pooled groups must be exactly %d rows", BM);
+  MPX_REQUIRE(K % 4 == 0 && ldx % 4 == 0, "mpx_linear_rowmax: K and ldx must be multiples of 4");
+  MPX_REQUIRE((((uintptr_t)x | (uintptr_t)w) & 15) == 0, "mpx_linear_rowmax: x and w must be 16-byte aligned");
+  MPX_REQUIRE(ldx >= K && ldy >= N, "mpx_linear_rowmax: leading dimension too small");
+  if (M == 0) return 0;
+  MPX_REQUIRE(M / BM <= 65535, "mpx_linear_rowmax: M too large");
+  hipError_t e = hipMemset2DAsync(y, (size_t)ldy * sizeof(float), 0, (size_t)N * sizeof(float), (size_t)(M / BM),
+                                  mpx_s(stream));
+  MPX_REQUIRE(e == hipSuccess, "mpx_linear_rowmax: memset failed: %s", hipGetErrorString(e));
+  static const int bk = getenv("MPX_GEMM_BK") ? atoi(getenv("MPX_GEMM_BK")) : 16;
+  if (bk == 32 && K >= 64)
+    hipLaunchKernelGGL((linear_kernel<32, true>), dim3(cdiv(N, BN), M / BM), dim3(256), 0, mpx_s(stream), x, ldx, w,
+                       bias, M, N, K, MPX_ACT_RELU, y, ldy);
+  else
+    hipLaunchKernelGGL((linear_kernel<16, true>), dim3(cdiv(N, BN), M / BM), dim3(256), 0, mpx_s(stream), x, ldx, w,
+                       bias, M, N, K, MPX_ACT_RELU, y, ldy);
+  MPX_LAUNCH_CHECK("mpx_linear_rowmax");
 }
 
 // ---- GroupNorm + LeakyReLU ---------------------------------------------------------------------------

@@ -45,6 +45,7 @@ PROTOTYPES = {
     "mpx_sa_pack_bf16x3_size": [I, I, I, I],
     "mpx_sa_pack_bf16x3": [P, P, P, P, P, P, I, I, I, I, P, P],
     "mpx_linear": [P, I, P, P, I, I, I, I, P, I, P],
+    "mpx_linear_rowmax": [P, I, P, P, I, I, I, I, P, I, P],
     "mpx_groupnorm_leaky": [P, P, P, I, I, I, F, P, P],
     "mpx_rowmax": [P, I, I, I, I, P, I, P],
 }

@@ -129,12 +129,20 @@ class MPiNetsPointNet(nn.Module):
         h = sa3_in.view(B * sa2.npoint, K3)
         h = linear(h, self._sa3_first_weight(), c3[0].bias, ACT_RELU)
         h = linear(h, c3[1].weight.view(c3[1].out_channels, -1), c3[1].bias, ACT_RELU)
-        h = linear(h, c3[2].weight.view(c3[2].out_channels, -1), c3[2].bias, ACT_RELU)
-        pooled = torch.empty((B, h.size(1)), dtype=torch.float32, device=dev)
-        for b0 in range(0, B, 65535):
-            nb = min(65535, B - b0)
-            lib.call("mpx_rowmax", lib.ptr(h[b0 * sa2.npoint:]), h.stride(0), nb, sa2.npoint, h.size(1),
-                     lib.ptr(pooled[b0:]), pooled.stride(0))
+        # last layer + max over each environment's 128 points in one kernel (nothing [B*128,1024] is stored)
+        w3 = c3[2].weight.view(c3[2].out_channels, -1)
+        pooled = torch.empty((B, w3.size(0)), dtype=torch.float32, device=dev)
+        if sa2.npoint == 128:
+            for b0 in range(0, B, 65535):
+                nb = min(65535, B - b0)
+                lib.call("mpx_linear_rowmax", lib.ptr(h[b0 * 128:]), h.stride(0), lib.ptr(w3), lib.ptr(c3[2].bias),
+                         nb * 128, w3.size(0), w3.size(1), 128, lib.ptr(pooled[b0:]), pooled.stride(0))
+        else:
+            h = linear(h, w3, c3[2].bias, ACT_RELU)
+            for b0 in range(0, B, 65535):
+                nb = min(65535, B - b0)
+                lib.call("mpx_rowmax", lib.ptr(h[b0 * sa2.npoint:]), h.stride(0), nb, sa2.npoint, h.size(1),
+                         lib.ptr(pooled[b0:]), pooled.stride(0))
         self.last_counts = (cnt1, cnt2)  # distinct-neighbour counts of the latest forward (bench accounting)
         if aux is not None:
             aux.update(fps_idx1=idx1, xyz1=xyz1, ball_idx1=nbr1, ball_cnt1=cnt1, f1=f1, fps_idx2=idx2, ball_idx2=nbr2,

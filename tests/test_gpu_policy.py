@@ -258,3 +258,17 @@ def test_padding_elision_is_bit_identical(precision):
     c1, c2 = a["ball_cnt1"].float(), a["ball_cnt2"].float()
     print("mean distinct neighbours: SA1 %.1f, SA2 %.1f of 128" % (c1.mean(), c2.mean()))
     assert c1.min() >= 1 and c2.max() <= 128
+
+
+def test_linear_rowmax_equals_linear_then_rowmax():
+    from mpinets_amd import _lib
+    from mpinets_amd.pointnet2 import linear
+
+    rng = np.random.default_rng(4)
+    x = T(rng.normal(size=(5 * 128, 512)).astype(np.float32))
+    w = T((rng.normal(size=(1024, 512)) * 0.05).astype(np.float32))
+    b = T(rng.normal(size=1024).astype(np.float32))
+    ref = linear(x, w, b, 1).reshape(5, 128, 1024).max(dim=1).values
+    out = torch.full((5, 1024), -1.0, device=dev())
+    _lib.call("mpx_linear_rowmax", _lib.ptr(x), 512, _lib.ptr(w), _lib.ptr(b), 640, 1024, 512, 128, _lib.ptr(out), 1024)
+    assert torch.equal(out, ref)
