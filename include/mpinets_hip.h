@@ -159,14 +159,14 @@ int mpx_group_points(const float *xyz, int stride, const float *new_xyz, int new
  * wpack: weights + biases packed by mpx_sa_pack_weights for this (C, c1, c2, c3).
  * out rows at out + (b*npoint + j)*out_stride, c3 floats each.
  * Supported: (C,c1,c2,c3) = (1,64,64,64) and (64,128,128,256); nsample % 32 == 0.
- * cnt (optional, from mpx_ball_query): neighbourhood tiles that hold only padding (repeats of
- * the first neighbour) are skipped -- the MLP is per point and max-pooling is idempotent, so
- * the output is bit-identical to walking all nsample slots (cnt == NULL).  order (optional,
- * from mpx_sort_queries): query ids in the order workgroups should take them (longest first). */
+ * cnt (optional, from mpx_ball_query): only the DISTINCT neighbours are evaluated -- slots
+ * [cnt, nsample) repeat the first neighbour, the MLP is per point and max-pooling is idempotent,
+ * so the output is bit-identical to walking all nsample slots (cnt == NULL).  Several queries
+ * share a wave and their rows are packed at 4-row granularity into the 32-row MFMA tiles.    */
 int mpx_sa_mlp(const float *xyz, int stride, const float *new_xyz, int new_stride,
                const float *feat, int feat_stride, int C, const int32_t *idx, const int32_t *cnt,
-               const int32_t *order, int B, int N, int npoint, int nsample, const float *wpack, int c1,
-               int c2, int c3, float *out, int out_stride, mpx_stream_t stream);
+               int B, int N, int npoint, int nsample, const float *wpack, int c1, int c2, int c3,
+               float *out, int out_stride, mpx_stream_t stream);
 /* number of floats mpx_sa_pack_weights writes for this configuration (host call)            */
 int64_t mpx_sa_pack_size(int C, int c1, int c2, int c3);
 /* w1 [c1,3+C], w2 [c2,c1], w3 [c3,c2] row-major (Conv2d 1x1 weights), b* biases -> wpack    */

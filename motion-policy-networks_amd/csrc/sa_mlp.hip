@@ -151,17 +151,13 @@ template <int CF, int C1, int C2, int C3>
 __global__ void __launch_bounds__(256, 2)
     sa_mlp_kernel(const float *__restrict__ xyz, int stride, const float *__restrict__ new_xyz, int new_stride,
                   const float *__restrict__ feat, int feat_stride, const int32_t *__restrict__ idx,
-                  const int32_t *__restrict__ cnt, const int32_t *__restrict__ order, int64_t n_query, int N,
-                  int npoint, int nsample, const float *__restrict__ wpack, float *__restrict__ out,
-                  int out_stride) {
+                  int64_t n_query, int N, int npoint, int nsample, const float *__restrict__ wpack,
+                  float *__restrict__ out, int out_stride) {
   using Cfg = SaCfg<CF, C1, C2, C3>;
   const int lane = threadIdx.x & 63;
   const int half = lane >> 5, col = lane & 31;
-  int64_t qid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t qid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (qid >= n_query) return;  // wave-uniform
-  // `order` (optional): queries sorted by tile count, longest first -- the 4 waves of a workgroup then
-  // finish together and the tail of the launch is made of the short ones
-  if (order) qid = __builtin_amdgcn_readfirstlane(order[qid]);
   const int64_t b = qid / npoint;
 
   const __amdgpu_buffer_rsrc_t wrsrc =
@@ -179,15 +175,7 @@ __global__ void __launch_bounds__(256, 2)
 #pragma unroll
   for (int ot = 0; ot < Cfg::OT3; ++ot) omax[ot] = -__builtin_inff();
 
-  // Slots [cnt, nsample) of a neighbourhood repeat its first member (ball-query padding); the MLP is
-  // per point and max-pooling is idempotent, so tiles that hold nothing but repeats change nothing:
-  // walk only the tiles that contain distinct neighbours (bit-identical result, less work).
-  int n_rows = nsample;
-  if (cnt) {
-    const int c = __builtin_amdgcn_readfirstlane(cnt[qid]);
-    n_rows = c <= 0 ? 32 : (c >= nsample ? nsample : ((c + 31) & ~31));
-  }
-  for (int rt = 0; rt < n_rows; rt += 32) {
+  for (int rt = 0; rt < nsample; rt += 32) {
     // Loop-invariant buffer offsets are laundered through an empty asm each iteration: otherwise LICM
     // hoists the (invariant) bias and first-chunk weight loads out of the loop and they are spilled.
     int w1o = (int)Cfg::W1_OFF * 4, w2o = (int)Cfg::W2_OFF * 4, w3o = (int)Cfg::W3_OFF * 4;
@@ -284,17 +272,204 @@ __global__ void __launch_bounds__(256, 2)
   }
 }
 
+
+// ---- packed variant: only distinct neighbours are evaluated ---------------------------------------------
+// Slots [cnt, nsample) of a neighbourhood repeat its first member (ball-query padding).  The MLP is per
+// point and max-pooling is idempotent, so evaluating each distinct neighbour once gives a bit-identical
+// result.  A wave takes Q consecutive queries, rounds each neighbourhood up to a multiple of 4 rows
+// (repeating the first neighbour) and packs them back to back into 32-row MFMA tiles.  After the last
+// layer a lane holds, per output channel, four groups of 4 consecutive rows; every group belongs to one
+// query, so pooling is a max over each group followed by a merge of the groups in row order that flushes
+// the running maximum to the output row whenever the (wave-uniform) query changes.
+template <int CF, int C1, int C2, int C3, int Q>
+__global__ void __launch_bounds__(256, 2)
+    sa_mlp_packed_kernel(const float *__restrict__ xyz, int stride, const float *__restrict__ new_xyz,
+                         int new_stride, const float *__restrict__ feat, int feat_stride,
+                         const int32_t *__restrict__ idx, const int32_t *__restrict__ cnt, int64_t n_query, int N,
+                         int npoint, int nsample, const float *__restrict__ wpack, float *__restrict__ out,
+                         int out_stride) {
+  using Cfg = SaCfg<CF, C1, C2, C3>;
+  static_assert(Q >= 1 && Q <= 32, "queries per wave");
+  const int lane = threadIdx.x & 63;
+  const int half = lane >> 5, col = lane & 31;
+  const int64_t q0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * Q;
+  if (q0 >= n_query) return;  // wave-uniform
+  const int nq = (int)min((int64_t)Q, n_query - q0);
+
+  // lane i < nq: distinct-neighbour count of query q0+i, its row count (multiple of 4) and row offset
+  int my_cnt = 0, my_rows = 0;
+  if (lane < nq) {
+    const int c = cnt[q0 + lane];
+    my_cnt = c <= 0 ? 1 : (c > nsample ? nsample : c);  // no hit: the zero-initialised row = point 0
+    my_rows = (my_cnt + 3) & ~3;
+  }
+  int pre = my_rows;  // inclusive prefix sum over lanes 0..Q-1
+#pragma unroll
+  for (int o = 1; o < Q; o <<= 1) {
+    const int t = __shfl_up(pre, o);
+    if (lane >= o) pre += t;
+  }
+  const int total = __builtin_amdgcn_readlane(pre, Q - 1);
+  pre -= my_rows;  // exclusive
+  int s_pre[Q], s_cnt[Q];
+#pragma unroll
+  for (int i = 0; i < Q; ++i) {
+    s_pre[i] = __builtin_amdgcn_readlane(pre, i);
+    s_cnt[i] = __builtin_amdgcn_readlane(my_cnt, i);
+  }
+
+  const __amdgpu_buffer_rsrc_t wrsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(wpack), 0, (int)(Cfg::TOTAL * 4), 0x00020000);
+  const int wvoff = lane * 16;
+  const float *bias3 = wpack + Cfg::B3_OFF;
+
+  float run[Cfg::OT3];  // running max of the query being merged (this lane's half of its rows)
+#pragma unroll
+  for (int ot = 0; ot < Cfg::OT3; ++ot) run[ot] = -__builtin_inff();
+  int cur = 0;  // query (0..nq-1) being merged; wave-uniform
+
+  auto flush = [&](int qi) {
+    float *orow = out + (q0 + qi) * out_stride;
+#pragma unroll
+    for (int ot = 0; ot < Cfg::OT3; ++ot) {
+      float v = run[ot];
+      v = fmaxf(v, __shfl_xor(v, 32));
+      const int ch = ot * 32 + col;
+      v = fmaxf(v + bias3[ch], 0.0f);
+      if (half == 0) orow[ch] = v;
+      run[ot] = -__builtin_inff();
+    }
+  };
+
+  for (int rt = 0; rt < total; rt += 32) {
+    int w1o = (int)Cfg::W1_OFF * 4, w2o = (int)Cfg::W2_OFF * 4, w3o = (int)Cfg::W3_OFF * 4;
+    int b1o = (int)Cfg::B1_OFF * 4, b2o = (int)Cfg::B2_OFF * 4;
+    asm volatile("" : "+s"(w1o), "+s"(w2o), "+s"(w3o), "+s"(b1o), "+s"(b2o));
+    // ---- which (query, slot) is this lane's row? rows past the end repeat the last query's first slot --
+    const int p = rt + col;
+    int qi = 0, qpre = 0, qcnt = s_cnt[0];
+#pragma unroll
+    for (int i = 1; i < Q; ++i) {
+      const bool ge = i < nq && p >= s_pre[i];
+      qi = ge ? i : qi;
+      qpre = ge ? s_pre[i] : qpre;
+      qcnt = ge ? s_cnt[i] : qcnt;
+    }
+    const int slot = p - qpre;
+    const int64_t qg = q0 + qi;
+    const int k = idx[qg * nsample + (slot < qcnt ? slot : 0)];
+    const int64_t b = qg / npoint;
+    const float *ctr = new_xyz + qg * new_stride;
+    const float *pp = xyz + (b * N + k) * (int64_t)stride;
+    const float *f = feat + (b * N + k) * (int64_t)feat_stride;
+
+    float x0[Cfg::KS0];
+    {
+      const float dx = pp[0] - ctr[0], dy = pp[1] - ctr[1], dz = pp[2] - ctr[2];
+      x0[0] = half ? dy : dx;
+      if (CF == 1) {
+        x0[1] = half ? f[0] : dz;
+      } else {
+        x0[1] = half ? 0.0f : dz;
+        const float4 *fr = reinterpret_cast<const float4 *>(f + half * (CF / 2));
+#pragma unroll
+        for (int i = 0; i < CF / 8; ++i) {
+          const float4 v = fr[i];
+          x0[2 + 4 * i + 0] = v.x;
+          x0[2 + 4 * i + 1] = v.y;
+          x0[2 + 4 * i + 2] = v.z;
+          x0[2 + 4 * i + 3] = v.w;
+        }
+      }
+    }
+
+    f32x16 a1[Cfg::OT1];
+#pragma unroll
+    for (int ot = 0; ot < Cfg::OT1; ++ot) a1[ot] = bias_tile(wrsrc, b1o, ot, half);
+    stream_weights<Cfg::S1 / 4>(wrsrc, wvoff, w1o, [&](int g, const float4 &w) __attribute__((always_inline)) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int s = 4 * g + u, t = s / Cfg::OT1, ot = s % Cfg::OT1;
+        a1[ot] = mfma32(comp(w, u), x0[t], a1[ot]);
+      }
+    });
+#pragma unroll
+    for (int ot = 0; ot < Cfg::OT1; ++ot)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a1[ot][r] = fmaxf(a1[ot][r], 0.0f);
+
+    f32x16 a2[Cfg::OT2];
+#pragma unroll
+    for (int ot = 0; ot < Cfg::OT2; ++ot) a2[ot] = bias_tile(wrsrc, b2o, ot, half);
+    stream_weights<Cfg::S2 / 4>(wrsrc, wvoff, w2o, [&](int g, const float4 &w) __attribute__((always_inline)) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int s = 4 * g + u, t = s / Cfg::OT2, ot = s % Cfg::OT2;
+        a2[ot] = mfma32(comp(w, u), a1[t >> 4][t & 15], a2[ot]);
+      }
+    });
+#pragma unroll
+    for (int ot = 0; ot < Cfg::OT2; ++ot)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a2[ot][r] = fmaxf(a2[ot][r], 0.0f);
+
+    // ---- layer 3 (roles flipped) and the per-group maxima: gm[ot][j] = max over rows 8j+4*half .. +3 -------
+    float gm[Cfg::OT3][4];
+    {
+      f32x16 a3;
+      constexpr int GPT = Cfg::KS2 / 4;
+      stream_weights<Cfg::S3 / 4>(wrsrc, wvoff, w3o, [&](int g, const float4 &w) __attribute__((always_inline)) {
+        const int ot = g / GPT, gg = g % GPT;
+        if (gg == 0) a3 = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int t = 4 * gg + u;
+          a3 = mfma32(a2[t >> 4][t & 15], comp(w, u), a3);
+        }
+        if (gg == GPT - 1) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            gm[ot][j] = fmaxf(fmaxf(a3[4 * j], a3[4 * j + 1]), fmaxf(a3[4 * j + 2], a3[4 * j + 3]));
+        }
+      });
+    }
+    // ---- merge the tile's 8 row groups in row order; group g = 2j + half holds rows rt + 4g .. +3 --------
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      if (rt + 4 * g < total) {  // wave-uniform
+        const int gq = __builtin_amdgcn_readlane(qi, 4 * g);  // the lane of the group's first row knows its query
+        if (gq != cur) {
+          flush(cur);
+          cur = gq;
+        }
+        if ((g & 1) == half) {
+#pragma unroll
+          for (int ot = 0; ot < Cfg::OT3; ++ot) run[ot] = fmaxf(run[ot], gm[ot][g >> 1]);
+        }
+      }
+    }
+  }
+  flush(cur);
+}
+
 // ---- host entry points -----------------------------------------------------------------------------------
 template <int CF, int C1, int C2, int C3>
 static int launch_sa(const float *xyz, int stride, const float *new_xyz, int new_stride, const float *feat,
-                     int feat_stride, const int32_t *idx, const int32_t *cnt, const int32_t *order, int B, int N,
-                     int npoint, int nsample,
+                     int feat_stride, const int32_t *idx, const int32_t *cnt, int B, int N, int npoint, int nsample,
                      const float *wpack, float *out, int out_stride, mpx_stream_t stream) {
   const int64_t nq = (int64_t)B * npoint;
   MPX_REQUIRE(nq / 4 + 1 < ((int64_t)1 << 31), "mpx_sa_mlp: too many query points");
-  hipLaunchKernelGGL((sa_mlp_kernel<CF, C1, C2, C3>), dim3((unsigned)((nq + 3) / 4)), dim3(256), 0,
-                     mpx_s(stream), xyz, stride, new_xyz, new_stride, feat, feat_stride, idx, cnt, order, nq, N,
-                     npoint, nsample, wpack, out, out_stride);
+  if (cnt) {
+    constexpr int Q = CF == 1 ? 16 : 4;  // queries per wave: ~6 tiles of work on typical scenes
+    const int64_t nw = (nq + Q - 1) / Q;
+    hipLaunchKernelGGL((sa_mlp_packed_kernel<CF, C1, C2, C3, Q>), dim3((unsigned)((nw + 3) / 4)), dim3(256), 0,
+                       mpx_s(stream), xyz, stride, new_xyz, new_stride, feat, feat_stride, idx, cnt, nq, N, npoint,
+                       nsample, wpack, out, out_stride);
+  } else {
+    hipLaunchKernelGGL((sa_mlp_kernel<CF, C1, C2, C3>), dim3((unsigned)((nq + 3) / 4)), dim3(256), 0,
+                       mpx_s(stream), xyz, stride, new_xyz, new_stride, feat, feat_stride, idx, nq, N, npoint,
+                       nsample, wpack, out, out_stride);
+  }
   MPX_LAUNCH_CHECK("mpx_sa_mlp");
 }
 
@@ -307,9 +482,9 @@ static int launch_sa(const float *xyz, int stride, const float *new_xyz, int new
   }
 
 MPX_EXPORT int mpx_sa_mlp(const float *xyz, int stride, const float *new_xyz, int new_stride,
-                          const float *feat, int feat_stride, int C, const int32_t *idx, const int32_t *cnt,
-                          const int32_t *order, int B, int N, int npoint, int nsample, const float *wpack, int c1,
-                          int c2, int c3, float *out, int out_stride, mpx_stream_t stream) {
+                          const float *feat, int feat_stride, int C, const int32_t *idx, const int32_t *cnt, int B,
+                          int N, int npoint, int nsample, const float *wpack, int c1, int c2, int c3, float *out,
+                          int out_stride, mpx_stream_t stream) {
   MPX_REQUIRE(B >= 0 && N >= 1 && npoint >= 0, "mpx_sa_mlp: bad size");
   MPX_REQUIRE(nsample > 0 && nsample % 32 == 0, "mpx_sa_mlp: nsample must be a positive multiple of 32");
   MPX_REQUIRE(stride >= 3 && new_stride >= 3 && out_stride >= c3, "mpx_sa_mlp: bad stride");
@@ -318,7 +493,7 @@ MPX_EXPORT int mpx_sa_mlp(const float *xyz, int stride, const float *new_xyz, in
   MPX_REQUIRE(((uintptr_t)wpack & 15) == 0, "mpx_sa_mlp: wpack must be 16-byte aligned");
   if (B == 0 || npoint == 0) return 0;
 #define CALL(a, b, c, d) \
-  return launch_sa<a, b, c, d>(xyz, stride, new_xyz, new_stride, feat, feat_stride, idx, cnt, order, B, N, npoint, nsample, wpack, out, out_stride, stream)
+  return launch_sa<a, b, c, d>(xyz, stride, new_xyz, new_stride, feat, feat_stride, idx, cnt, B, N, npoint, nsample, wpack, out, out_stride, stream)
   SA_DISPATCH(CALL)
 #undef CALL
 }

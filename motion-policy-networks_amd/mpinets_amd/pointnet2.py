@@ -138,12 +138,16 @@ def launch_sa(precision: str, xyz_ptr: int, stride: int, new_xyz_ptr: int, new_s
     ``cnt`` (from the ball query) lets the kernel skip neighbourhood tiles that hold only padding --
     bit-identical output; for the lockstep bf16x3 kernel the queries are first ordered by tile count."""
     c1, c2, c3 = widths
+    if precision == "fp32":
+        _lib.call("mpx_sa_mlp", xyz_ptr, stride, new_xyz_ptr, new_stride, feat_ptr, feat_stride, C, _lib.ptr(idx),
+                  _lib.ptr(cnt), B, N, npoint, nsample, _lib.ptr(wpack), c1, c2, c3, out_ptr, out_stride)
+        return
     order = None
     if cnt is not None:
         order = torch.empty(B * npoint, dtype=torch.int32, device=idx.device)
         scratch = torch.empty(32, dtype=torch.int32, device=idx.device)
         _lib.call("mpx_sort_queries", _lib.ptr(cnt), B * npoint, nsample, _lib.ptr(order), _lib.ptr(scratch))
-    _lib.call(SA_KERNEL[precision], xyz_ptr, stride, new_xyz_ptr, new_stride, feat_ptr, feat_stride, C, _lib.ptr(idx),
+    _lib.call("mpx_sa_mlp_bf16x3", xyz_ptr, stride, new_xyz_ptr, new_stride, feat_ptr, feat_stride, C, _lib.ptr(idx),
               _lib.ptr(cnt), _lib.ptr(order), B, N, npoint, nsample, _lib.ptr(wpack), c1, c2, c3, out_ptr, out_stride)
 
 
