@@ -141,9 +141,9 @@ int mpx_ball_query(const float *new_xyz, int new_stride, const float *xyz, int s
                    int N, int npoint, float radius, int nsample, int32_t *idx, int32_t *cnt,
                    mpx_stream_t stream);
 
-/* order[i] = query ids (0..n-1) sorted by DEcreasing number of 32-neighbour tiles
- * ceil(cnt/32) (ties in unspecified order).  scratch: int32[32] device words (zeroed by the
- * call).  Used to give the lockstep waves of mpx_sa_mlp_bf16x3 equal work.                  */
+/* order[i] = query ids (0..n-1) sorted by DEcreasing number of rows they contribute to the packed
+ * SA kernels, 4*ceil(clamp(cnt,1,nsample)/4) (ties in unspecified order).  scratch: int32[128]
+ * device words (zeroed by the call).  Gives the lockstep waves of mpx_sa_mlp_bf16x3 equal work. */
 int mpx_sort_queries(const int32_t *cnt, int64_t n, int nsample, int32_t *order, int32_t *scratch,
                      mpx_stream_t stream);
 
@@ -178,9 +178,10 @@ int mpx_sa_pack_weights(const float *w1, const float *b1, const float *w2, const
  * x_hi*w_hi + x_hi*w_lo + x_lo*w_hi on the bf16 matrix cores with fp32 accumulation (5.3x fewer
  * MFMA cycles; |error| ~ 2^-16 relative per product, ~3e-7 on the policy output).  Same arguments
  * and outputs as mpx_sa_mlp; wpack comes from mpx_sa_pack_bf16x3 (size in BYTES from
- * mpx_sa_pack_bf16x3_size).  Opt-in: the fp32 kernel is the parity default.  `order` (optional,
- * from mpx_sort_queries) assigns queries to workgroups by tile count (the 8 waves of a workgroup
- * run max(tiles) of their queries).                                                         */
+ * mpx_sa_pack_bf16x3_size).  Opt-in: the fp32 kernel is the parity default.  cnt as in mpx_sa_mlp
+ * (distinct neighbours only, rows packed; NULL = all slots).  `order` (optional, from
+ * mpx_sort_queries) is the order in which waves take the queries: the 8 waves of a workgroup walk
+ * the weight stream in lockstep and run max(tiles) of their row counts.                      */
 int mpx_sa_mlp_bf16x3(const float *xyz, int stride, const float *new_xyz, int new_stride,
                       const float *feat, int feat_stride, int C, const int32_t *idx,
                       const int32_t *cnt, const int32_t *order, int B, int N, int npoint,

@@ -355,55 +355,58 @@ MPX_EXPORT int mpx_group_points(const float *xyz, int stride, const float *new_x
   MPX_LAUNCH_CHECK("mpx_group_points");
 }
 
-// ---- queries sorted by neighbourhood tile count (counting sort, <= 8 bins) ---------------------------
+// ---- queries sorted by the number of rows they contribute (counting sort, <= 64 bins) ------------------
+// rows = distinct neighbours rounded up to a multiple of 4 (what the packed SA kernels evaluate);
+// bin = rows/4 - 1.  Decreasing order: the longest queries go first.
+constexpr int SORT_BINS = 64;
+__device__ __forceinline__ int sort_bin(int c, int nsample) {
+  const int cc = c <= 0 ? 1 : (c > nsample ? nsample : c);
+  return ((cc + 3) >> 2) - 1;
+}
+
 __global__ void __launch_bounds__(256)
     tile_hist_kernel(const int32_t *__restrict__ cnt, int64_t n, int nsample, int32_t *__restrict__ hist) {
-  __shared__ int lh[8];
-  if (threadIdx.x < 8) lh[threadIdx.x] = 0;
+  __shared__ int lh[SORT_BINS];
+  if (threadIdx.x < SORT_BINS) lh[threadIdx.x] = 0;
   __syncthreads();
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) {
-    const int c = cnt[i];
-    const int t = c <= 0 ? 1 : ((c >= nsample ? nsample : c) + 31) / 32;
-    atomicAdd(&lh[t - 1], 1);
-  }
+  if (i < n) atomicAdd(&lh[sort_bin(cnt[i], nsample)], 1);
   __syncthreads();
-  if (threadIdx.x < 8 && lh[threadIdx.x]) atomicAdd(hist + threadIdx.x, lh[threadIdx.x]);
+  if (threadIdx.x < SORT_BINS && lh[threadIdx.x]) atomicAdd(hist + threadIdx.x, lh[threadIdx.x]);
 }
 
 __global__ void __launch_bounds__(256)
     tile_scatter_kernel(const int32_t *__restrict__ cnt, int64_t n, int nsample, const int32_t *__restrict__ hist,
                         int32_t *__restrict__ cursor, int32_t *__restrict__ order) {
   // block-local ranking in LDS, then ONE global atomic per (block, bin) to reserve a range
-  __shared__ int lh[8], lbase[8];
-  if (threadIdx.x < 8) lh[threadIdx.x] = 0;
+  __shared__ int lh[SORT_BINS], lbase[SORT_BINS];
+  if (threadIdx.x < SORT_BINS) lh[threadIdx.x] = 0;
   __syncthreads();
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  int t = 0, rank = 0;
+  int bin = 0, rank = 0;
   if (i < n) {
-    const int c = cnt[i];
-    t = c <= 0 ? 1 : ((c >= nsample ? nsample : c) + 31) / 32;
-    rank = atomicAdd(&lh[t - 1], 1);
+    bin = sort_bin(cnt[i], nsample);
+    rank = atomicAdd(&lh[bin], 1);
   }
   __syncthreads();
-  if (threadIdx.x < 8) {
-    int base = 0;  // bins in decreasing tile count
-    for (int b = 7; b > (int)threadIdx.x; --b) base += hist[b];
+  if (threadIdx.x < SORT_BINS) {
+    int base = 0;  // bins in decreasing row count
+    for (int b = SORT_BINS - 1; b > (int)threadIdx.x; --b) base += hist[b];
     lbase[threadIdx.x] = base + (lh[threadIdx.x] ? atomicAdd(cursor + threadIdx.x, lh[threadIdx.x]) : 0);
   }
   __syncthreads();
-  if (i < n) order[lbase[t - 1] + rank] = (int32_t)i;
+  if (i < n) order[lbase[bin] + rank] = (int32_t)i;
 }
 
 MPX_EXPORT int mpx_sort_queries(const int32_t *cnt, int64_t n, int nsample, int32_t *order, int32_t *scratch,
                                 mpx_stream_t stream) {
   MPX_REQUIRE(n >= 0 && n < ((int64_t)1 << 31), "mpx_sort_queries: bad n");
-  MPX_REQUIRE(nsample > 0 && nsample <= 256, "mpx_sort_queries: nsample must be in (0, 256]");
+  MPX_REQUIRE(nsample > 0 && nsample <= 4 * SORT_BINS, "mpx_sort_queries: nsample must be in (0, %d]", 4 * SORT_BINS);
   if (n == 0) return 0;
-  hipError_t e = hipMemsetAsync(scratch, 0, 32 * sizeof(int32_t), mpx_s(stream));
+  hipError_t e = hipMemsetAsync(scratch, 0, 2 * SORT_BINS * sizeof(int32_t), mpx_s(stream));
   MPX_REQUIRE(e == hipSuccess, "mpx_sort_queries: memset failed: %s", hipGetErrorString(e));
   hipLaunchKernelGGL(tile_hist_kernel, dim3(cdiv(n, 256)), dim3(256), 0, mpx_s(stream), cnt, n, nsample, scratch);
   hipLaunchKernelGGL(tile_scatter_kernel, dim3(cdiv(n, 256)), dim3(256), 0, mpx_s(stream), cnt, n, nsample, scratch,
-                     scratch + 16, order);
+                     scratch + SORT_BINS, order);
   MPX_LAUNCH_CHECK("mpx_sort_queries");
 }

@@ -214,15 +214,19 @@ struct Stream {
   }
 };
 
-// raw (fp32) layer-1 inputs of one neighbour, as fetched from memory
+// raw (fp32) layer-1 inputs of one packed row: neighbour point, its query's centre, its feature half-row
 template <int CF>
 struct RawIn {
-  float px, py, pz;
+  float px, py, pz, cx, cy, cz;
   float f[CF == 1 ? 1 : CF / 2];
-  __device__ __forceinline__ void load(const float *__restrict__ p, const float *__restrict__ fr, int half) {
+  __device__ __forceinline__ void load(const float *__restrict__ p, const float *__restrict__ c,
+                                       const float *__restrict__ fr, int half) {
     px = p[0];
     py = p[1];
     pz = p[2];
+    cx = c[0];
+    cy = c[1];
+    cz = c[2];
     if (CF == 1) {
       f[0] = fr[0];
     } else {
@@ -252,7 +256,11 @@ __device__ __forceinline__ f32x16 bias_tile_lds(const float *bias_lds, int ot, i
   return v;
 }
 
-template <int CF, int C1, int C2, int C3>
+// Q queries per wave; their DISTINCT neighbours (count from the ball query; padding repeats the first
+// neighbour, and max-pooling is idempotent) are rounded up to multiples of 4 rows and packed back to
+// back into 32-row tiles.  `order` (optional) lists the queries sorted by row count so that the 8
+// lockstep waves of a workgroup carry (nearly) the same number of tiles; the workgroup runs max(tiles).
+template <int CF, int C1, int C2, int C3, int Q>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
     sa_mlp_bf16_kernel(const float *__restrict__ xyz, int stride, const float *__restrict__ new_xyz, int new_stride,
                        const float *__restrict__ feat, int feat_stride, const int32_t *__restrict__ idx,
@@ -262,29 +270,39 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
   using Cfg = BCfg<CF, C1, C2, C3>;
   __shared__ __attribute__((aligned(16))) unsigned char ring[2 * CHUNK_BYTES + 4 * (C1 + C2) + 64];
   float *bias_lds = reinterpret_cast<float *>(ring + 2 * CHUNK_BYTES);  // [b1 | b2]
+  int *tiles_lds = reinterpret_cast<int *>(ring + 2 * CHUNK_BYTES + 4 * (C1 + C2));
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int half = lane >> 5, col = lane & 31;
-  int64_t qid = (int64_t)blockIdx.x * WAVES + wave;
-  const bool live = qid < n_query;  // wave-uniform; dead waves still walk the stream (barriers)
-  if (!live) qid = n_query - 1;
-  // `order` (optional) lists the queries sorted by their number of neighbourhood tiles, so that the 8
-  // lockstep waves of a workgroup have (nearly) the same amount of work
-  if (order) qid = __builtin_amdgcn_readfirstlane(order[qid]);
-  const int64_t b = qid / npoint;
+  const int64_t q0 = ((int64_t)blockIdx.x * WAVES + wave) * Q;
+  const bool live = q0 < n_query;  // wave-uniform; dead waves still walk the stream (barriers), store nothing
+  const int nq = live ? (int)min((int64_t)Q, n_query - q0) : 0;
 
-  // Tiles that hold nothing but ball-query padding (repeats of the first neighbour) are skipped: the
-  // MLP is per point and max-pooling is idempotent, so the result is bit-identical.  The workgroup
-  // walks the weight stream in lockstep, so it runs max(tiles) over its waves.
-  int *tiles_lds = reinterpret_cast<int *>(ring + 2 * CHUNK_BYTES + 4 * (C1 + C2));
-  {
-    int rows = nsample;
-    if (cnt) {
-      const int c = __builtin_amdgcn_readfirstlane(cnt[qid]);
-      rows = c <= 0 ? 32 : (c >= nsample ? nsample : ((c + 31) & ~31));
-    }
-    if (lane == 0) tiles_lds[wave] = rows;
+  // lane i < nq: global id, distinct-neighbour count, row count (multiple of 4) and row offset of query i
+  int my_q = 0, my_cnt = 1, my_rows = 0;
+  if (lane < nq) {
+    my_q = order ? order[q0 + lane] : (int)(q0 + lane);
+    const int c = cnt ? cnt[my_q] : nsample;
+    my_cnt = c <= 0 ? 1 : (c > nsample ? nsample : c);  // no hit: the zero-initialised row = point 0
+    my_rows = (my_cnt + 3) & ~3;
   }
+  int pre = my_rows;
+#pragma unroll
+  for (int o = 1; o < Q; o <<= 1) {
+    const int t = __shfl_up(pre, o);
+    if (lane >= o) pre += t;
+  }
+  const int total = __builtin_amdgcn_readlane(pre, Q - 1);
+  pre -= my_rows;
+  int s_pre[Q], s_cnt[Q], s_q[Q];
+#pragma unroll
+  for (int i = 0; i < Q; ++i) {
+    s_pre[i] = __builtin_amdgcn_readlane(pre, i);
+    s_cnt[i] = __builtin_amdgcn_readlane(my_cnt, i);
+    s_q[i] = __builtin_amdgcn_readlane(my_q, i);
+  }
+  if (lane == 0) tiles_lds[wave] = total <= 32 ? 32 : ((total + 31) & ~31);
+
   for (int i = threadIdx.x; i < C1 + C2; i += 64 * WAVES)
     bias_lds[i] = reinterpret_cast<const float *>(wpack + Cfg::B1_OFF)[i];
   Stream ws;
@@ -295,38 +313,70 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
   ws.lds_lane = lane * 16;
   ws.next_cc = 0;
   ws.nch = Cfg::NCH;
-  ws.start();  // (its barrier also publishes the biases and the per-wave tile counts)
+  ws.start();  // (its barrier also publishes the biases and the per-wave row counts)
   int n_rows = 0;
 #pragma unroll
   for (int w = 0; w < WAVES; ++w) n_rows = max(n_rows, tiles_lds[w]);
   const float *bias3 = reinterpret_cast<const float *>(wpack + Cfg::B3_OFF);
 
-  const float *ctr = new_xyz + qid * new_stride;
-  const float cx = ctr[0], cy = ctr[1], cz = ctr[2];
-  const int32_t *nbr = idx + qid * nsample;
-  const float *cloud = xyz + b * N * (int64_t)stride;
-  const float *fbase = feat + b * N * (int64_t)feat_stride;
-
-  float omax[Cfg::OT3];
+  // row -> (global query id, neighbour index); rows past this wave's end repeat its last query's slot 0
+  auto map_row = [&](int p, int &qg, int &nb_off) {
+    int qpre = 0, qcnt = s_cnt[0];
+    qg = s_q[0];
 #pragma unroll
-  for (int ot = 0; ot < Cfg::OT3; ++ot) omax[ot] = -__builtin_inff();
+    for (int i = 1; i < Q; ++i) {
+      const bool ge = i < nq && p >= s_pre[i];
+      qg = ge ? s_q[i] : qg;
+      qpre = ge ? s_pre[i] : qpre;
+      qcnt = ge ? s_cnt[i] : qcnt;
+    }
+    const int slot = p - qpre;
+    nb_off = slot < qcnt ? slot : 0;
+  };
+  auto gather = [&](RawIn<CF> &raw, int qg, int k) {
+    const int64_t b = qg / npoint;
+    raw.load(xyz + (b * N + k) * (int64_t)stride, new_xyz + (int64_t)qg * new_stride,
+             feat + (b * N + k) * (int64_t)feat_stride, half);
+  };
 
-  // gather pipeline: neighbour index two tiles ahead, neighbour data one tile ahead
+  float run[Cfg::OT3];  // running max of the query being merged, per output tile (this lane's half of the rows)
+  int cur[Cfg::OT3];    // ... and which query that is (wave-uniform)
+#pragma unroll
+  for (int ot = 0; ot < Cfg::OT3; ++ot) {
+    run[ot] = -__builtin_inff();
+    cur[ot] = s_q[0];
+  }
+  auto flush = [&](int ot, int qg) {
+    float v = run[ot];
+    v = fmaxf(v, __shfl_xor(v, 32));
+    const int ch = ot * 32 + col;
+    v = fmaxf(v + bias3[ch], 0.0f);
+    if (live && half == 0) out[(int64_t)qg * out_stride + ch] = v;
+    run[ot] = -__builtin_inff();
+  };
+
+  // gather pipeline: neighbour index one tile ahead (issued at tile start), neighbour data issued in layer 3
   RawIn<CF> raw;
-  int k_next = n_rows > 32 ? nbr[32 + col] : 0;
+  int q_cur, q_next = 0, k_next = 0;
   {
-    const int k0 = nbr[col];
-    raw.load(cloud + (int64_t)k0 * stride, fbase + (int64_t)k0 * feat_stride, half);
+    int off;
+    map_row(col, q_cur, off);
+    const int k0 = idx[(int64_t)q_cur * nsample + off];
+    gather(raw, q_cur, k0);
+    if (n_rows > 32) {
+      map_row(32 + col, q_next, off);
+      k_next = idx[(int64_t)q_next * nsample + off];
+    }
   }
 
   for (int rt = 0; rt < n_rows; rt += 32) {
-    // ---- layer-1 operands from the prefetched neighbour, split hi/lo -------------------------------------------
+    // ---- layer-1 operands from the prefetched row, split hi/lo -------------------------------------------
     bf16x8 xh[Cfg::KS0], xl[Cfg::KS0];
     {
       float v[8 * Cfg::KS0];
 #pragma unroll
       for (int i = 0; i < 8 * Cfg::KS0; ++i) v[i] = 0.0f;
-      const float dx = raw.px - cx, dy = raw.py - cy, dz = raw.pz - cz;
+      const float dx = raw.px - raw.cx, dy = raw.py - raw.cy, dz = raw.pz - raw.cz;
       v[0] = half ? dy : dx;
       if (CF == 1) {
         v[1] = half ? raw.f[0] : dz;
@@ -343,12 +393,18 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         split8(t8, xh[s], xl[s]);
       }
     }
-    // The next tile's gather is issued inside the chunk walk below, at the first chunk of layer 3
+    const int q_tile = q_cur;  // query of this lane's row in the tile being computed
+    const int q_gather = q_next, k_gather = k_next;
+    q_cur = q_next;
+    if (rt + 64 < n_rows) {  // index of the row after next: issued now, consumed a tile later
+      int off;
+      map_row(rt + 64 + col, q_next, off);
+      k_next = idx[(int64_t)q_next * nsample + off];
+    }
+    // The next tile's row data is fetched inside the chunk walk below, at the first chunk of layer 3
     // (register pressure peaks in layer 2; layer 3 is long enough to cover the latency).
     constexpr int GATHER_CHUNK = Cfg::O3 / G;
 
-    // The neighbourhood tile is one unrolled walk over the STP step-tiles of the weight stream, G at a
-    // time; `st` is a compile-time constant in every use below.
     f32x16 a1[Cfg::OT1], a2[Cfg::OT2];
     bf16x8 h1[Cfg::OT1][2], l1[Cfg::OT1][2], h2[Cfg::OT2][2], l2[Cfg::OT2][2];
     f32x16 a3[Cfg::OPC][2];
@@ -357,10 +413,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 
 #pragma unroll
     for (int c = 0; c < Cfg::NCH; ++c) {
-      if (c == GATHER_CHUNK && rt + 32 < n_rows) {
-        raw.load(cloud + (int64_t)k_next * stride, fbase + (int64_t)k_next * feat_stride, half);
-        if (rt + 64 < n_rows) k_next = nbr[rt + 64 + col];
-      }
+      if (c == GATHER_CHUNK && rt + 32 < n_rows) gather(raw, q_gather, k_gather);
       // ---- operands that become available / are first needed in this chunk ---------------------------------
       if (c * G == Cfg::O2) {
 #pragma unroll
@@ -414,7 +467,10 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         }
       }
       ws.advance();
-      // ---- end of an output tile of layer 3: pool its 32 points -------------------------------------------
+      // ---- end of an output tile of layer 3: pool its rows per query -----------------------------------------
+      // a lane holds, for its channel, four groups of 4 consecutive rows (group g = 2j + half = rows 4g..4g+3);
+      // groups never straddle queries, so: max inside each group, then merge the 8 groups in row order and
+      // flush the running maximum whenever the (wave-uniform) query changes.
 #pragma unroll
       for (int j = 0; j < G; ++j) {
         const int st = c * G + j;
@@ -423,26 +479,26 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         if (q % Cfg::KS2 == Cfg::KS2 - 1) {
           const int ot = q / Cfg::KS2;
           const f32x16 &u0 = a3[ot % Cfg::OPC][0], &u1 = a3[ot % Cfg::OPC][1];
-          float m = u0[0] + u1[0];
+          float gm[4];
 #pragma unroll
-          for (int r = 1; r < 16; ++r) m = fmaxf(m, u0[r] + u1[r]);
-          omax[ot] = fmaxf(omax[ot], m);
+          for (int jj = 0; jj < 4; ++jj)
+            gm[jj] = fmaxf(fmaxf(u0[4 * jj] + u1[4 * jj], u0[4 * jj + 1] + u1[4 * jj + 1]),
+                           fmaxf(u0[4 * jj + 2] + u1[4 * jj + 2], u0[4 * jj + 3] + u1[4 * jj + 3]));
+#pragma unroll
+          for (int g = 0; g < 8; ++g) {
+            const int gq = __builtin_amdgcn_readlane(q_tile, 4 * g);
+            if (gq != cur[ot]) {
+              flush(ot, cur[ot]);
+              cur[ot] = gq;
+            }
+            if ((g & 1) == half) run[ot] = fmaxf(run[ot], gm[g >> 1]);
+          }
         }
       }
     }
   }
-
-  if (live) {
-    float *orow = out + qid * out_stride;
 #pragma unroll
-    for (int ot = 0; ot < Cfg::OT3; ++ot) {
-      float v = omax[ot];
-      v = fmaxf(v, __shfl_xor(v, 32));
-      const int ch = ot * 32 + col;
-      v = fmaxf(v + bias3[ch], 0.0f);
-      if (half == 0) orow[ch] = v;
-    }
-  }
+  for (int ot = 0; ot < Cfg::OT3; ++ot) flush(ot, cur[ot]);
 }
 
 // ---- host entry points --------------------------------------------------------------------------------------------
@@ -460,9 +516,11 @@ static int launch_sa_bf16(const float *xyz, int stride, const float *new_xyz, in
                           int npoint, int nsample,
                           const void *wpack, float *out, int out_stride, mpx_stream_t stream) {
   const int64_t nq = (int64_t)B * npoint;
-  MPX_REQUIRE(nq / WAVES + 1 < ((int64_t)1 << 31), "mpx_sa_mlp_bf16x3: too many query points");
-  hipLaunchKernelGGL((sa_mlp_bf16_kernel<CF, C1, C2, C3>), dim3((unsigned)((nq + WAVES - 1) / WAVES)), dim3(64 * WAVES),
-                     0, mpx_s(stream), xyz, stride, new_xyz, new_stride, feat, feat_stride, idx, cnt, order, nq, N, npoint, nsample,
+  MPX_REQUIRE(nq < ((int64_t)1 << 31), "mpx_sa_mlp_bf16x3: too many query points");
+  constexpr int Q = CF == 1 ? 16 : 4;  // queries per wave
+  const int64_t per_block = (int64_t)WAVES * Q;
+  hipLaunchKernelGGL((sa_mlp_bf16_kernel<CF, C1, C2, C3, Q>), dim3((unsigned)((nq + per_block - 1) / per_block)),
+                     dim3(64 * WAVES), 0, mpx_s(stream), xyz, stride, new_xyz, new_stride, feat, feat_stride, idx, cnt, order, nq, N, npoint, nsample,
                      static_cast<const unsigned char *>(wpack), out, out_stride);
   MPX_LAUNCH_CHECK("mpx_sa_mlp_bf16x3");
 }

@@ -145,7 +145,7 @@ def launch_sa(precision: str, xyz_ptr: int, stride: int, new_xyz_ptr: int, new_s
     order = None
     if cnt is not None:
         order = torch.empty(B * npoint, dtype=torch.int32, device=idx.device)
-        scratch = torch.empty(32, dtype=torch.int32, device=idx.device)
+        scratch = torch.empty(128, dtype=torch.int32, device=idx.device)
         _lib.call("mpx_sort_queries", _lib.ptr(cnt), B * npoint, nsample, _lib.ptr(order), _lib.ptr(scratch))
     _lib.call("mpx_sa_mlp_bf16x3", xyz_ptr, stride, new_xyz_ptr, new_stride, feat_ptr, feat_stride, C, _lib.ptr(idx),
               _lib.ptr(cnt), _lib.ptr(order), B, N, npoint, nsample, _lib.ptr(wpack), c1, c2, c3, out_ptr, out_stride)

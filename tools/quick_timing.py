@@ -49,7 +49,7 @@ def main():
     cnt2 = torch.empty((B, 128), dtype=torch.int32, device=dev)
     ord1 = torch.empty(B * 512, dtype=torch.int32, device=dev)
     ord2 = torch.empty(B * 128, dtype=torch.int32, device=dev)
-    scr = torch.empty(32, dtype=torch.int32, device=dev)
+    scr = torch.empty(128, dtype=torch.int32, device=dev)
     f1 = torch.empty((B, 512, 64), device=dev)
     w1 = sa1._packed.get(sa1.convs(), 1)
     w2 = sa2._packed.get(sa2.convs(), 64)
