@@ -281,8 +281,10 @@ __global__ void __launch_bounds__(256, 2)
 // layer a lane holds, per output channel, four groups of 4 consecutive rows; every group belongs to one
 // query, so pooling is a max over each group followed by a merge of the groups in row order that flushes
 // the running maximum to the output row whenever the (wave-uniform) query changes.
+// One wave per workgroup: waves carry different numbers of tiles, and a multi-wave workgroup would hold
+// its SIMD slots until its slowest wave retires.
 template <int CF, int C1, int C2, int C3, int Q>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CF == 1 ? 4 : 2, CF == 1 ? 4 : 2)))
     sa_mlp_packed_kernel(const float *__restrict__ xyz, int stride, const float *__restrict__ new_xyz,
                          int new_stride, const float *__restrict__ feat, int feat_stride,
                          const int32_t *__restrict__ idx, const int32_t *__restrict__ cnt, int64_t n_query, int N,
@@ -292,8 +294,7 @@ __global__ void __launch_bounds__(256, 2)
   static_assert(Q >= 1 && Q <= 32, "queries per wave");
   const int lane = threadIdx.x & 63;
   const int half = lane >> 5, col = lane & 31;
-  const int64_t q0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * Q;
-  if (q0 >= n_query) return;  // wave-uniform
+  const int64_t q0 = (int64_t)blockIdx.x * Q;
   const int nq = (int)min((int64_t)Q, n_query - q0);
 
   // lane i < nq: distinct-neighbour count of query q0+i, its row count (multiple of 4) and row offset
@@ -323,31 +324,26 @@ __global__ void __launch_bounds__(256, 2)
   const int wvoff = lane * 16;
   const float *bias3 = wpack + Cfg::B3_OFF;
 
-  float run[Cfg::OT3];  // running max of the query being merged (this lane's half of its rows)
+  const int qbase = (int)q0;  // query ids fit 31 bits (checked by the launcher)
+  float run[Cfg::OT3];  // running max of the query being merged, per output tile (this lane's half of the rows)
+  int cur[Cfg::OT3];    // ... and which of this wave's queries that is (wave-uniform)
 #pragma unroll
-  for (int ot = 0; ot < Cfg::OT3; ++ot) run[ot] = -__builtin_inff();
-  int cur = 0;  // query (0..nq-1) being merged; wave-uniform
-
-  auto flush = [&](int qi) {
-    float *orow = out + (q0 + qi) * out_stride;
-#pragma unroll
-    for (int ot = 0; ot < Cfg::OT3; ++ot) {
-      float v = run[ot];
-      v = fmaxf(v, __shfl_xor(v, 32));
-      const int ch = ot * 32 + col;
-      v = fmaxf(v + bias3[ch], 0.0f);
-      if (half == 0) orow[ch] = v;
-      run[ot] = -__builtin_inff();
-    }
+  for (int ot = 0; ot < Cfg::OT3; ++ot) {
+    run[ot] = -__builtin_inff();
+    cur[ot] = 0;
+  }
+  auto flush = [&](int ot, int qi) __attribute__((always_inline)) {
+    float v = run[ot];
+    v = fmaxf(v, __shfl_xor(v, 32));
+    const int ch = ot * 32 + col;
+    v = fmaxf(v + bias3[ch], 0.0f);
+    if (half == 0) out[(int64_t)(qbase + qi) * out_stride + ch] = v;
+    run[ot] = -__builtin_inff();
   };
-
-  for (int rt = 0; rt < total; rt += 32) {
-    int w1o = (int)Cfg::W1_OFF * 4, w2o = (int)Cfg::W2_OFF * 4, w3o = (int)Cfg::W3_OFF * 4;
-    int b1o = (int)Cfg::B1_OFF * 4, b2o = (int)Cfg::B2_OFF * 4;
-    asm volatile("" : "+s"(w1o), "+s"(w2o), "+s"(w3o), "+s"(b1o), "+s"(b2o));
-    // ---- which (query, slot) is this lane's row? rows past the end repeat the last query's first slot --
-    const int p = rt + col;
-    int qi = 0, qpre = 0, qcnt = s_cnt[0];
+  // row -> (query of this wave, neighbour slot); rows past the end repeat the last query's first slot
+  auto map_row = [&](int p, int &qi, int &off) __attribute__((always_inline)) {
+    int qpre = 0, qcnt = s_cnt[0];
+    qi = 0;
 #pragma unroll
     for (int i = 1; i < Q; ++i) {
       const bool ge = i < nq && p >= s_pre[i];
@@ -356,31 +352,69 @@ __global__ void __launch_bounds__(256, 2)
       qcnt = ge ? s_cnt[i] : qcnt;
     }
     const int slot = p - qpre;
+    off = slot < qcnt ? slot : 0;
+  };
+  // raw layer-1 inputs of one row: (x - centre) and this lane-half's feature chunk (plain locals: an
+  // array inside a struct that is passed around by reference is not promoted to registers)
+  constexpr int NF = CF == 1 ? 1 : CF / 2;
+  float raw_dx, raw_dy, raw_dz, raw_f[NF];
+  auto gather = [&](int qi, int k) __attribute__((always_inline)) {
     const int64_t qg = q0 + qi;
-    const int k = idx[qg * nsample + (slot < qcnt ? slot : 0)];
     const int64_t b = qg / npoint;
     const float *ctr = new_xyz + qg * new_stride;
     const float *pp = xyz + (b * N + k) * (int64_t)stride;
     const float *f = feat + (b * N + k) * (int64_t)feat_stride;
+    raw_dx = pp[0] - ctr[0];
+    raw_dy = pp[1] - ctr[1];
+    raw_dz = pp[2] - ctr[2];
+    if (CF == 1) {
+      raw_f[0] = f[0];
+    } else {
+      const float4 *fr = reinterpret_cast<const float4 *>(f + half * (CF / 2));
+#pragma unroll
+      for (int i = 0; i < CF / 8; ++i) {
+        const float4 v = fr[i];
+        raw_f[4 * i + 0] = v.x;
+        raw_f[4 * i + 1] = v.y;
+        raw_f[4 * i + 2] = v.z;
+        raw_f[4 * i + 3] = v.w;
+      }
+    }
+  };
+
+  // gather pipeline: the neighbour index of the next tile is fetched at tile start, its data during layer 3
+  int q_cur, q_next = 0, k_next = 0;
+  {
+    int off;
+    map_row(col, q_cur, off);
+    gather(q_cur, idx[(q0 + q_cur) * nsample + off]);
+    if (total > 32) {
+      map_row(32 + col, q_next, off);
+      k_next = idx[(q0 + q_next) * nsample + off];
+    }
+  }
+
+  for (int rt = 0; rt < total; rt += 32) {
+    int w1o = (int)Cfg::W1_OFF * 4, w2o = (int)Cfg::W2_OFF * 4, w3o = (int)Cfg::W3_OFF * 4;
+    int b1o = (int)Cfg::B1_OFF * 4, b2o = (int)Cfg::B2_OFF * 4;
+    asm volatile("" : "+s"(w1o), "+s"(w2o), "+s"(w3o), "+s"(b1o), "+s"(b2o));
 
     float x0[Cfg::KS0];
-    {
-      const float dx = pp[0] - ctr[0], dy = pp[1] - ctr[1], dz = pp[2] - ctr[2];
-      x0[0] = half ? dy : dx;
-      if (CF == 1) {
-        x0[1] = half ? f[0] : dz;
-      } else {
-        x0[1] = half ? 0.0f : dz;
-        const float4 *fr = reinterpret_cast<const float4 *>(f + half * (CF / 2));
+    x0[0] = half ? raw_dy : raw_dx;
+    if (CF == 1) {
+      x0[1] = half ? raw_f[0] : raw_dz;
+    } else {
+      x0[1] = half ? 0.0f : raw_dz;
 #pragma unroll
-        for (int i = 0; i < CF / 8; ++i) {
-          const float4 v = fr[i];
-          x0[2 + 4 * i + 0] = v.x;
-          x0[2 + 4 * i + 1] = v.y;
-          x0[2 + 4 * i + 2] = v.z;
-          x0[2 + 4 * i + 3] = v.w;
-        }
-      }
+      for (int i = 0; i < CF / 2; ++i) x0[2 + i] = raw_f[i];
+    }
+    const int q_tile = q_cur;  // which query this lane's row of the current tile belongs to
+    const int q_gather = q_next, k_gather = k_next;
+    q_cur = q_next;
+    if (rt + 64 < total) {
+      int off;
+      map_row(rt + 64 + col, q_next, off);
+      k_next = idx[(q0 + q_next) * nsample + off];
     }
 
     f32x16 a1[Cfg::OT1];
@@ -413,8 +447,14 @@ __global__ void __launch_bounds__(256, 2)
 #pragma unroll
       for (int r = 0; r < 16; ++r) a2[ot][r] = fmaxf(a2[ot][r], 0.0f);
 
-    // ---- layer 3 (roles flipped) and the per-group maxima: gm[ot][j] = max over rows 8j+4*half .. +3 -------
-    float gm[Cfg::OT3][4];
+    // the next tile's rows are fetched now: layer 3 below is long enough to cover the latency and
+    // layer 2's accumulators (the register peak) are gone
+    if (rt + 32 < total) gather(q_gather, k_gather);
+
+    // ---- layer 3 (roles flipped), pooled per query as each output tile completes ------------------------------
+    // a lane holds, for its channel, four groups of 4 consecutive rows (group g = 2j + half = rows 4g..4g+3);
+    // groups never straddle queries, so: max inside each group, then merge the 8 groups in row order and
+    // flush the running maximum whenever the (wave-uniform) query changes.
     {
       f32x16 a3;
       constexpr int GPT = Cfg::KS2 / 4;
@@ -427,29 +467,25 @@ __global__ void __launch_bounds__(256, 2)
           a3 = mfma32(a2[t >> 4][t & 15], comp(w, u), a3);
         }
         if (gg == GPT - 1) {
+          float gm[4];
 #pragma unroll
           for (int j = 0; j < 4; ++j)
-            gm[ot][j] = fmaxf(fmaxf(a3[4 * j], a3[4 * j + 1]), fmaxf(a3[4 * j + 2], a3[4 * j + 3]));
+            gm[j] = fmaxf(fmaxf(a3[4 * j], a3[4 * j + 1]), fmaxf(a3[4 * j + 2], a3[4 * j + 3]));
+#pragma unroll
+          for (int grp = 0; grp < 8; ++grp) {
+            const int gq = __builtin_amdgcn_readlane(q_tile, 4 * grp);
+            if (gq != cur[ot]) {
+              flush(ot, cur[ot]);
+              cur[ot] = gq;
+            }
+            if ((grp & 1) == half) run[ot] = fmaxf(run[ot], gm[grp >> 1]);
+          }
         }
       });
     }
-    // ---- merge the tile's 8 row groups in row order; group g = 2j + half holds rows rt + 4g .. +3 --------
-#pragma unroll
-    for (int g = 0; g < 8; ++g) {
-      if (rt + 4 * g < total) {  // wave-uniform
-        const int gq = __builtin_amdgcn_readlane(qi, 4 * g);  // the lane of the group's first row knows its query
-        if (gq != cur) {
-          flush(cur);
-          cur = gq;
-        }
-        if ((g & 1) == half) {
-#pragma unroll
-          for (int ot = 0; ot < Cfg::OT3; ++ot) run[ot] = fmaxf(run[ot], gm[ot][g >> 1]);
-        }
-      }
-    }
   }
-  flush(cur);
+#pragma unroll
+  for (int ot = 0; ot < Cfg::OT3; ++ot) flush(ot, cur[ot]);
 }
 
 // ---- host entry points -----------------------------------------------------------------------------------
@@ -462,7 +498,7 @@ static int launch_sa(const float *xyz, int stride, const float *new_xyz, int new
   if (cnt) {
     constexpr int Q = CF == 1 ? 16 : 4;  // queries per wave: ~6 tiles of work on typical scenes
     const int64_t nw = (nq + Q - 1) / Q;
-    hipLaunchKernelGGL((sa_mlp_packed_kernel<CF, C1, C2, C3, Q>), dim3((unsigned)((nw + 3) / 4)), dim3(256), 0,
+    hipLaunchKernelGGL((sa_mlp_packed_kernel<CF, C1, C2, C3, Q>), dim3((unsigned)nw), dim3(64), 0,
                        mpx_s(stream), xyz, stride, new_xyz, new_stride, feat, feat_stride, idx, cnt, nq, N, npoint,
                        nsample, wpack, out, out_stride);
   } else {
