@@ -92,7 +92,8 @@ def main():
     assert ws == args.gpus or ws == 1, f"WORLD_SIZE={ws} but --gpus {args.gpus}"
     n_gpus = ws
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
-    dev = torch.device("cuda", local)
+    # MPX_DEVICE_OVERRIDE: development only (several ranks sharing one GPU to exercise the N > 1 path)
+    dev = torch.device("cuda", int(os.environ.get("MPX_DEVICE_OVERRIDE", local)))
     torch.cuda.set_device(dev)
     _lib.load()
 

@@ -21,10 +21,13 @@ def world() -> Tuple[int, int, int]:
 
 
 def init(backend: Optional[str] = None) -> Tuple[int, int, int]:
+    """Join the job torchrun started (no-op for a single process).  Backend: RCCL ("nccl") when GPUs
+    are present, gloo otherwise; ``MPX_DIST_BACKEND`` overrides (tests run 2 ranks on one GPU with gloo)."""
     rank, ws, local = world()
     if ws > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
+        backend = backend or os.environ.get("MPX_DIST_BACKEND")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         kwargs = {}
@@ -56,10 +59,15 @@ def barrier() -> None:
         dist.barrier()
 
 
+def _comm_device(device=None):
+    """Collectives run on the GPU with RCCL and on the host with gloo."""
+    return device if dist.get_backend() == "nccl" else torch.device("cpu")
+
+
 def max_over_ranks(value: float, device=None) -> float:
     if not dist.is_initialized():
         return value
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    t = torch.tensor([value], dtype=torch.float64, device=_comm_device(device))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -69,6 +77,7 @@ def gather_to_rank0(t: torch.Tensor) -> Optional[torch.Tensor]:
     if not dist.is_initialized():
         return t
     rank, ws = dist.get_rank(), dist.get_world_size()
+    t = t.contiguous().to(_comm_device(t.device))
     bufs = [torch.empty_like(t) for _ in range(ws)] if rank == 0 else None
     dist.gather(t, bufs, dst=0)
     return torch.cat(bufs, dim=0) if rank == 0 else None
