@@ -38,8 +38,9 @@ __global__ void __launch_bounds__(256)
   constexpr int LDT = BK + 4;       // padded row: conflict-free 16-byte fragment reads
   constexpr int HK = BK / 2;        // k-values per lane-half per slab
   constexpr int NLD = BK / 8;       // float4 staged per thread per matrix per slab
-  __shared__ __attribute__((aligned(16))) float As[2][BM * LDT];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDT];
+  __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LDT];  // [As0 | As1 | Bs0 | Bs1]
+  float(*As)[BM * LDT] = reinterpret_cast<float(*)[BM * LDT]>(smem);
+  float(*Bs)[BN * LDT] = reinterpret_cast<float(*)[BN * LDT]>(smem + 2 * BM * LDT);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
   const int wm = wave >> 1, wn = wave & 1;
@@ -123,14 +124,46 @@ __global__ void __launch_bounds__(256)
         }
       m = fmaxf(m, __shfl_xor(m, 32));
       if (half == 0) atomicMax(reinterpret_cast<int *>(y + (size_t)blockIdx.y * ldy + col), __float_as_int(m));
-    } else {
+    }
+  }
+  if (!POOL) {
+    // Store epilogue staged through LDS (the operand buffers are free after the last barrier): 64 scalar
+    // 4-byte stores per lane are store-issue bound; written as rows of float4 it is 16 wide stores.
+    // Per wave and per 32-row half: acc -> lds[32][64+4] (ds_write_b32), back as float4 along the row.
+    constexpr int LDC = 64 + 4;
+    float *stage = smem + wave * (32 * LDC);  // 4 waves x 8.5 KB inside the 40 KB of operand buffers
+    static_assert(4 * 32 * LDC <= 2 * (BM + BN) * LDT, "staging must fit the operand buffers");
+    const bool vec_ok = (ldy % 4 == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          if (row < M) y[(size_t)row * ldy + col] = act_apply(acc[i][j][r] + bv, act);
+      for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn * 64 + j * 32 + l31;
+        const float bv = (bias && col < N) ? bias[col] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          stage[((r & 3) + 8 * (r >> 2) + 4 * half) * LDC + j * 32 + l31] = act_apply(acc[i][j][r] + bv, act);
+      }
+      // (a wave only touches its own staging area: no barrier needed, LDS ops of a wave are ordered)
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const int e = t * 64 + lane;      // 512 float4 = 32 rows x 16
+        const int rr = e >> 4, c4 = (e & 15) * 4;
+        const int row = m0 + wm * 64 + i * 32 + rr;
+        const int col = n0 + wn * 64 + c4;
+        const float4 v = *reinterpret_cast<const float4 *>(&stage[rr * LDC + c4]);
+        if (row < M) {
+          float *dst = y + (size_t)row * ldy + col;
+          if (vec_ok && col + 3 < N) {
+            *reinterpret_cast<float4 *>(dst) = v;
+          } else {
+            if (col + 0 < N) dst[0] = v.x;
+            if (col + 1 < N) dst[1] = v.y;
+            if (col + 2 < N) dst[2] = v.z;
+            if (col + 3 < N) dst[3] = v.w;
+          }
         }
+      }
     }
   }
 }
