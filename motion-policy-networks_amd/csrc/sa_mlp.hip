@@ -289,12 +289,20 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CF == 1
                          int new_stride, const float *__restrict__ feat, int feat_stride,
                          const int32_t *__restrict__ idx, const int32_t *__restrict__ cnt, int64_t n_query, int N,
                          int npoint, int nsample, const float *__restrict__ wpack, float *__restrict__ out,
-                         int out_stride) {
+                         int out_stride, int bpe) {
   using Cfg = SaCfg<CF, C1, C2, C3>;
   static_assert(Q >= 1 && Q <= 32, "queries per wave");
   const int lane = threadIdx.x & 63;
   const int half = lane >> 5, col = lane & 31;
-  const int64_t q0 = (int64_t)blockIdx.x * Q;
+  // XCD-aware order: hardware dispatches workgroup h to XCD h % 8 (observed, used for speed only).  All
+  // workgroups of one environment are given to one XCD so its cloud / feature rows are fetched into ONE L2
+  // instead of eight (bpe = workgroups per environment; falls back to the natural order for ragged grids).
+  int64_t wg = blockIdx.x;
+  if (bpe > 0) {
+    const int64_t xcd = wg & 7, slot = wg >> 3;
+    wg = ((slot / bpe) * 8 + xcd) * bpe + slot % bpe;
+  }
+  const int64_t q0 = wg * Q;
   const int nq = (int)min((int64_t)Q, n_query - q0);
 
   // lane i < nq: distinct-neighbour count of query q0+i, its row count (multiple of 4) and row offset
@@ -498,9 +506,11 @@ static int launch_sa(const float *xyz, int stride, const float *new_xyz, int new
   if (cnt) {
     constexpr int Q = CF == 1 ? 16 : 4;  // queries per wave: ~6 tiles of work on typical scenes
     const int64_t nw = (nq + Q - 1) / Q;
+    // whole environments per XCD when the grid is regular (npoint % Q == 0, B % 8 == 0)
+    const int bpe = (npoint % Q == 0 && B % 8 == 0) ? npoint / Q : 0;
     hipLaunchKernelGGL((sa_mlp_packed_kernel<CF, C1, C2, C3, Q>), dim3((unsigned)nw), dim3(64), 0,
                        mpx_s(stream), xyz, stride, new_xyz, new_stride, feat, feat_stride, idx, cnt, nq, N, npoint,
-                       nsample, wpack, out, out_stride);
+                       nsample, wpack, out, out_stride, bpe);
   } else {
     hipLaunchKernelGGL((sa_mlp_kernel<CF, C1, C2, C3>), dim3((unsigned)((nq + 3) / 4)), dim3(256), 0,
                        mpx_s(stream), xyz, stride, new_xyz, new_stride, feat, feat_stride, idx, nq, N, npoint,
