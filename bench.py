@@ -79,6 +79,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--envs", type=int, default=8192, help="environments per GPU")
     ap.add_argument("--fast-steps", type=int, default=3, help="steps of the secondary bf16x3 measurement (0 = skip)")
+    ap.add_argument("--extra", type=int, default=1, help="also time BASELINE configs 2 and 4 (collision validation only)")
     ap.add_argument("--cpu-envs", type=int, default=8, help="env-steps in the CPU baseline sample (0 = skip)")
     ap.add_argument("--scene-pool", type=int, default=1024, help="distinct host-generated primitive sets tiled over the batch (clouds are drawn per env on the device)")
     args = ap.parse_args()
@@ -138,6 +139,38 @@ def main():
         fprof = _lib.profile_stop()["mpx_sa_mlp_bf16x3"]
         model.set_precision("fp32")
         fast = (fel, float(np.mean(fprof[0::2])), float(np.mean(fprof[1::2])))
+
+    # ---- extra: BASELINE configs 2 and 4 (FK + swept-sphere SDF collision validation only) on this rank's envs
+    extra = None
+    if rank == 0 and args.extra:
+        from mpinets_amd.scenes import linear_trajectories, random_configurations
+
+        def timed(fn, n=20):
+            fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(n):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / n
+
+        traj = torch.from_numpy(linear_trajectories(B, 50, 5)).to(dev)
+        q1k = torch.from_numpy(random_configurations(1024, 6)).to(dev)
+        sub = lambda t, n: t[:n].contiguous()
+        from mpinets_amd.geometry import TorchCuboids, TorchCylinders
+        cub1k = TorchCuboids(sub(prob["cuboid_centers"], 1024), sub(prob["cuboid_dims"], 1024), sub(prob["cuboid_quats"], 1024))
+        cyl1k = TorchCylinders(sub(prob["cylinder_centers"], 1024), sub(prob["cylinder_radii"], 1024),
+                               sub(prob["cylinder_heights"], 1024), sub(prob["cylinder_quats"], 1024))
+        c4_ms = timed(lambda: eng.collision.check(traj, eng.cuboids, eng.cylinders))
+        c2_ms = timed(lambda: eng.collision.check(q1k, cub1k, cyl1k, return_sdf=True))
+        extra = {
+            "c4_collision_validation": {"envs": B, "waypoints": 50, "ms": c4_ms, "env_waypoints_per_s": B * 50 / c4_ms * 1e3,
+                                        "what": "FK + 56-sphere SDF vs 16 cuboids + 16 cylinders, has_collision[B] (model.py:293-314)"},
+            "c2_fk_sdf_1024": {"envs": 1024, "ms": c2_ms, "env_steps_per_s": 1024 / c2_ms * 1e3,
+                               "what": "FK + sphere SDF, flags + min-sdf [1024,56] written"},
+        }
 
     # final host gather (the only cross-rank data movement): joint angles + collision flags
     q_all = shard.gather_to_rank0(eng.q)
@@ -215,6 +248,8 @@ def main():
             },
             "result_check": {"gathered_q": list(q_all.shape), "collision_rate": float((f_all != 0).float().mean())},
         }
+        if extra is not None:
+            out["extra_configs"] = extra
         if fast is not None:
             fel, f1_ms, f2_ms = fast
             out["fast_mode"] = {
