@@ -107,6 +107,18 @@ int mpx_franka_success(const float *q, const float *target_poses, int B, float f
                        float cos_rot_tol, int32_t *done, int32_t *steps, float *pos_err,
                        float *cos_angle, mpx_stream_t stream);
 
+/* Batched trajectory metrics (row N3; mpinets/metrics.py:311-384, 410-434 without PyBullet):
+ * traj [B,T,7] joint angles, lengths (optional int32 [B]) valid waypoints per trajectory,
+ * target_poses [B,4,4] (right_gripper), limits [7,2].  Per trajectory: final position error [cm],
+ * final orientation error [deg], end-effector path lengths (m, deg), joint-limit violation flag,
+ * self-collision flag.  Self collision uses the in-repo Geometric-Fabrics model
+ * (config/franka_fabric_config.yaml:120-140: base body cylinder vs spheres on link7 / hand /
+ * finger tips) -- NOT PyBullet's mesh test like the reference Evaluator.                        */
+int mpx_trajectory_metrics(const float *traj, const int32_t *lengths, const float *target_poses,
+                           const float *limits, int B, int T, float finger, float *pos_err_cm,
+                           float *orient_err_deg, float *path_pos, float *path_orient_deg,
+                           int32_t *limit_violation, int32_t *self_collision, mpx_stream_t stream);
+
 /* ---- scene point clouds: mpinets/geometry.py:571-608 (construct_mixed_point_cloud), batched ----- */
 
 /* For every environment: area-proportional pool sizes int(p_i*N)+500, N pool slots drawn without

@@ -262,3 +262,109 @@ MPX_EXPORT int mpx_franka_success(const float *q, const float *target_poses, int
                      finger, pos_tol, cos_rot_tol, done, steps, pos_err, cos_angle);
   MPX_LAUNCH_CHECK("mpx_franka_success");
 }
+
+// ---- batched trajectory metrics (next row N3: mpinets/metrics.py:311-384, 436-523 without PyBullet) ---------
+// One wave per trajectory; lanes = waypoints (64 per pass).  Per waypoint: FK -> right_gripper pose,
+// joint-limit test (metrics.py:311-322, published limits), self-collision test.  Per trajectory:
+// final position error [cm] and orientation error [deg] vs the target (metrics.py:338-361), end-effector
+// path lengths (metrics.py:410-434), flags.  Self collision uses the in-repo Geometric-Fabrics model
+// (config/franka_fabric_config.yaml:120-140: body cylinder (0,0,-0.3)-(0,0,0.333) r 0.15 vs spheres on
+// link7 (r 0.1), hand and finger tips (r 0.01)); the reference Evaluator asks PyBullet meshes instead.
+// `lengths` (optional) = number of valid waypoints per trajectory (>= 1); later rows are ignored.
+__device__ __forceinline__ float rot_angle_deg(const float *a, const float *b) {  // angle of A B^T, row-major 3x3
+  float tr = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) tr = mpx_fma(a[i], b[i], tr);
+  const float c = fminf(fmaxf((tr - 1.0f) * 0.5f, -1.0f), 1.0f);
+  return acosf(c) * 57.29577951308232f;
+}
+
+__global__ void __launch_bounds__(64)
+    trajectory_metrics_kernel(const float *__restrict__ traj, const int32_t *__restrict__ lengths,
+                              const float *__restrict__ targets, const float *__restrict__ limits, int T,
+                              float finger, float *__restrict__ pos_err_cm, float *__restrict__ orient_err_deg,
+                              float *__restrict__ path_pos, float *__restrict__ path_orient_deg,
+                              int32_t *__restrict__ limit_violation, int32_t *__restrict__ self_collision) {
+  __shared__ float frames[64 * FRAME_FLOATS];
+  __shared__ float eff[65 * 12];  // right_gripper poses of this pass, slot 64 = last waypoint of the previous pass
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x;
+  int len = lengths ? lengths[b] : T;
+  len = len < 1 ? 1 : (len > T ? T : len);
+  const float *tq = traj + (size_t)b * T * 7;
+  float sum_pos = 0.0f, sum_rot = 0.0f;
+  bool bad_limit = false, bad_self = false;
+  for (int t0 = 0; t0 < len; t0 += 64) {
+    const int t = t0 + lane;
+    const bool valid = t < len;
+    if (valid) {
+      float q[7];
+#pragma unroll
+      for (int j = 0; j < 7; ++j) {
+        q[j] = tq[(size_t)t * 7 + j];
+        bad_limit |= q[j] < limits[2 * j] || q[j] > limits[2 * j + 1];
+      }
+      float *fr = frames + lane * FRAME_FLOATS;
+      franka_fk_frames(q, finger, fr);
+#pragma unroll
+      for (int k = 0; k < 12; ++k) eff[lane * 12 + k] = fr[12 * 14 + k];
+      // self collision: distance of the sphere centres to the base segment (0,0,-0.3)-(0,0,0.333)
+      const int links[4] = {7, 9, 12, 13};
+      const float radii[4] = {0.1f, 0.01f, 0.01f, 0.01f};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const float *c = fr + 12 * links[s] + 9;
+        const float zc = fminf(fmaxf(c[2], -0.3f), 0.333f);
+        const float dz = c[2] - zc;
+        const float d = sqrtf(mpx_fma(dz, dz, mpx_fma(c[1], c[1], c[0] * c[0])));
+        bad_self |= d < 0.15f + radii[s];
+      }
+    }
+    __syncthreads();
+    if (valid && t > 0) {
+      const float *cur = eff + lane * 12;
+      const float *prev = lane > 0 ? eff + (lane - 1) * 12 : eff + 64 * 12;
+      const float dx = cur[9] - prev[9], dy = cur[10] - prev[10], dz = cur[11] - prev[11];
+      sum_pos += sqrtf(mpx_fma(dz, dz, mpx_fma(dy, dy, dx * dx)));
+      sum_rot += rot_angle_deg(cur, prev);
+    }
+    if (valid && t == len - 1) {
+      const float *cur = eff + lane * 12;
+      const float *tg = targets + (size_t)b * 16;
+      const float dx = cur[9] - tg[3], dy = cur[10] - tg[7], dz = cur[11] - tg[11];
+      pos_err_cm[b] = 100.0f * sqrtf(mpx_fma(dz, dz, mpx_fma(dy, dy, dx * dx)));
+      const float tr[9] = {tg[0], tg[1], tg[2], tg[4], tg[5], tg[6], tg[8], tg[9], tg[10]};
+      orient_err_deg[b] = rot_angle_deg(cur, tr);
+    }
+    __syncthreads();
+    if (lane == 63) {
+#pragma unroll
+      for (int k = 0; k < 12; ++k) eff[64 * 12 + k] = eff[63 * 12 + k];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    sum_pos += __shfl_xor(sum_pos, o);
+    sum_rot += __shfl_xor(sum_rot, o);
+  }
+  const bool any_limit = __any(bad_limit), any_self = __any(bad_self);
+  if (lane == 0) {
+    path_pos[b] = sum_pos;
+    path_orient_deg[b] = sum_rot;
+    limit_violation[b] = any_limit;
+    self_collision[b] = any_self;
+  }
+}
+
+MPX_EXPORT int mpx_trajectory_metrics(const float *traj, const int32_t *lengths, const float *target_poses,
+                                      const float *limits, int B, int T, float finger, float *pos_err_cm,
+                                      float *orient_err_deg, float *path_pos, float *path_orient_deg,
+                                      int32_t *limit_violation, int32_t *self_collision, mpx_stream_t stream) {
+  MPX_REQUIRE(B >= 0 && T >= 1, "mpx_trajectory_metrics: bad size");
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(trajectory_metrics_kernel, dim3(B), dim3(64), 0, mpx_s(stream), traj, lengths, target_poses,
+                     limits, T, finger, pos_err_cm, orient_err_deg, path_pos, path_orient_deg, limit_violation,
+                     self_collision);
+  MPX_LAUNCH_CHECK("mpx_trajectory_metrics");
+}

@@ -33,6 +33,7 @@ PROTOTYPES = {
     "mpx_franka_collision": [P, I, I, F, P, P, P, I, P, P, I, P, P, P, I, P, P, P],
     "mpx_joint_step": [P, P, P, I, P, P, P, P],
     "mpx_franka_success": [P, P, I, F, F, F, P, P, P, P, P],
+    "mpx_trajectory_metrics": [P, P, P, P, I, I, F, P, P, P, P, P, P, P],
     "mpx_scene_cloud": [P, P, P, I, P, P, P, P, I, I, I, ctypes.c_uint64, P, P, P, P, L, I, I, P],
     "mpx_fps": [P, I, I, I, I, P, P, I, P],
     "mpx_ball_query": [P, I, P, I, I, I, I, F, I, P, P, P],

@@ -1,0 +1,84 @@
+"""Batched, PyBullet-free trajectory evaluation on the device (next row N3 of SURVEY.md section 8f).
+
+The reference's ``Evaluator.evaluate_trajectory`` (``mpinets/metrics.py:436-523``) scores ONE
+trajectory at a time with PyBullet (and optionally Lula) collision checkers on the host.  This
+module scores a whole batch ``[B, T, 7]`` on the GPU with the metrics that need no physics engine,
+under the reference's names:
+
+=================================  ==============================================================
+``position_error`` [cm]            ``check_final_position`` (metrics.py:338-347)
+``orientation_error`` [deg]        ``check_final_orientation`` (metrics.py:349-361)
+``eff_position_path_length`` [m]   ``calculate_eff_path_lengths`` (metrics.py:410-434)
+``eff_orientation_path_length``    same, degrees
+``joint_limit_violation``          ``violates_joint_limits`` (metrics.py:311-322), published limits
+``collision``                      swept-sphere SDF check of ``model.py:293-314`` -- NOT PyBullet/Lula
+``self_collision``                 body-cylinder vs end-link spheres of ``config/franka_fabric_config.yaml``
+                                   -- NOT PyBullet
+``correct_final_region``           ``check_final_region`` (metrics.py:363-384) with SDF volumes
+``success``                        position < 1 cm, orientation < 15 deg, region ok, no violation
+                                   (metrics.py:514-519)
+=================================  ==============================================================
+
+SPARC smoothness (an FFT of a <= 150-sample series) stays on the host and is not part of this module.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib
+from . import franka_tables as ft
+from .robot import FrankaCollisionSampler
+
+
+class BatchedEvaluator:
+    def __init__(self, device, finger: float = ft.FINGER_OPENING):
+        self.device = torch.device(device)
+        self.finger = float(finger)
+        self.limits = torch.as_tensor(ft.JOINT_LIMITS_PUBLISHED, dtype=torch.float32, device=self.device).contiguous()
+        self.collision_sampler = FrankaCollisionSampler(self.device, with_base_link=False, finger=finger)
+
+    @torch.no_grad()
+    def evaluate_trajectories(self, trajectories: torch.Tensor, target_poses: torch.Tensor,
+                              lengths: Optional[torch.Tensor] = None, cuboids=None, cylinders=None,
+                              target_volume=None, negative_volumes=None) -> Dict[str, torch.Tensor]:
+        """:param trajectories: [B,T,7] joint angles (rows past ``lengths[b]`` are ignored; they must still be
+            valid configurations, e.g. the final one repeated, for the collision sweep)
+        :param target_poses: [B,4,4] ``right_gripper`` targets
+        :param cuboids/cylinders: scene primitives (``geometry.TorchCuboids`` / ``TorchCylinders``) or None
+        :param target_volume: optional primitive set (M >= 1 per env); the final position must be inside one
+        :param negative_volumes: optional primitive set; the final position must be outside all of them
+        """
+        _lib.require_cuda(trajectories, target_poses)
+        B, T, _ = trajectories.shape
+        dev = trajectories.device
+        tr, tg = _lib.f32c(trajectories), _lib.f32c(target_poses)
+        ln = None if lengths is None else _lib.i32c(lengths)
+        f = lambda: torch.empty(B, dtype=torch.float32, device=dev)
+        i = lambda: torch.zeros(B, dtype=torch.int32, device=dev)
+        pos, ori, pp, po, jl, sc = f(), f(), f(), f(), i(), i()
+        _lib.call("mpx_trajectory_metrics", _lib.ptr(tr), _lib.ptr(ln), _lib.ptr(tg), _lib.ptr(self.limits), B, T,
+                  self.finger, _lib.ptr(pos), _lib.ptr(ori), _lib.ptr(pp), _lib.ptr(po), _lib.ptr(jl), _lib.ptr(sc))
+        if ln is not None:  # freeze the tail so the swept-sphere check only sees valid waypoints
+            t_idx = torch.minimum(torch.arange(T, device=dev)[None, :], (ln.long() - 1).clamp(min=0)[:, None])
+            tr = torch.gather(tr, 1, t_idx[:, :, None].expand(-1, -1, 7)).contiguous()
+        collision = self.collision_sampler.check(tr, cuboids, cylinders)
+        region = torch.ones(B, dtype=torch.bool, device=dev)
+        if target_volume is not None or negative_volumes is not None:
+            last = (ln.long() - 1).clamp(min=0) if ln is not None else torch.full((B,), T - 1, device=dev)
+            from .robot import franka_fk
+
+            final = franka_fk(tr[torch.arange(B, device=dev), last], self.finger)[:, ft.LINK_ID["right_gripper"], 9:]
+            p = final[:, None, :].contiguous()
+            if target_volume is not None:
+                region &= target_volume.sdf(p)[:, 0] <= 0
+            if negative_volumes is not None:
+                region &= negative_volumes.sdf(p)[:, 0] > 0
+        jl, sc = jl != 0, sc != 0
+        violation = collision | jl | sc
+        return {"position_error": pos, "orientation_error": ori, "eff_position_path_length": pp,
+                "eff_orientation_path_length": po, "joint_limit_violation": jl, "self_collision": sc,
+                "collision": collision, "physical_violations": violation, "correct_final_region": region,
+                "success": (pos < 1) & (ori < 15) & region & ~violation,
+                "num_steps": ln if ln is not None else torch.full((B,), T, dtype=torch.int32, device=dev)}

@@ -629,3 +629,62 @@ ORC_API void orc_success(const float *eff_frames, const float *targets, int B, f
     ok[b] = err < pos_tol && ca > cos_tol;
   }
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Batched trajectory metrics (row N3).  Restates the PyBullet-free parts of the reference's
+ * Evaluator: violates_joint_limits (metrics.py:311-322), check_final_position (:338-347),
+ * check_final_orientation (:349-361), calculate_eff_path_lengths (:410-434).  Self collision
+ * is the engine's sphere-vs-body-cylinder model from config/franka_fabric_config.yaml:120-140
+ * (the reference asks PyBullet): PARITY UNPINNED for that flag.
+ * ---------------------------------------------------------------------------------------- */
+static float orc_rot_angle_deg(const float *a, const float *b) {
+  float tr = 0.0f;
+  for (int i = 0; i < 9; ++i) tr = fmaf(a[i], b[i], tr);
+  float c = fminf(fmaxf((tr - 1.0f) * 0.5f, -1.0f), 1.0f);
+  return acosf(c) * 57.29577951308232f;
+}
+
+ORC_API void orc_trajectory_metrics(const float *traj, const int32_t *lengths, const float *targets,
+                                    const float *limits, int B, int T, float finger, float *pos_err_cm,
+                                    float *orient_err_deg, float *path_pos, float *path_orient_deg,
+                                    int32_t *limit_violation, int32_t *self_collision) {
+  float *T1 = (float *)malloc(sizeof(float) * 15 * 12);
+  for (int b = 0; b < B; ++b) {
+    int len = lengths ? lengths[b] : T;
+    len = len < 1 ? 1 : (len > T ? T : len);
+    float prev[12], cur[12];
+    double sp = 0.0, sr = 0.0;
+    int bad_l = 0, bad_s = 0;
+    for (int t = 0; t < len; ++t) {
+      const float *q = traj + ((size_t)b * T + t) * 7;
+      for (int j = 0; j < 7; ++j) bad_l |= q[j] < limits[2 * j] || q[j] > limits[2 * j + 1];
+      orc_franka_fk(q, 1, finger, T1);
+      memcpy(cur, T1 + 12 * 14, sizeof(cur));
+      const int links[4] = {7, 9, 12, 13};
+      const float radii[4] = {0.1f, 0.01f, 0.01f, 0.01f};
+      for (int s = 0; s < 4; ++s) {
+        const float *c = T1 + 12 * links[s] + 9;
+        float zc = fminf(fmaxf(c[2], -0.3f), 0.333f);
+        float dz = c[2] - zc;
+        float d = sqrtf(fmaf(dz, dz, fmaf(c[1], c[1], c[0] * c[0])));
+        bad_s |= d < 0.15f + radii[s];
+      }
+      if (t > 0) {
+        float dx = cur[9] - prev[9], dy = cur[10] - prev[10], dz = cur[11] - prev[11];
+        sp += sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
+        sr += orc_rot_angle_deg(cur, prev);
+      }
+      memcpy(prev, cur, sizeof(cur));
+    }
+    const float *tg = targets + (size_t)b * 16;
+    float dx = cur[9] - tg[3], dy = cur[10] - tg[7], dz = cur[11] - tg[11];
+    pos_err_cm[b] = 100.0f * sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
+    float tr[9] = {tg[0], tg[1], tg[2], tg[4], tg[5], tg[6], tg[8], tg[9], tg[10]};
+    orient_err_deg[b] = orc_rot_angle_deg(cur, tr);
+    path_pos[b] = (float)sp;
+    path_orient_deg[b] = (float)sr;
+    limit_violation[b] = bad_l;
+    self_collision[b] = bad_s;
+  }
+  free(T1);
+}

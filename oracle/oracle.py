@@ -196,6 +196,22 @@ def success(eff_frames, targets, pos_tol=0.01, cos_tol=float(np.cos(np.radians(1
     return ok.astype(bool), pe, ca
 
 
+def trajectory_metrics(traj, lengths, targets, limits, finger: float = 0.025) -> dict:
+    """Row N3: PyBullet-free parts of metrics.py's Evaluator for trajectories [B,T,7]."""
+    x, tg, lim = _f(traj), _f(targets), _f(limits)
+    B, T = x.shape[:2]
+    ln = None if lengths is None else _i(lengths)
+    out = {k: np.empty(B, np.float32) for k in ("position_error", "orientation_error", "eff_position_path_length",
+                                                "eff_orientation_path_length")}
+    jl, sc = np.zeros(B, np.int32), np.zeros(B, np.int32)
+    lib().orc_trajectory_metrics(_p(x), _p(ln), _p(tg), _p(lim), B, T, ctypes.c_float(finger), _p(out["position_error"]),
+                                 _p(out["orientation_error"]), _p(out["eff_position_path_length"]),
+                                 _p(out["eff_orientation_path_length"]), _p(jl), _p(sc))
+    out["joint_limit_violation"] = jl.astype(bool)
+    out["self_collision"] = sc.astype(bool)
+    return out
+
+
 # ---------------------------------------------------------------- pointnet2_ops (unpinned)
 def opt_n_threads(n: int) -> int:
     return int(lib().orc_opt_n_threads(ctypes.c_int(n)))

@@ -1,0 +1,84 @@
+"""Row N3: batched trajectory metrics vs the oracle (and vs hand-checkable cases)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def test_trajectory_metrics_match_oracle(oracle):
+    from mpinets_amd import franka_tables as ft
+    from mpinets_amd.geometry import TorchCuboids, TorchCylinders
+    from mpinets_amd.metrics import BatchedEvaluator
+    from mpinets_amd.robot import franka_fk, frames_to_matrix
+    from mpinets_amd.scenes import linear_trajectories, make_scenes, random_configurations
+
+    B, Tn = 40, 150  # > 64 waypoints: several passes per trajectory
+    traj = linear_trajectories(B, Tn, 3)
+    traj[1, 10, 2] = 3.5  # outside the published limits
+    lengths = np.random.default_rng(0).integers(1, Tn + 1, B).astype(np.int32)
+    lengths[0], lengths[2] = Tn, 1
+    goal = random_configurations(B, 11)
+    goal[3] = traj[3, lengths[3] - 1]  # env 3 ends exactly on its target
+    tt = torch.from_numpy(traj).to(dev())
+    targets = frames_to_matrix(franka_fk(torch.from_numpy(goal).to(dev()))[:, ft.LINK_ID["right_gripper"]]).contiguous()
+    scn = make_scenes(B, 4, ("tabletop",), 16, 16)
+    cub = TorchCuboids(*(torch.from_numpy(scn[k]).to(dev()) for k in ("cuboid_centers", "cuboid_dims", "cuboid_quats")))
+    cyl = TorchCylinders(*(torch.from_numpy(scn[k]).to(dev()) for k in ("cylinder_centers", "cylinder_radii", "cylinder_heights", "cylinder_quats")))
+    ev = BatchedEvaluator(dev())
+    got = ev.evaluate_trajectories(tt, targets, torch.from_numpy(lengths).to(dev()), cub, cyl)
+    ref = oracle.trajectory_metrics(traj, lengths, targets.cpu().numpy(), ft.JOINT_LIMITS_PUBLISHED)
+    for k, tol in (("position_error", 1e-3), ("orientation_error", 2e-2), ("eff_position_path_length", 1e-4),
+                   ("eff_orientation_path_length", 0.2)):
+        np.testing.assert_allclose(got[k].cpu().numpy(), ref[k], rtol=1e-4, atol=tol, err_msg=k)
+    np.testing.assert_array_equal(got["joint_limit_violation"].cpu().numpy(), ref["joint_limit_violation"])
+    np.testing.assert_array_equal(got["self_collision"].cpu().numpy(), ref["self_collision"])
+    assert bool(got["joint_limit_violation"][1]) == (lengths[1] > 10)
+    assert got["position_error"][3] < 1e-3 and got["orientation_error"][3] < 0.1
+    assert got["eff_position_path_length"][2] == 0  # a single waypoint has no path
+    # collision flag = the fused swept-sphere check on the valid part of each trajectory
+    frozen = traj.copy()
+    for b in range(B):
+        frozen[b, lengths[b]:] = frozen[b, lengths[b] - 1]
+    np.testing.assert_array_equal(got["collision"].cpu().numpy(),
+                                  ev.collision_sampler.check(torch.from_numpy(frozen).to(dev()), cub, cyl).cpu().numpy())
+    s = got["success"].cpu().numpy()
+    assert s.dtype == bool and (~s | ~got["physical_violations"].cpu().numpy()).all()
+
+
+def test_neutral_pose_is_clean_and_folded_arm_self_collides(oracle):
+    from mpinets_amd import franka_tables as ft
+    from mpinets_amd.metrics import BatchedEvaluator
+    from mpinets_amd.robot import franka_fk, frames_to_matrix
+
+    q = np.stack([ft.DEFAULT_Q, np.array([0.0, -1.7, 0.0, -3.0, 0.0, 0.3, 0.0])]).astype(np.float32)[:, None, :]
+    tq = torch.from_numpy(q).to(dev())
+    targets = frames_to_matrix(franka_fk(tq[:, 0])[:, ft.LINK_ID["right_gripper"]]).contiguous()
+    out = BatchedEvaluator(dev()).evaluate_trajectories(tq, targets)
+    ref = oracle.trajectory_metrics(q, None, targets.cpu().numpy(), ft.JOINT_LIMITS_PUBLISHED)
+    np.testing.assert_array_equal(out["self_collision"].cpu().numpy(), ref["self_collision"])
+    assert not bool(out["self_collision"][0]) and not bool(out["joint_limit_violation"][0])
+    assert bool(out["success"][0])  # standing on the target, nothing violated
+    assert (out["position_error"] < 1e-3).all()
+
+
+def test_final_region_check():
+    from mpinets_amd import franka_tables as ft
+    from mpinets_amd.geometry import TorchCuboids
+    from mpinets_amd.metrics import BatchedEvaluator
+    from mpinets_amd.robot import franka_fk, frames_to_matrix
+
+    q = torch.from_numpy(np.tile(ft.DEFAULT_Q.astype(np.float32), (2, 3, 1))).to(dev())
+    pose = frames_to_matrix(franka_fk(q[:, 0])[:, ft.LINK_ID["right_gripper"]]).contiguous()
+    c = pose[:, None, :3, 3].contiguous()
+    ident = torch.tensor([[[1.0, 0, 0, 0]]], device=dev()).repeat(2, 1, 1)
+    inside = TorchCuboids(c, torch.full((2, 1, 3), 0.2, device=dev()), ident)
+    far = TorchCuboids(c + 1.0, torch.full((2, 1, 3), 0.2, device=dev()), ident)
+    ev = BatchedEvaluator(dev())
+    assert ev.evaluate_trajectories(q, pose, target_volume=inside, negative_volumes=far)["correct_final_region"].all()
+    assert not ev.evaluate_trajectories(q, pose, target_volume=far)["correct_final_region"].any()
+    assert not ev.evaluate_trajectories(q, pose, negative_volumes=inside)["success"].any()
