@@ -119,6 +119,32 @@ int mpx_trajectory_metrics(const float *traj, const int32_t *lengths, const floa
                            float *orient_err_deg, float *path_pos, float *path_orient_deg,
                            int32_t *limit_violation, int32_t *self_collision, mpx_stream_t stream);
 
+/* ---- training losses with analytic gradients (row N1; mpinets/loss.py:31-166) -------------------- */
+
+/* collision_loss (loss.py:48-95) on points [B,N,3] (strides in floats): per environment
+ * loss_sum[b] = sum_n max(0, margin - min(cuboid sdf, cylinder sdf)); the reference's mean is
+ * sum_b loss_sum[b] / (B*N).  grad_points (optional, strided like points) receives
+ * d(loss_sum[b]) / d(point): the autograd of geometry.py:256-288 / :478-507 restated analytically.
+ * frames / dims / radii / heights as for mpx_cuboid_sdf / mpx_cylinder_sdf.                          */
+int mpx_collision_hinge(const float *points, int64_t batch_stride, int point_stride, int B, int N,
+                        const float *cub_frames, const float *cub_dims, int M1, const float *cyl_frames,
+                        const float *cyl_radii, const float *cyl_heights, int M2, float margin,
+                        float *loss_sum, float *grad_points, int64_t grad_batch_stride,
+                        int grad_point_stride, mpx_stream_t stream);
+
+/* point_match_loss (loss.py:31-45) on contiguous input/target [B, n_per_env]: sums[b] =
+ * {sum d^2, sum |d|}; grad_input (optional) = w_sq*2*d + w_abs*sign(d) -- pass w = 1/(B*n_per_env)
+ * for the reference's two mean reductions.                                                           */
+int mpx_point_match(const float *input, const float *target, int B, int n_per_env, float w_sq, float w_abs,
+                    float *sums, float *grad_input, mpx_stream_t stream);
+
+/* Backward of mpx_franka_cloud (robofin FrankaSampler.sample under autograd; loss.py:142-147):
+ * grad_q[b,k] = sum_points grad_points[b,p] . d(point)/d(q_k), joint angles in radians.             */
+int mpx_franka_cloud_grad(const float *q, int B, float finger, const float *table_pts,
+                          const int32_t *table_link, const int32_t *subset, int n, const float *grad_points,
+                          int64_t grad_batch_stride, int grad_point_stride, float *grad_q,
+                          mpx_stream_t stream);
+
 /* ---- scene point clouds: mpinets/geometry.py:571-608 (construct_mixed_point_cloud), batched ----- */
 
 /* For every environment: area-proportional pool sizes int(p_i*N)+500, N pool slots drawn without

@@ -504,7 +504,7 @@ static int launch_sa(const float *xyz, int stride, const float *new_xyz, int new
   const int64_t nq = (int64_t)B * npoint;
   MPX_REQUIRE(nq / 4 + 1 < ((int64_t)1 << 31), "mpx_sa_mlp: too many query points");
   if (cnt) {
-    constexpr int Q = CF == 1 ? 16 : 4;  // queries per wave: ~6 tiles of work on typical scenes
+    constexpr int Q = CF == 1 ? 16 : 8;  // queries per wave: 6-9 tiles of work on typical scenes
     const int64_t nw = (nq + Q - 1) / Q;
     // whole environments per XCD when the grid is regular (npoint % Q == 0, B % 8 == 0)
     const int bpe = (npoint % Q == 0 && B % 8 == 0) ? npoint / Q : 0;

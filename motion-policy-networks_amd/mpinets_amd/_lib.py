@@ -34,6 +34,9 @@ PROTOTYPES = {
     "mpx_joint_step": [P, P, P, I, P, P, P, P],
     "mpx_franka_success": [P, P, I, F, F, F, P, P, P, P, P],
     "mpx_trajectory_metrics": [P, P, P, P, I, I, F, P, P, P, P, P, P, P],
+    "mpx_collision_hinge": [P, L, I, I, I, P, P, I, P, P, P, I, F, P, P, L, I, P],
+    "mpx_point_match": [P, P, I, I, F, F, P, P, P],
+    "mpx_franka_cloud_grad": [P, I, F, P, P, P, I, P, L, I, P, P],
     "mpx_scene_cloud": [P, P, P, I, P, P, P, P, I, I, I, ctypes.c_uint64, P, P, P, P, L, I, I, P],
     "mpx_fps": [P, I, I, I, I, P, P, I, P],
     "mpx_ball_query": [P, I, P, I, I, I, I, F, I, P, P, P],

@@ -81,6 +81,29 @@ def frames_to_matrix(frames: torch.Tensor) -> torch.Tensor:
     return m
 
 
+class _SampleFn(torch.autograd.Function):
+    """``FrankaSampler.sample`` under autograd (the reference differentiates robofin's torch FK, loss.py:142-147)."""
+
+    @staticmethod
+    def forward(ctx, q, sampler, subset, n_out):
+        out = torch.empty((q.size(0), n_out, 3), dtype=torch.float32, device=q.device)
+        qc = _lib.f32c(q.detach())
+        sampler.sample_into(qc, out, subset)
+        ctx.sampler, ctx.subset, ctx.n_out = sampler, subset, n_out
+        ctx.save_for_backward(qc)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (qc,) = ctx.saved_tensors
+        s, g = ctx.sampler, _lib.f32c(g)
+        gq = torch.empty_like(qc)
+        _lib.call("mpx_franka_cloud_grad", _lib.ptr(qc), qc.size(0), s.finger, _lib.ptr(s.table_pts),
+                  _lib.ptr(s.table_link), _lib.ptr(ctx.subset), ctx.n_out, _lib.ptr(g), g.stride(0), g.stride(1),
+                  _lib.ptr(gq))
+        return gq, None, None, None
+
+
 class FrankaSampler:
     """Robot-surface point clouds by FK of a per-link point table.
 
@@ -132,6 +155,8 @@ class FrankaSampler:
         else:
             subset = self._draw(num_points)
         n_out = self.num_table_points if subset is None else int(subset.numel())
+        if torch.is_grad_enabled() and q.requires_grad:
+            return _SampleFn.apply(q, self, subset, n_out)
         out = torch.empty((q.size(0), n_out, 3), dtype=torch.float32, device=q.device)
         self.sample_into(q, out, subset)
         return out

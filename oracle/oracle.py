@@ -212,6 +212,96 @@ def trajectory_metrics(traj, lengths, targets, limits, finger: float = 0.025) ->
     return out
 
 
+# ---------------------------------------------------------------- losses (row N1), torch CPU autograd
+def fk_frames_torch(q, finger: float = 0.025):
+    """Differentiable restatement of the Franka chain (same public URDF constants as orc_franka_fk):
+    q torch [B,7] -> (R [B,15,3,3], t [B,15,3]) in q's dtype.  Used for gradient checks only."""
+    import torch
+
+    dt = q.dtype
+    JR = [((1, 0, 0), (0, 1, 0), (0, 0, 1)), ((1, 0, 0), (0, 0, 1), (0, -1, 0)), ((1, 0, 0), (0, 0, -1), (0, 1, 0)),
+          ((1, 0, 0), (0, 0, -1), (0, 1, 0)), ((1, 0, 0), (0, 0, 1), (0, -1, 0)), ((1, 0, 0), (0, 0, -1), (0, 1, 0)),
+          ((1, 0, 0), (0, 0, -1), (0, 1, 0))]
+    JT = [(0, 0, 0.333), (0, 0, 0), (0, -0.316, 0), (0.0825, 0, 0), (-0.0825, 0.384, 0), (0, 0, 0), (0.088, 0, 0)]
+    B = q.shape[0]
+    R = torch.eye(3, dtype=dt).expand(B, 3, 3)
+    t = torch.zeros(B, 3, dtype=dt)
+    Rs, ts = [R], [t]
+
+    def step(R, t, fr, ft):
+        fr = torch.tensor(fr, dtype=dt)
+        ft = torch.tensor(ft, dtype=dt)
+        return R @ fr, t + R @ ft
+
+    for j in range(7):
+        R, t = step(R, t, JR[j], JT[j])
+        c, s_ = torch.cos(q[:, j]), torch.sin(q[:, j])
+        z, o = torch.zeros_like(c), torch.ones_like(c)
+        Rz = torch.stack([torch.stack([c, -s_, z], 1), torch.stack([s_, c, z], 1), torch.stack([z, z, o], 1)], 1)
+        R = R @ Rz
+        Rs.append(R), ts.append(t)
+    I3 = ((1, 0, 0), (0, 1, 0), (0, 0, 1))
+    SH = 0.5 ** 0.5
+    R8, t8 = step(R, t, I3, (0, 0, 0.107))
+    Rh, th = step(R8, t8, ((SH, SH, 0), (-SH, SH, 0), (0, 0, 1)), (0, 0, 0))
+    Rl, tl = step(Rh, th, I3, (0, finger, 0.0584))
+    Rr, tr = step(Rh, th, I3, (0, -finger, 0.0584))
+    Rlt, tlt = step(Rl, tl, I3, (0, 0, 0.045))
+    Rrt, trt = step(Rr, tr, I3, (0, 0, 0.045))
+    Rg, tg = step(R8, t8, ((-SH, -SH, 0), (SH, -SH, 0), (0, 0, 1)), (0, 0, 0.1))
+    for a, b in ((R8, t8), (Rh, th), (Rl, tl), (Rr, tr), (Rlt, tlt), (Rrt, trt), (Rg, tg)):
+        Rs.append(a), ts.append(b)
+    return torch.stack(Rs, 1), torch.stack(ts, 1)
+
+
+def robot_cloud_torch(q, table_pts, table_link, subset=None, finger: float = 0.025):
+    """Differentiable FrankaSampler.sample: q torch [B,7] -> [B,n,3]."""
+    import torch
+
+    R, t = fk_frames_torch(q, finger)
+    pts = torch.as_tensor(np.asarray(table_pts), dtype=q.dtype)
+    link = torch.as_tensor(np.asarray(table_link)).long()
+    if subset is not None:
+        sub = torch.as_tensor(np.asarray(subset)).long()
+        pts, link = pts[sub], link[sub]
+    return torch.einsum("bnij,nj->bni", R[:, link], pts) + t[:, link]
+
+
+def sdf_torch(points, frames, kind, a, b=None):
+    """Differentiable restatement of TorchCuboids.sdf (geometry.py:256-288, kind='cuboid', a=dims [B,M,3]) and
+    TorchCylinders.sdf (:478-507, kind='cylinder', a=radii [B,M], b=heights [B,M]); frames [B,M,4,4]."""
+    import torch
+
+    proj = torch.einsum("bmij,bnj->bmni", frames[:, :, :3, :3], points) + frames[:, :, None, :3, 3]
+    if kind == "cuboid":
+        mask = ~(a.abs() <= 1e-8).any(-1)
+        d = proj.abs() - (a / 2)[:, :, None, :]
+    else:
+        mask = ~((a.abs() <= 1e-8) | (b.abs() <= 1e-8))
+        rho = torch.linalg.norm(proj[..., :2], dim=-1)
+        d = torch.stack((rho.abs() - a[:, :, None], proj[..., 2].abs() - (b / 2)[:, :, None]), -1)
+    outside = torch.linalg.norm(torch.maximum(d, torch.zeros_like(d)), dim=-1)
+    inside = torch.minimum(d.max(-1).values, torch.zeros_like(outside))
+    sdf = torch.where(mask[:, :, None], outside + inside, torch.full_like(outside, float("inf")))
+    if sdf.shape[1] == 0:
+        return torch.full(points.shape[:2], float("inf"), dtype=points.dtype)
+    return sdf.min(1).values
+
+
+def collision_loss_torch(points, cub_frames, cub_dims, cyl_frames, cyl_radii, cyl_heights, margin: float = 0.03):
+    """loss.py:48-95 on torch CPU tensors."""
+    import torch
+
+    s = torch.minimum(sdf_torch(points, cub_frames, "cuboid", cub_dims),
+                      sdf_torch(points, cyl_frames, "cylinder", cyl_radii, cyl_heights))
+    return torch.clamp(margin - s, min=0).mean()
+
+
+def point_match_loss_torch(a, b):
+    """loss.py:31-45."""
+    return ((a - b) ** 2).mean() + (a - b).abs().mean()
+
+
 # ---------------------------------------------------------------- pointnet2_ops (unpinned)
 def opt_n_threads(n: int) -> int:
     return int(lib().orc_opt_n_threads(ctypes.c_int(n)))

@@ -26,6 +26,12 @@ def golden():
 
 
 @pytest.fixture(scope="session")
+def loss_golden():
+    path = os.path.join(ROOT, "tests", "golden", "loss_golden.npz")
+    return dict(np.load(path, allow_pickle=False))
+
+
+@pytest.fixture(scope="session")
 def oracle():
     from oracle import oracle as orc
 

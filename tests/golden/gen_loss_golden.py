@@ -1,0 +1,136 @@
+"""Generates tests/golden/loss_golden.npz by IMPORTING the reference's mpinets/loss.py.
+
+Runs only in the build container (needs /root/reference).  loss.py imports robofin (absent): the
+stub ``robofin.pointcloud.torch.FrankaSampler`` handed to it is the oracle's differentiable FK of
+this repo's link-point table (``oracle.robot_cloud_torch``) -- so ``collision_loss`` /
+``point_match_loss`` and the container's composition, reductions and autograd are the reference's,
+the kinematics are ours (robofin: parity unpinned).  Only data is committed.
+
+    python tests/golden/gen_loss_golden.py
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.abspath(os.path.join(HERE, "..", ".."))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "motion-policy-networks_amd"), "/root/reference"]
+
+from mpinets_amd import franka_tables as ft  # noqa: E402
+from oracle import oracle  # noqa: E402
+
+SUBSET = np.random.default_rng(5).permutation(4096)[:1024].astype(np.int32)
+TABLE = ft.link_point_table(4096, with_base_link=False)
+
+
+def install_stubs():
+    g, p = types.ModuleType("geometrout"), types.ModuleType("geometrout.primitive")
+
+    class _Stub:
+        pass
+
+    p.Sphere = p.Cuboid = p.Cylinder = _Stub
+    rf, rr = types.ModuleType("robofin"), types.ModuleType("robofin.robots")
+    rp, rt = types.ModuleType("robofin.pointcloud"), types.ModuleType("robofin.pointcloud.torch")
+
+    class FrankaRealRobot:
+        JOINT_LIMITS, DOF = ft.JOINT_LIMITS_REAL, 7
+
+    class FrankaRobot:
+        JOINT_LIMITS, DOF = ft.JOINT_LIMITS_PUBLISHED, 7
+
+    class FrankaSampler:
+        def __init__(self, device, num_fixed_points=None, use_cache=False, with_base_link=True):
+            assert num_fixed_points == 1024 and not with_base_link
+
+        def sample(self, q):
+            return oracle.robot_cloud_torch(q, TABLE[0], TABLE[1], SUBSET)
+
+    rr.FrankaRealRobot, rr.FrankaRobot, rt.FrankaSampler = FrankaRealRobot, FrankaRobot, FrankaSampler
+    for name, mod in (("geometrout", g), ("geometrout.primitive", p), ("robofin", rf), ("robofin.robots", rr),
+                      ("robofin.pointcloud", rp), ("robofin.pointcloud.torch", rt)):
+        sys.modules[name] = mod
+
+
+def random_scene(rng, B, M1, M2):
+    quat = lambda n: rng.normal(size=(B, n, 4)).astype(np.float32)
+    s = {
+        "cuboid_centers": rng.uniform(-0.6, 0.6, (B, M1, 3)).astype(np.float32) + np.float32([0.4, 0, 0.3]),
+        "cuboid_dims": rng.uniform(0.05, 0.5, (B, M1, 3)).astype(np.float32),
+        "cuboid_quats": quat(M1),
+        "cylinder_centers": rng.uniform(-0.6, 0.6, (B, M2, 3)).astype(np.float32) + np.float32([0.4, 0, 0.3]),
+        "cylinder_radii": rng.uniform(0.03, 0.25, (B, M2, 1)).astype(np.float32),
+        "cylinder_heights": rng.uniform(0.05, 0.6, (B, M2, 1)).astype(np.float32),
+        "cylinder_quats": quat(M2),
+    }
+    # zero-volume padding rows as the data loader makes them (data_loader.py:202)
+    s["cuboid_dims"][:, -1] = 0
+    s["cuboid_quats"][:, -1] = [1, 0, 0, 0]
+    s["cylinder_radii"][:, -1] = 0
+    s["cylinder_heights"][:, -1] = 0
+    s["cylinder_quats"][:, -1] = [1, 0, 0, 0]
+    return s
+
+
+def main():
+    install_stubs()
+    import mpinets.loss as ref_loss
+
+    rng = np.random.default_rng(0)
+    out = {"subset": SUBSET}
+    order = ("cuboid_centers", "cuboid_dims", "cuboid_quats", "cylinder_centers", "cylinder_radii",
+             "cylinder_heights", "cylinder_quats")
+
+    # 1) collision_loss on free clouds (points inside, near and far from the primitives)
+    B, N = 3, 400
+    scn = random_scene(rng, B, 5, 4)
+    pts = rng.uniform(-0.5, 1.2, (B, N, 3)).astype(np.float32)
+    near = np.concatenate((scn["cuboid_centers"][:, :4], scn["cylinder_centers"][:, :3]), 1)  # [B,7,3]
+    pick = rng.integers(0, near.shape[1], (B, 300))
+    pts[:, :300] = np.take_along_axis(near, pick[:, :, None], 1) + rng.normal(scale=0.12, size=(B, 300, 3))
+    pts = pts.astype(np.float32)
+    pc = torch.tensor(pts, requires_grad=True)
+    loss = ref_loss.collision_loss(pc, *(torch.tensor(scn[k]) for k in order))
+    loss.backward()
+    out.update({f"c_{k}": v for k, v in scn.items()})
+    out.update(c_points=pts, c_loss=loss.item(), c_grad=pc.grad.numpy())
+    sdf_in = (torch.minimum(ref_loss.TorchCuboids(*(torch.tensor(scn[k]) for k in order[:3])).sdf(pc),
+                            ref_loss.TorchCylinders(*(torch.tensor(scn[k]) for k in order[3:])).sdf(pc)) < 0).float().mean()
+    print("active fraction", (np.abs(out["c_grad"]).sum(-1) > 0).mean(), "inside fraction", sdf_in.item())
+    assert np.isfinite(out["c_grad"]).all() and (np.abs(out["c_grad"]).sum(-1) > 0).mean() > 0.3
+
+    # 2) point_match_loss
+    a = rng.normal(size=(4, 300, 3)).astype(np.float32)
+    b = a + rng.normal(scale=0.05, size=a.shape).astype(np.float32)
+    b[0, :10] = a[0, :10]  # exact matches: sign(0) = 0
+    ta = torch.tensor(a, requires_grad=True)
+    pm = ref_loss.point_match_loss(ta, torch.tensor(b))
+    pm.backward()
+    out.update(p_input=a, p_target=b, p_loss=pm.item(), p_grad=ta.grad.numpy())
+
+    # 3) the container: normalised joints -> (collision loss, point-match loss) and their gradients
+    B = 6
+    scn = random_scene(rng, B, 6, 5)
+    qn = rng.uniform(-0.9, 0.9, (B, 7)).astype(np.float32)
+    tn = np.clip(qn + rng.normal(scale=0.1, size=qn.shape), -1, 1).astype(np.float32)
+    container = ref_loss.CollisionAndBCLossContainer()
+    grads = []
+    for which in (0, 1):
+        x = torch.tensor(qn, requires_grad=True)
+        losses = container(x, *(torch.tensor(scn[k]) for k in order), torch.tensor(tn))
+        losses[which].backward()
+        grads.append(x.grad.numpy())
+        out[("k_collision_loss", "k_point_match_loss")[which]] = losses[which].item()
+    out.update({f"k_{k}": v for k, v in scn.items()})
+    out.update(k_input=qn, k_target=tn, k_grad_collision=grads[0], k_grad_point_match=grads[1])
+    assert np.abs(grads[0]).max() > 0
+
+    np.savez_compressed(os.path.join(HERE, "loss_golden.npz"), **out)
+    print({k: (v.shape if hasattr(v, "shape") else v) for k, v in out.items() if k.endswith(("loss", "grad"))})
+
+
+if __name__ == "__main__":
+    main()

@@ -29,6 +29,32 @@ def test_library_exports_every_declared_symbol():
     assert sorted(_lib.exported_symbols()) == names  # the ctypes prototypes cover the whole header
 
 
+def test_ctypes_prototypes_agree_with_the_header():
+    """Every binding has the header's parameter count and pointer / int / int64 / float classes (a missing
+    trailing stream argument would put garbage in the stream register)."""
+    from mpinets_amd import _lib
+
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "mpinets_hip.h")).read(), flags=re.S)
+    decls = dict(re.findall(r"\b(mpx_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", text))
+
+    def cls(param):
+        if "*" in param or "mpx_stream_t" in param:
+            return ctypes.c_void_p
+        if "int64_t" in param and "uint64_t" not in param:
+            return ctypes.c_int64
+        if "uint64_t" in param:
+            return ctypes.c_uint64
+        if re.search(r"\bfloat\b", param):
+            return ctypes.c_float
+        return ctypes.c_int
+
+    for name, argtypes in _lib.PROTOTYPES.items():
+        params = [p.strip() for p in decls[name].split(",") if p.strip() and p.strip() != "void"]
+        want = [cls(p) for p in params]
+        got = [ctypes.c_void_p if a is ctypes.c_char_p else a for a in argtypes]
+        assert got == want, f"{name}: ctypes {got} != header {want}"
+
+
 def test_library_loads_and_reports_errors_without_gpu():
     from mpinets_amd import _lib
 
