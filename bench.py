@@ -80,6 +80,7 @@ def main():
     ap.add_argument("--envs", type=int, default=8192, help="environments per GPU")
     ap.add_argument("--fast-steps", type=int, default=3, help="steps of the secondary bf16x3 measurement (0 = skip)")
     ap.add_argument("--extra", type=int, default=1, help="also time BASELINE configs 2 and 4 (collision validation only)")
+    ap.add_argument("--c5-steps", type=int, default=2, help="steps of the config-5-shaped extra (mixed scenes, scene re-render); 0 = skip")
     ap.add_argument("--cpu-envs", type=int, default=8, help="env-steps in the CPU baseline sample (0 = skip)")
     ap.add_argument("--scene-pool", type=int, default=1024, help="distinct host-generated primitive sets tiled over the batch (clouds are drawn per env on the device)")
     args = ap.parse_args()
@@ -120,6 +121,7 @@ def main():
     elapsed = time.perf_counter() - t0
     prof = _lib.profile_stop()
     elapsed = shard.max_over_ranks(elapsed, dev)
+    cnt1, cnt2 = (c.clone() for c in model.point_cloud_encoder.last_counts)  # ball-query hit counts of the last timed step
 
     # ---- secondary measurement: the opt-in split-bf16 mode of the two grouped MLPs (same step, same
     # envs, continuing the rollout).  The headline above stays the exact-fp32 path.
@@ -139,6 +141,10 @@ def main():
         fprof = _lib.profile_stop()["mpx_sa_mlp_bf16x3"]
         model.set_precision("fp32")
         fast = (fel, float(np.mean(fprof[0::2])), float(np.mean(fprof[1::2])))
+
+    # final host gather (the only cross-rank data movement): joint angles + collision flags
+    q_all = shard.gather_to_rank0(eng.q)
+    f_all = shard.gather_to_rank0(eng.flags)
 
     # ---- extra: BASELINE configs 2 and 4 (FK + swept-sphere SDF collision validation only) on this rank's envs
     extra = None
@@ -172,9 +178,36 @@ def main():
                                "what": "FK + sphere SDF, flags + min-sdf [1024,56] written"},
         }
 
-    # final host gather (the only cross-rank data movement): joint angles + collision flags
-    q_all = shard.gather_to_rank0(eng.q)
-    f_all = shard.gather_to_rank0(eng.flags)
+    # ---- extra: BASELINE config 5 shape -- mixed tabletop / cubby / dresser scenes, scene cloud re-rendered
+    # from the primitives at every step, then the same closed-loop policy step (all ranks, weak scaling)
+    c5 = None
+    if args.extra and args.c5_steps > 0:
+        prob5 = make_problem_batch(B, seed=5000 + rank, device=dev, kinds=("tabletop", "cubby", "dresser"), M1=40,
+                                   M2=16, scene_pool=args.scene_pool, device_clouds=True)
+        eng5 = RolloutEngine(model, prob5, rerender_scene=True, scene_seed=17 + rank)
+        eng5.step()
+        torch.cuda.synchronize()
+        shard.barrier()
+        names5 = ("mpx_scene_cloud", "mpx_sa_mlp", "mpx_fps", "mpx_ball_query", "mpx_linear", "mpx_linear_rowmax")
+        _lib.profile_start(*names5)
+        t5 = time.perf_counter()
+        for _ in range(args.c5_steps):
+            eng5.step()
+        torch.cuda.synchronize()
+        shard.barrier()
+        el5 = shard.max_over_ranks(time.perf_counter() - t5, dev)
+        prof5 = _lib.profile_stop()
+        c5 = {"envs_per_gpu": B, "steps": args.c5_steps, "ms_per_step": el5 / args.c5_steps * 1e3,
+              "env_steps_per_s": B * n_gpus * args.c5_steps / el5, "dtype": "f32",
+              "collision_rate": float((eng5.flags != 0).float().mean().item()),
+              "kernels_ms_per_step": {k[4:]: float(np.sum(v)) / args.c5_steps for k, v in prof5.items()},
+              "mean_distinct_neighbours": [float(c.float().mean().item()) for c in model.point_cloud_encoder.last_counts],
+              "what": "mixed tabletop/cubby/dresser scenes (40 cuboids + 16 cylinders, zero-padded); every step: "
+                      "scene cloud re-render (4096 pts from the primitives) + policy forward + joint update + FK "
+                      "cloud refresh + collision check"}
+        del eng5, prob5
+        if extra is not None:
+            extra["c5_mixed_rerender"] = c5
 
     if rank == 0:
         sa = prof["mpx_sa_mlp"]
@@ -183,7 +216,6 @@ def main():
         # repeats the first neighbour; max-pooling is idempotent -> bit-identical output).  The roofline uses
         # the FLOPs of the 32-row MFMA tiles actually issued (counts of the last timed step), not the nominal
         # 128 slots per neighbourhood.
-        cnt1, cnt2 = model.point_cloud_encoder.last_counts
 
         def tiles(c, q):  # fp32 kernel: q consecutive queries per wave, rows packed at 4-row granularity
             rows4 = (c.clamp(1, 128) + 3) // 4 * 4

@@ -145,6 +145,29 @@ int mpx_franka_cloud_grad(const float *q, int B, float finger, const float *tabl
                           int64_t grad_batch_stride, int grad_point_stride, float *grad_q,
                           mpx_stream_t stream);
 
+/* ---- differentiable grouping + max-pool of the set-abstraction stack (row N1) --------------------
+ * The reference trains through pointnet2_ops' QueryAndGroup / max-pool (model.py:366-383).  Here a
+ * neighbourhood contributes only its distinct neighbours (cnt from mpx_ball_query; padding repeats
+ * the first hit and neither a max nor its gradient sees repeats): rows of one [R, 3+C] matrix,
+ * query q owning rows offsets[q] .. offsets[q+1] (offsets int64 [B*npoint+1] = exclusive prefix
+ * sum of max(cnt,1)).                                                                              */
+
+/* rows[offsets[q]+r] = [xyz[idx[q,r]] - new_xyz[q] | feat[idx[q,r]]]  (QueryAndGroup, use_xyz=True) */
+int mpx_pack_rows(const float *xyz, int xyz_stride, const float *new_xyz, int new_stride,
+                  const float *feat, int feat_stride, int C, const int32_t *idx, const int32_t *cnt,
+                  const int64_t *offsets, int B, int N, int npoint, int nsample, float *rows,
+                  mpx_stream_t stream);
+/* backward: grad_feat[b, idx[q,r], c] += grad_rows[offsets[q]+r, 3+c] (atomic adds; grad_feat pre-zeroed) */
+int mpx_pack_rows_grad(const float *grad_rows, int C, const int32_t *idx, const int32_t *cnt,
+                       const int64_t *offsets, int B, int N, int npoint, int nsample, float *grad_feat,
+                       int feat_stride, mpx_stream_t stream);
+/* out[q,c] = max over the rows of segment q of y[R,C]; arg[q,c] = first row attaining it           */
+int mpx_segment_max(const float *y, int C, const int64_t *offsets, int64_t Q, float *out, int out_stride,
+                    int64_t *arg, mpx_stream_t stream);
+/* backward: grad_y[arg[q,c], c] = grad_out[q,c] (grad_y pre-zeroed)                                  */
+int mpx_segment_max_grad(const float *grad_out, int grad_stride, const int64_t *arg, int64_t Q, int C,
+                         float *grad_y, mpx_stream_t stream);
+
 /* ---- scene point clouds: mpinets/geometry.py:571-608 (construct_mixed_point_cloud), batched ----- */
 
 /* For every environment: area-proportional pool sizes int(p_i*N)+500, N pool slots drawn without

@@ -37,6 +37,10 @@ PROTOTYPES = {
     "mpx_collision_hinge": [P, L, I, I, I, P, P, I, P, P, P, I, F, P, P, L, I, P],
     "mpx_point_match": [P, P, I, I, F, F, P, P, P],
     "mpx_franka_cloud_grad": [P, I, F, P, P, P, I, P, L, I, P, P],
+    "mpx_pack_rows": [P, I, P, I, P, I, I, P, P, P, I, I, I, I, P, P],
+    "mpx_pack_rows_grad": [P, I, P, P, P, I, I, I, I, P, I, P],
+    "mpx_segment_max": [P, I, P, L, P, I, P, P],
+    "mpx_segment_max_grad": [P, I, P, L, I, P, P],
     "mpx_scene_cloud": [P, P, P, I, P, P, P, P, I, I, I, ctypes.c_uint64, P, P, P, P, L, I, I, P],
     "mpx_fps": [P, I, I, I, I, P, P, I, P],
     "mpx_ball_query": [P, I, P, I, I, I, I, F, I, P, P, P],

@@ -71,6 +71,45 @@ class MPiNetsPointNet(nn.Module):
         h = groupnorm_leaky(h, fc[4].weight, fc[4].bias, fc[4].num_groups, fc[4].eps, out=h)
         return linear(h, fc[6].weight, fc[6].bias, out=out)
 
+    def forward_train(self, point_cloud: torch.Tensor, aux: Optional[dict] = None) -> torch.Tensor:
+        """Differentiable forward (training_step, model.py:185-240): sampling / neighbour search / grouping /
+        max-pool are this engine's kernels (no padding rows), the dense layers are torch ops under autograd."""
+        from .pointnet2 import sa_module_train
+
+        pc = _lib.f32c(point_cloud)
+        B, N, _ = pc.shape
+        dev = pc.device
+        sa1, sa2, sa3 = self.SA_modules
+        lib = _lib
+        idx1 = torch.empty((B, sa1.npoint), dtype=torch.int32, device=dev)
+        xyz1 = torch.empty((B, sa1.npoint, 3), dtype=torch.float32, device=dev)
+        lib.call("mpx_fps", lib.ptr(pc), B, N, 4, sa1.npoint, lib.ptr(idx1), lib.ptr(xyz1), 3)
+        nbr1 = torch.empty((B, sa1.npoint, sa1.nsample), dtype=torch.int32, device=dev)
+        cnt1 = torch.empty((B, sa1.npoint), dtype=torch.int32, device=dev)
+        lib.call("mpx_ball_query", lib.ptr(xyz1), 3, lib.ptr(pc), 4, B, N, sa1.npoint, float(sa1.radius),
+                 sa1.nsample, lib.ptr(nbr1), lib.ptr(cnt1))
+        # the slab is read in place: coordinates at stride 4, label column = the one input feature (no gradient)
+        f1 = sa_module_train(sa1.convs(), pc, 4, xyz1, 3, pc[:, :, 3:], 4, 1, nbr1, cnt1, (B, N, sa1.npoint, sa1.nsample))
+        idx2 = torch.empty((B, sa2.npoint), dtype=torch.int32, device=dev)
+        xyz2 = torch.empty((B, sa2.npoint, 3), dtype=torch.float32, device=dev)
+        lib.call("mpx_fps", lib.ptr(xyz1), B, sa1.npoint, 3, sa2.npoint, lib.ptr(idx2), lib.ptr(xyz2), 3)
+        nbr2 = torch.empty((B, sa2.npoint, sa2.nsample), dtype=torch.int32, device=dev)
+        cnt2 = torch.empty((B, sa2.npoint), dtype=torch.int32, device=dev)
+        lib.call("mpx_ball_query", lib.ptr(xyz2), 3, lib.ptr(xyz1), 3, B, sa1.npoint, sa2.npoint, float(sa2.radius),
+                 sa2.nsample, lib.ptr(nbr2), lib.ptr(cnt2))
+        f1 = f1.contiguous()
+        f2 = sa_module_train(sa2.convs(), xyz1, 3, xyz2, 3, f1, f1.size(2), f1.size(2), nbr2, cnt2,
+                             (B, sa1.npoint, sa2.npoint, sa2.nsample))
+        h = torch.cat((xyz2, f2), dim=2)  # group-all: absolute coordinates | features
+        for conv in sa3.convs():
+            h = torch.relu(torch.nn.functional.linear(h, conv.weight.view(conv.out_channels, -1), conv.bias))
+        pooled = h.max(dim=1).values
+        self.last_counts = (cnt1, cnt2)
+        if aux is not None:
+            aux.update(fps_idx1=idx1, xyz1=xyz1, ball_idx1=nbr1, ball_cnt1=cnt1, f1=f1, fps_idx2=idx2, ball_idx2=nbr2,
+                       ball_cnt2=cnt2, f3=pooled)
+        return self.fc_layer(pooled)
+
     def _sa3_first_weight(self) -> torch.Tensor:
         conv = self.SA_modules[2].convs()[0]
         key = (conv.weight._version, conv.weight.data_ptr())
@@ -90,6 +129,11 @@ class MPiNetsPointNet(nn.Module):
         if not point_cloud.is_cuda:
             raise _lib.MpxError("CPU tensors not supported (reference: model.py:417)")
         assert point_cloud.ndim == 3 and point_cloud.size(2) == 4
+        if self.training and torch.is_grad_enabled():
+            enc = self.forward_train(point_cloud, aux=aux)
+            if out is not None:
+                raise _lib.MpxError("out= is an inference-path argument")
+            return enc
         pc = _lib.f32c(point_cloud)
         B, N, _ = pc.shape
         dev = pc.device
@@ -212,6 +256,9 @@ class MotionPolicyNetwork(nn.Module):
             raise _lib.MpxError("CPU tensors not supported (reference: model.py:417)")
         B = xyz.size(0)
         dev = xyz.device
+        if self.training and torch.is_grad_enabled():  # differentiable path (training_step)
+            pc_encoding = self.point_cloud_encoder(xyz, aux=aux)
+            return self.decoder(torch.cat((pc_encoding, self.feature_encoder(q)), dim=1))
         cat = torch.empty((B, 2048 + 64), dtype=torch.float32, device=dev)
         self.point_cloud_encoder(xyz, out=cat[:, :2048], aux=aux)
         fe = self.feature_encoder
@@ -232,16 +279,37 @@ class MotionPolicyNetwork(nn.Module):
 
 
 class TrainingMotionPolicyNetwork(MotionPolicyNetwork):
-    """Adds the rollout / validation helpers of the reference (model.py:94-318), forward only."""
+    """Adds the training / rollout / validation helpers of the reference (model.py:94-318)."""
 
     def __init__(self, num_robot_points: int, point_match_loss_weight: float = 1.0,
                  collision_loss_weight: float = 1.0):
         super().__init__()
+        from .loss import CollisionAndBCLossContainer
+
         self.num_robot_points = num_robot_points
         self.point_match_loss_weight = point_match_loss_weight
         self.collision_loss_weight = collision_loss_weight
         self.fk_sampler = None
         self.collision_sampler = None
+        self.loss_fun = CollisionAndBCLossContainer()
+        self.logged: Dict[str, torch.Tensor] = {}
+
+    def log(self, name: str, value: torch.Tensor) -> None:
+        """Stand-in for LightningModule.log: keeps the latest detached value per name."""
+        self.logged[name] = value.detach()
+
+    def training_step(self, batch: Dict[str, torch.Tensor], batch_idx: int = 0) -> torch.Tensor:
+        """model.py:185-240: one supervised step -> the weighted loss (call ``.backward()`` on it)."""
+        xyz, q = batch["xyz"], batch["configuration"]
+        y_hat = torch.clamp(q + self(xyz, q), min=-1, max=1)
+        collision_loss, point_match_loss = self.loss_fun(
+            y_hat, batch["cuboid_centers"], batch["cuboid_dims"], batch["cuboid_quats"], batch["cylinder_centers"],
+            batch["cylinder_radii"], batch["cylinder_heights"], batch["cylinder_quats"], batch["supervision"])
+        self.log("point_match_loss", point_match_loss)
+        self.log("collision_loss", collision_loss)
+        val_loss = self.point_match_loss_weight * point_match_loss + self.collision_loss_weight * collision_loss
+        self.log("val_loss", val_loss)
+        return val_loss
 
     def rollout(self, batch: Dict[str, torch.Tensor], rollout_length: int,
                 sampler: Callable[[torch.Tensor], torch.Tensor], unnormalize: bool = False) -> List[torch.Tensor]:

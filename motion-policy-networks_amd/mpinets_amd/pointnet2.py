@@ -170,6 +170,72 @@ def sa_mlp_fused(xyz: torch.Tensor, new_xyz: torch.Tensor, feat: torch.Tensor, f
 
 
 # ---- module -------------------------------------------------------------------------------------------
+# ---- training path (row N1): differentiable grouping + max-pool on packed distinct-neighbour rows ------
+class _PackRows(torch.autograd.Function):
+    """QueryAndGroup(use_xyz=True) without the padding: -> rows [R, 3+C]; gradient flows to ``feat`` only."""
+
+    @staticmethod
+    def forward(ctx, feat, xyz, xyz_stride, new_xyz, new_stride, feat_stride, C, idx, cnt, offsets, R, dims):
+        B, N, npoint, nsample = dims
+        rows = torch.empty((R, 3 + C), dtype=torch.float32, device=idx.device)
+        _lib.call("mpx_pack_rows", _lib.ptr(xyz), xyz_stride, _lib.ptr(new_xyz), new_stride, _lib.ptr(feat),
+                  feat_stride, C, _lib.ptr(idx), _lib.ptr(cnt), _lib.ptr(offsets), B, N, npoint, nsample, _lib.ptr(rows))
+        ctx.save_for_backward(idx, cnt, offsets)
+        ctx.meta = (C, dims, tuple(feat.shape), feat_stride)
+        return rows
+
+    @staticmethod
+    def backward(ctx, g):
+        idx, cnt, offsets = ctx.saved_tensors
+        C, (B, N, npoint, nsample), shape, feat_stride = ctx.meta
+        if not ctx.needs_input_grad[0]:
+            return (None,) * 12
+        g = _lib.f32c(g)
+        gf = torch.zeros(shape, dtype=torch.float32, device=g.device)
+        _lib.call("mpx_pack_rows_grad", _lib.ptr(g), C, _lib.ptr(idx), _lib.ptr(cnt), _lib.ptr(offsets), B, N, npoint,
+                  nsample, _lib.ptr(gf), gf.stride(1))
+        return (gf,) + (None,) * 11
+
+
+class _SegmentMax(torch.autograd.Function):
+    """Max-pool over each query's rows: y [R,C], offsets [Q+1] -> [Q,C]."""
+
+    @staticmethod
+    def forward(ctx, y, offsets, Q):
+        y = _lib.f32c(y)
+        C = y.size(1)
+        out = torch.empty((Q, C), dtype=torch.float32, device=y.device)
+        arg = torch.empty((Q, C), dtype=torch.int64, device=y.device)
+        _lib.call("mpx_segment_max", _lib.ptr(y), C, _lib.ptr(offsets), Q, _lib.ptr(out), C, _lib.ptr(arg))
+        ctx.save_for_backward(arg)
+        ctx.meta = (y.size(0), C, Q)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (arg,) = ctx.saved_tensors
+        R, C, Q = ctx.meta
+        g = _lib.f32c(g)
+        gy = torch.zeros((R, C), dtype=torch.float32, device=g.device)
+        _lib.call("mpx_segment_max_grad", _lib.ptr(g), g.stride(0), _lib.ptr(arg), Q, C, _lib.ptr(gy))
+        return gy, None, None
+
+
+def sa_module_train(convs: List[nn.Conv2d], xyz: torch.Tensor, xyz_stride: int, new_xyz: torch.Tensor,
+                    new_stride: int, feat: torch.Tensor, feat_stride: int, C: int, idx: torch.Tensor,
+                    cnt: torch.Tensor, dims: Tuple[int, int, int, int]) -> torch.Tensor:
+    """Differentiable set-abstraction MLP + max-pool -> [B, npoint, C_out].  ``feat`` is any tensor whose storage
+    holds the point-major features (``feat_stride`` floats between points); it receives the gradient."""
+    B, N, npoint, nsample = dims
+    offsets = torch.zeros(B * npoint + 1, dtype=torch.int64, device=idx.device)
+    torch.cumsum(cnt.reshape(-1).clamp(min=1), 0, out=offsets[1:])
+    R = int(offsets[-1].item())  # one host sync per module and step: the row count sizes the activations
+    h = _PackRows.apply(feat, xyz, xyz_stride, new_xyz, new_stride, feat_stride, C, idx, cnt, offsets, R, dims)
+    for conv in convs:  # dense algebra: library GEMMs under autograd
+        h = torch.relu(torch.nn.functional.linear(h, conv.weight.view(conv.out_channels, -1), conv.bias))
+    return _SegmentMax.apply(h, offsets, B * npoint).view(B, npoint, -1)
+
+
 class PointnetSAModule(nn.Module):
     """``PointnetSAModule(npoint=None, radius=None, nsample=None, mlp=[...], bn=False, use_xyz=True)``.
 
@@ -212,11 +278,20 @@ class PointnetSAModule(nn.Module):
             feat_pm = _lib.f32c(features).transpose(1, 2).contiguous()  # [B,N,C] point-major
             idx, new_xyz = furthest_point_sample(xyz, self.npoint, return_xyz=True)
             nbr, cnt = ball_query(self.radius, self.nsample, xyz, new_xyz, return_counts=True)
+            if self.training and torch.is_grad_enabled():
+                fpm = features.transpose(1, 2).contiguous() if features.requires_grad else feat_pm
+                out = sa_module_train(convs, xyz, 3, new_xyz, 3, fpm, C, C, nbr, cnt, (B, N, self.npoint, self.nsample))
+                return new_xyz, out.transpose(1, 2).contiguous()
             wpack = self._packed.get(convs, C, self.precision)
             out = sa_mlp_fused(xyz, new_xyz, feat_pm, C, C, nbr, wpack, tuple(c.out_channels for c in convs),
                                precision=self.precision, cnt=cnt if self.elide_padding else None)
             return new_xyz, out.transpose(1, 2).contiguous()
         # group-all: one "neighbourhood" holding every point, xyz NOT re-centred
+        if self.training and torch.is_grad_enabled():
+            h = torch.cat([xyz] + ([features.transpose(1, 2)] if features is not None else []), dim=2)
+            for conv in convs:
+                h = torch.relu(torch.nn.functional.linear(h, conv.weight.view(conv.out_channels, -1), conv.bias))
+            return None, h.max(dim=1).values.unsqueeze(-1)
         parts = [xyz]
         if features is not None:
             parts.append(_lib.f32c(features).transpose(1, 2))

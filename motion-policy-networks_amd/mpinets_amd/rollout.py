@@ -23,7 +23,9 @@ from .robot import FrankaCollisionSampler, FrankaSampler
 
 class RolloutEngine:
     def __init__(self, model: MotionPolicyNetwork, problem: Dict[str, torch.Tensor], num_robot_points: int = 2048,
-                 robot_subset: Optional[torch.Tensor] = None):
+                 robot_subset: Optional[torch.Tensor] = None, rerender_scene: bool = False, scene_seed: int = 0):
+        """``rerender_scene``: draw a fresh 4096-point scene cloud from the primitives at the start of every step
+        (BASELINE config 5, "closed-loop point-cloud re-render"); default keeps the scene rows of the slab."""
         self.model = model
         dev = problem["xyz"].device
         self.device = dev
@@ -44,6 +46,16 @@ class RolloutEngine:
         self.limits = torch.as_tensor(ft.JOINT_LIMITS_REAL, dtype=torch.float32, device=dev).contiguous()
         self.flags = torch.zeros(self.B, dtype=torch.int32, device=dev)
         self.steps_done = 0
+        self.rerender_scene, self.scene_seed = bool(rerender_scene), int(scene_seed)
+        if self.rerender_scene:
+            self._prims = {k: problem[k] for k in ("cuboid_centers", "cuboid_dims", "cuboid_quats", "cylinder_centers",
+                                                   "cylinder_radii", "cylinder_heights", "cylinder_quats")}
+            self._n_robot = int(self.subset.numel())
+            self._n_scene = self.xyz.size(1) - self._n_robot - 128
+            m = self._prims["cuboid_dims"].size(1) + self._prims["cylinder_radii"].size(1)
+            self._scene_scratch = (torch.empty((self.B, self._n_scene), dtype=torch.int16, device=dev),
+                                   torch.zeros((self.B, m), dtype=torch.uint8, device=dev),
+                                   torch.zeros(self.B, dtype=torch.int32, device=dev))
         # success tracking (rollout_until_success): target poses, done flags, per-env step counts
         self.targets = None
         self.done = None
@@ -63,6 +75,12 @@ class RolloutEngine:
     def step(self) -> torch.Tensor:
         """Advance every environment by one policy step; returns the new joint angles [B,7]."""
         lib = _lib
+        if self.rerender_scene:
+            from .scenes import sample_scene_clouds
+
+            sample_scene_clouds(self._prims, self._n_scene, self.scene_seed + 7919 * self.steps_done,
+                                out=self.xyz[:, self._n_robot:self._n_robot + self._n_scene],
+                                scratch=self._scene_scratch)
         dq = self.model(self.xyz, self.q_norm)
         lib.call("mpx_joint_step", lib.ptr(self.q_norm), lib.ptr(dq), lib.ptr(self.limits), self.B,
                  lib.ptr(self.q_norm), lib.ptr(self.q), lib.ptr(self.done))

@@ -179,7 +179,7 @@ def sample_scene_clouds_host(scn: Dict[str, np.ndarray], num_points: int, seed: 
 
 
 def sample_scene_clouds(prims: Dict[str, torch.Tensor], num_points: int, seed: int, out: Optional[torch.Tensor] = None,
-                        write_label: bool = False, return_aux: bool = False):
+                        write_label: bool = False, return_aux: bool = False, scratch: Optional[tuple] = None):
     """Device-side batched ``construct_mixed_point_cloud`` (geometry.py:571-608; csrc/scene.hip).
 
     ``prims``: cuboid_{centers,dims,quats} [B,M1,*], cylinder_{centers,radii,heights,quats} [B,M2,*] on the
@@ -199,9 +199,11 @@ def sample_scene_clouds(prims: Dict[str, torch.Tensor], num_points: int, seed: i
     if out is None:
         out = torch.empty((B, num_points, 4 if write_label else 3), dtype=torch.float32, device=dev)
     assert out.ndim == 3 and out.size(0) == B and out.size(1) >= num_points and out.stride(2) == 1
-    assign = torch.empty((B, num_points), dtype=torch.int16, device=dev)
-    labels = torch.zeros((B, M1 + M2), dtype=torch.uint8, device=dev)
-    nobs = torch.zeros(B, dtype=torch.int32, device=dev)
+    if scratch is None:  # (assign, labels, nobs): callers that re-render every step keep them
+        scratch = (torch.empty((B, num_points), dtype=torch.int16, device=dev),
+                   torch.zeros((B, M1 + M2), dtype=torch.uint8, device=dev),
+                   torch.zeros(B, dtype=torch.int32, device=dev))
+    assign, labels, nobs = scratch
     for b0 in range(0, B, 65535):
         nb = min(65535, B - b0)
         sl = slice(b0, b0 + nb)

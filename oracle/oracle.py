@@ -440,6 +440,58 @@ def policy_forward(sd: Dict[str, np.ndarray], pc, q) -> Tuple[np.ndarray, dict]:
     return x, aux
 
 
+def policy_forward_torch(sd, pc, q):
+    """Differentiable restatement of MotionPolicyNetwork.forward (model.py:75-91, 409-426) for gradient checks.
+    ``sd``: name -> torch CPU tensor (float64 leaves with requires_grad); pc np [B,N,4]; q torch [B,7].
+    Sampling / neighbour indices come from the C restatement (they carry no gradient); every neighbourhood
+    keeps its nsample padded slots like the reference."""
+    import torch
+    import torch.nn.functional as F
+
+    pc = _f(pc)
+    dt = q.dtype
+    B = pc.shape[0]
+    bi = torch.arange(B)[:, None]
+
+    def sa(xyz_np, feat, npoint, radius, nsample, i):
+        fidx = fps(xyz_np, npoint)
+        new_np = gather_points(xyz_np, fidx)
+        bidx = torch.as_tensor(ball_query(new_np, xyz_np, radius, nsample)).long()  # [B,np,ns]
+        xyz_t, new_t = torch.as_tensor(xyz_np, dtype=dt), torch.as_tensor(new_np, dtype=dt)
+        bb = bi[:, :, None]
+        h = torch.cat((xyz_t[bb, bidx] - new_t[:, :, None, :], feat[bb, bidx]), dim=-1)
+        for k in (0, 2, 4):
+            w = sd[f"point_cloud_encoder.SA_modules.{i}.mlps.0.{k}.weight"]
+            h = torch.relu(F.linear(h, w.view(w.shape[0], -1), sd[f"point_cloud_encoder.SA_modules.{i}.mlps.0.{k}.bias"]))
+        return new_np, h.max(dim=2).values
+
+    xyz = np.ascontiguousarray(pc[..., :3])
+    xyz1, f1 = sa(xyz, torch.as_tensor(pc[..., 3:], dtype=dt), 512, 0.05, 128, 0)
+    xyz2, f2 = sa(xyz1, f1, 128, 0.3, 128, 1)
+    h = torch.cat((torch.as_tensor(xyz2, dtype=dt), f2), dim=-1)
+    for k in (0, 2, 4):
+        w = sd[f"point_cloud_encoder.SA_modules.2.mlps.0.{k}.weight"]
+        h = torch.relu(F.linear(h, w.view(w.shape[0], -1), sd[f"point_cloud_encoder.SA_modules.2.mlps.0.{k}.bias"]))
+    x = h.max(dim=1).values
+    p = "point_cloud_encoder.fc_layer."
+    x = F.linear(x, sd[p + "0.weight"], sd[p + "0.bias"])
+    x = F.leaky_relu(F.group_norm(x, 16, sd[p + "1.weight"], sd[p + "1.bias"]))
+    x = F.linear(x, sd[p + "3.weight"], sd[p + "3.bias"])
+    x = F.leaky_relu(F.group_norm(x, 16, sd[p + "4.weight"], sd[p + "4.bias"]))
+    enc = F.linear(x, sd[p + "6.weight"], sd[p + "6.bias"])
+    x = q
+    for k in (0, 2, 4, 6, 8):
+        x = F.linear(x, sd[f"feature_encoder.{k}.weight"], sd[f"feature_encoder.{k}.bias"])
+        if k != 8:
+            x = F.leaky_relu(x)
+    x = torch.cat((enc, x), dim=1)
+    for k in (0, 2, 4, 6):
+        x = F.linear(x, sd[f"decoder.{k}.weight"], sd[f"decoder.{k}.bias"])
+        if k != 6:
+            x = F.leaky_relu(x)
+    return x
+
+
 def unnormalize(q, limits) -> np.ndarray:
     """utils.py:207-209 with limits (-1, 1)."""
     q = _f(q)

@@ -1,0 +1,125 @@
+"""Row N1: the differentiable forward + training_step of the engine vs a float64 torch-autograd oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+NAMES = ("cuboid_centers", "cuboid_dims", "cuboid_quats", "cylinder_centers", "cylinder_radii", "cylinder_heights",
+         "cylinder_quats")
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def small_batch(B, seed):
+    from mpinets_amd.scenes import make_problem_batch
+
+    prob = make_problem_batch(B, seed=seed, device=dev(), kinds=("tabletop", "cubby"), M1=12, M2=8)
+    rng = np.random.default_rng(seed)
+    sup = torch.clamp(prob["q_norm"] + torch.tensor(rng.normal(scale=0.05, size=(B, 7)), dtype=torch.float32,
+                                                    device=dev()), -1, 1)
+    batch = {"xyz": prob["xyz"], "configuration": prob["q_norm"], "supervision": sup}
+    batch.update({k: prob[k] for k in NAMES})
+    return batch
+
+
+def test_segment_ops_match_torch():
+    from mpinets_amd.pointnet2 import _SegmentMax
+
+    g = torch.Generator(device="cpu").manual_seed(0)
+    lens = torch.randint(1, 40, (50,), generator=g)
+    off = torch.zeros(51, dtype=torch.int64)
+    off[1:] = torch.cumsum(lens, 0)
+    y = torch.randn(int(off[-1]), 96, generator=g)
+    y[3] = y[2]  # a tie inside one segment: first row wins
+    yd = y.to(dev()).requires_grad_(True)
+    out = _SegmentMax.apply(yd, off.to(dev()), 50)
+    w = torch.randn(50, 96, generator=g)
+    (out * w.to(dev())).sum().backward()
+    yc = y.clone().requires_grad_(True)
+    ref = torch.stack([yc[off[i]:off[i + 1]].max(0).values for i in range(50)])
+    (ref * w).sum().backward()
+    assert torch.equal(out.cpu(), ref.detach())
+    assert torch.equal(yd.grad.cpu(), yc.grad)
+
+
+def test_training_forward_equals_inference_forward():
+    """Same weights, same cloud: the differentiable path and the fused engine path agree to fp32 round-off."""
+    from mpinets_amd.model import MotionPolicyNetwork
+
+    torch.manual_seed(0)
+    mdl = MotionPolicyNetwork().to(dev())
+    batch = small_batch(3, 1)
+    mdl.train()
+    y_train = mdl(batch["xyz"], batch["configuration"])
+    assert y_train.requires_grad
+    mdl.eval()
+    with torch.no_grad():
+        y_inf = mdl(batch["xyz"], batch["configuration"])
+    np.testing.assert_allclose(y_train.detach().cpu().numpy(), y_inf.cpu().numpy(), atol=1e-5)  # north-star tolerance
+
+
+def test_training_step_gradients_match_oracle(oracle):
+    from mpinets_amd import franka_tables as ft
+    from mpinets_amd.model import TrainingMotionPolicyNetwork
+
+    torch.manual_seed(1)
+    mdl = TrainingMotionPolicyNetwork(num_robot_points=2048, point_match_loss_weight=1.0, collision_loss_weight=5.0)
+    mdl = mdl.to(dev()).train()
+    B = 2
+    batch = small_batch(B, 3)
+    loss = mdl.training_step(batch, 0)
+    loss.backward()
+    assert set(mdl.logged) == {"point_match_loss", "collision_loss", "val_loss"}
+
+    # ---- oracle: float64 autograd over the restated network + restated losses
+    sd = {k: v.detach().cpu().double().requires_grad_(True) for k, v in mdl.state_dict().items()}
+    q = batch["configuration"].cpu().double()
+    dq = oracle.policy_forward_torch(sd, batch["xyz"].cpu().numpy(), q)
+    y = torch.clamp(q + dq, -1, 1)
+    lim = torch.tensor(ft.JOINT_LIMITS_REAL, dtype=torch.float64)
+    unnorm = lambda x: (x + 1) * (lim[:, 1] - lim[:, 0]) / 2 + lim[:, 0]
+    pts, link = ft.link_point_table(4096, with_base_link=False)
+    sub = mdl.loss_fun.fk_sampler._fixed.cpu().numpy()
+    cloud = oracle.robot_cloud_torch(unnorm(y), pts, link, sub)
+    target = oracle.robot_cloud_torch(unnorm(batch["supervision"].cpu().double()), pts, link, sub)
+    npb = {k: batch[k].cpu().numpy() for k in NAMES}
+    cf = torch.tensor(oracle.inv_frames_4x4(npb["cuboid_centers"], npb["cuboid_quats"]), dtype=torch.float64)
+    yf = torch.tensor(oracle.inv_frames_4x4(npb["cylinder_centers"], npb["cylinder_quats"]), dtype=torch.float64)
+    t64 = lambda k: torch.tensor(npb[k], dtype=torch.float64)
+    coll = oracle.collision_loss_torch(cloud, cf, t64("cuboid_dims"), yf, t64("cylinder_radii")[..., 0],
+                                       t64("cylinder_heights")[..., 0])
+    pm = oracle.point_match_loss_torch(cloud, target)
+    ref_loss = pm + 5.0 * coll
+    ref_loss.backward()
+    assert abs(loss.item() - ref_loss.item()) < 1e-5
+    assert abs(mdl.logged["collision_loss"].item() - coll.item()) < 1e-6
+    worst = 0.0
+    for name, p in mdl.named_parameters():
+        ref = sd[name].grad
+        assert p.grad is not None and ref is not None, name
+        scale = ref.abs().max().item()
+        err = (p.grad.cpu().double() - ref).abs().max().item()
+        assert err <= 2e-4 * scale + 1e-9, (name, err, scale)
+        worst = max(worst, err / (scale + 1e-30))
+    print("worst relative gradient error", worst)
+
+
+def test_optimizer_steps_reduce_the_loss():
+    from mpinets_amd.model import TrainingMotionPolicyNetwork
+
+    torch.manual_seed(2)
+    mdl = TrainingMotionPolicyNetwork(2048, 1.0, 1.0).to(dev()).train()
+    opt = torch.optim.Adam(mdl.parameters(), lr=3e-4)
+    batch = small_batch(4, 5)
+    losses = []
+    for _ in range(6):
+        opt.zero_grad(set_to_none=True)
+        loss = mdl.training_step(batch, 0)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(mdl.parameters(), 1.0)  # run_training.py:112 gradient_clip_val=1.0
+        opt.step()
+        losses.append(loss.item())
+    assert losses[-1] < losses[0], losses
