@@ -81,3 +81,34 @@ def gather_to_rank0(t: torch.Tensor) -> Optional[torch.Tensor]:
     bufs = [torch.empty_like(t) for _ in range(ws)] if rank == 0 else None
     dist.gather(t, bufs, dst=0)
     return torch.cat(bufs, dim=0) if rank == 0 else None
+
+
+# ---- training only (row N1): the one collective of the code base ----------------------------------------
+def allreduce_gradients(params, bucket_bytes: int = 64 << 20) -> int:
+    """Average ``p.grad`` over the ranks (data-parallel training; the reference uses Lightning's DDP,
+    run_training.py:71-77).  Gradients are packed into flat buckets of ``bucket_bytes`` and each bucket is
+    one all-reduce: xGMI is point-to-point (a ring all-reduce is bound by one link, ~153 GB/s per direction),
+    so a few large messages beat one call per tensor -- the 19 M parameters (76 MB fp32) go out in two
+    buckets.  Returns the number of collectives issued (0 for a single process)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return 0
+    ws = dist.get_world_size()
+    grads = [p.grad for p in params if p.grad is not None]
+    calls, i = 0, 0
+    while i < len(grads):
+        j, size = i, 0
+        while j < len(grads) and (j == i or size + grads[j].numel() * grads[j].element_size() <= bucket_bytes):
+            size += grads[j].numel() * grads[j].element_size()
+            j += 1
+        bucket = grads[i:j]
+        flat = torch.cat([g.reshape(-1) for g in bucket])
+        comm = flat if dist.get_backend() == "nccl" else flat.cpu()
+        dist.all_reduce(comm, op=dist.ReduceOp.SUM)
+        comm = comm.to(flat.device) / ws
+        off = 0
+        for g in bucket:
+            g.copy_(comm[off:off + g.numel()].view_as(g))
+            off += g.numel()
+        calls += 1
+        i = j
+    return calls

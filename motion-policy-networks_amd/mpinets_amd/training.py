@@ -1,0 +1,30 @@
+"""Minimal training driver for ``TrainingMotionPolicyNetwork`` (row N1).
+
+The reference hands the model to a PyTorch-Lightning ``Trainer`` (run_training.py:58-117: Adam from
+``configure_optimizers``, ``gradient_clip_val=1.0``, DDP over the GPUs).  Lightning, logging and
+checkpoint callbacks are out of scope; this module is the numerical core of one
+optimisation step so the new kernels can be driven end to end: forward + losses + backward on the
+engine, bucketed gradient all-reduce over RCCL (``shard.allreduce_gradients``), clip, optimizer step.
+"""
+from __future__ import annotations
+
+from typing import Dict
+
+import torch
+
+from . import shard
+
+
+def train_step(model, optimizer: torch.optim.Optimizer, batch: Dict[str, torch.Tensor], batch_idx: int = 0,
+               gradient_clip_val: float = 1.0) -> torch.Tensor:
+    """One optimisation step; returns the detached loss of this rank's batch."""
+    model.train()
+    optimizer.zero_grad(set_to_none=True)
+    loss = model.training_step(batch, batch_idx)
+    loss.backward()
+    params = [p for p in model.parameters() if p.requires_grad]
+    shard.allreduce_gradients(params)
+    if gradient_clip_val is not None:
+        torch.nn.utils.clip_grad_norm_(params, gradient_clip_val)
+    optimizer.step()
+    return loss.detach()
