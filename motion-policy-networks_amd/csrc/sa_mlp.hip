@@ -283,14 +283,21 @@ __global__ void __launch_bounds__(256, 2)
 // the running maximum to the output row whenever the (wave-uniform) query changes.
 // One wave per workgroup: waves carry different numbers of tiles, and a multi-wave workgroup would hold
 // its SIMD slots until its slowest wave retires.
-template <int CF, int C1, int C2, int C3, int Q>
+//
+// FACT (factored first layer): W1.[p_j - c_i ; f_j] + b1 = (W1.[p_j ; f_j]) - (W1x.c_i - b1) is linear, so the
+// caller evaluates the first term once per POINT (`pre` [B*N, C1], a plain GEMM over the points) and the second
+// once per QUERY (`ctr` [B*npoint, C1]); the kernel then starts at relu(pre[j] - ctr[i]) -- a gather, a
+// subtraction -- and skips the layer-1 MFMAs of every (query, neighbour) row (15 % of SA2's matrix work).
+// Same arithmetic up to the order of that one sum (tolerance-level, not bit-level, vs the direct form).
+template <int CF, int C1, int C2, int C3, int Q, bool FACT>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CF == 1 ? 4 : 2, CF == 1 ? 4 : 2)))
     sa_mlp_packed_kernel(const float *__restrict__ xyz, int stride, const float *__restrict__ new_xyz,
                          int new_stride, const float *__restrict__ feat, int feat_stride,
                          const int32_t *__restrict__ idx, const int32_t *__restrict__ cnt, int64_t n_query, int N,
                          int npoint, int nsample, const float *__restrict__ wpack, float *__restrict__ out,
-                         int out_stride, int bpe) {
+                         int out_stride, int bpe, const float *__restrict__ pre_rows, const float *__restrict__ ctr) {
   using Cfg = SaCfg<CF, C1, C2, C3>;
+  __shared__ float ctr_s[FACT ? Q * C1 : 1];
   static_assert(Q >= 1 && Q <= 32, "queries per wave");
   const int lane = threadIdx.x & 63;
   const int half = lane >> 5, col = lane & 31;
@@ -304,6 +311,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CF == 1
   }
   const int64_t q0 = wg * Q;
   const int nq = (int)min((int64_t)Q, n_query - q0);
+  if constexpr (FACT) {  // this wave's per-query terms -> LDS (read back per row at every tile start)
+#pragma unroll
+    for (int i = threadIdx.x; i < Q * C1 / 4; i += 64) {
+      const int qi = (4 * i) / C1;
+      if (qi < nq)
+        *reinterpret_cast<float4 *>(ctr_s + 4 * i) = *reinterpret_cast<const float4 *>(ctr + q0 * C1 + 4 * i);
+    }
+    __syncthreads();
+  }
 
   // lane i < nq: distinct-neighbour count of query q0+i, its row count (multiple of 4) and row offset
   int my_cnt = 0, my_rows = 0;
@@ -364,11 +380,23 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CF == 1
   };
   // raw layer-1 inputs of one row: (x - centre) and this lane-half's feature chunk (plain locals: an
   // array inside a struct that is passed around by reference is not promoted to registers)
-  constexpr int NF = CF == 1 ? 1 : CF / 2;
+  constexpr int NF = FACT ? C1 / 2 : (CF == 1 ? 1 : CF / 2);
   float raw_dx, raw_dy, raw_dz, raw_f[NF];
   auto gather = [&](int qi, int k) __attribute__((always_inline)) {
     const int64_t qg = q0 + qi;
     const int64_t b = qg / npoint;
+    if constexpr (FACT) {  // this lane-half's 4-channel groups of the point's pre-activation row
+      const float *pa = pre_rows + (b * N + k) * (int64_t)C1 + 4 * half;
+#pragma unroll
+      for (int i = 0; i < C1 / 8; ++i) {
+        const float4 v = *reinterpret_cast<const float4 *>(pa + 8 * i);
+        raw_f[4 * i + 0] = v.x;
+        raw_f[4 * i + 1] = v.y;
+        raw_f[4 * i + 2] = v.z;
+        raw_f[4 * i + 3] = v.w;
+      }
+      return;
+    }
     const float *ctr = new_xyz + qg * new_stride;
     const float *pp = xyz + (b * N + k) * (int64_t)stride;
     const float *f = feat + (b * N + k) * (int64_t)feat_stride;
@@ -408,13 +436,27 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CF == 1
     asm volatile("" : "+s"(w1o), "+s"(w2o), "+s"(w3o), "+s"(b1o), "+s"(b2o));
 
     float x0[Cfg::KS0];
-    x0[0] = half ? raw_dy : raw_dx;
-    if (CF == 1) {
-      x0[1] = half ? raw_f[0] : raw_dz;
-    } else {
-      x0[1] = half ? 0.0f : raw_dz;
+    f32x16 a1[Cfg::OT1];
+    if constexpr (FACT) {
+      // register r of tile ot = channel 32*ot + 8*(r>>2) + 4*half + (r&3) = group i = 4*ot + (r>>2) of raw_f
+      const float *cq = ctr_s + q_cur * C1 + 4 * half;
 #pragma unroll
-      for (int i = 0; i < CF / 2; ++i) x0[2 + i] = raw_f[i];
+      for (int i = 0; i < C1 / 8; ++i) {
+        const float4 c = *reinterpret_cast<const float4 *>(cq + 8 * i);
+        a1[i >> 2][4 * (i & 3) + 0] = fmaxf(raw_f[4 * i + 0] - c.x, 0.0f);
+        a1[i >> 2][4 * (i & 3) + 1] = fmaxf(raw_f[4 * i + 1] - c.y, 0.0f);
+        a1[i >> 2][4 * (i & 3) + 2] = fmaxf(raw_f[4 * i + 2] - c.z, 0.0f);
+        a1[i >> 2][4 * (i & 3) + 3] = fmaxf(raw_f[4 * i + 3] - c.w, 0.0f);
+      }
+    } else {
+      x0[0] = half ? raw_dy : raw_dx;
+      if (CF == 1) {
+        x0[1] = half ? raw_f[0] : raw_dz;
+      } else {
+        x0[1] = half ? 0.0f : raw_dz;
+#pragma unroll
+        for (int i = 0; i < CF / 2; ++i) x0[2 + i] = raw_f[i];
+      }
     }
     const int q_tile = q_cur;  // which query this lane's row of the current tile belongs to
     const int q_gather = q_next, k_gather = k_next;
@@ -425,20 +467,21 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CF == 1
       k_next = idx[(q0 + q_next) * nsample + off];
     }
 
-    f32x16 a1[Cfg::OT1];
+    if constexpr (!FACT) {
 #pragma unroll
-    for (int ot = 0; ot < Cfg::OT1; ++ot) a1[ot] = bias_tile(wrsrc, b1o, ot, half);
-    stream_weights<Cfg::S1 / 4>(wrsrc, wvoff, w1o, [&](int g, const float4 &w) __attribute__((always_inline)) {
+      for (int ot = 0; ot < Cfg::OT1; ++ot) a1[ot] = bias_tile(wrsrc, b1o, ot, half);
+      stream_weights<Cfg::S1 / 4>(wrsrc, wvoff, w1o, [&](int g, const float4 &w) __attribute__((always_inline)) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int s = 4 * g + u, t = s / Cfg::OT1, ot = s % Cfg::OT1;
-        a1[ot] = mfma32(comp(w, u), x0[t], a1[ot]);
-      }
-    });
+        for (int u = 0; u < 4; ++u) {
+          const int s = 4 * g + u, t = s / Cfg::OT1, ot = s % Cfg::OT1;
+          a1[ot] = mfma32(comp(w, u), x0[t], a1[ot]);
+        }
+      });
 #pragma unroll
-    for (int ot = 0; ot < Cfg::OT1; ++ot)
+      for (int ot = 0; ot < Cfg::OT1; ++ot)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) a1[ot][r] = fmaxf(a1[ot][r], 0.0f);
+        for (int r = 0; r < 16; ++r) a1[ot][r] = fmaxf(a1[ot][r], 0.0f);
+    }
 
     f32x16 a2[Cfg::OT2];
 #pragma unroll
@@ -508,9 +551,9 @@ static int launch_sa(const float *xyz, int stride, const float *new_xyz, int new
     const int64_t nw = (nq + Q - 1) / Q;
     // whole environments per XCD when the grid is regular (npoint % Q == 0, B % 8 == 0)
     const int bpe = (npoint % Q == 0 && B % 8 == 0) ? npoint / Q : 0;
-    hipLaunchKernelGGL((sa_mlp_packed_kernel<CF, C1, C2, C3, Q>), dim3((unsigned)nw), dim3(64), 0,
+    hipLaunchKernelGGL((sa_mlp_packed_kernel<CF, C1, C2, C3, Q, false>), dim3((unsigned)nw), dim3(64), 0,
                        mpx_s(stream), xyz, stride, new_xyz, new_stride, feat, feat_stride, idx, cnt, nq, N, npoint,
-                       nsample, wpack, out, out_stride, bpe);
+                       nsample, wpack, out, out_stride, bpe, nullptr, nullptr);
   } else {
     hipLaunchKernelGGL((sa_mlp_kernel<CF, C1, C2, C3>), dim3((unsigned)((nq + 3) / 4)), dim3(256), 0,
                        mpx_s(stream), xyz, stride, new_xyz, new_stride, feat, feat_stride, idx, nq, N, npoint,
@@ -542,6 +585,28 @@ MPX_EXPORT int mpx_sa_mlp(const float *xyz, int stride, const float *new_xyz, in
   return launch_sa<a, b, c, d>(xyz, stride, new_xyz, new_stride, feat, feat_stride, idx, cnt, B, N, npoint, nsample, wpack, out, out_stride, stream)
   SA_DISPATCH(CALL)
 #undef CALL
+}
+
+MPX_EXPORT int mpx_sa_mlp_factored(const float *pre, const float *ctr, const int32_t *idx, const int32_t *cnt, int B,
+                                   int N, int npoint, int nsample, const float *wpack, int C, int c1, int c2, int c3,
+                                   float *out, int out_stride, mpx_stream_t stream) {
+  MPX_REQUIRE(C == 64 && c1 == 128 && c2 == 128 && c3 == 256,
+              "mpx_sa_mlp_factored: built for the (64+3, 128, 128, 256) module (C=%d, %d, %d, %d)", C, c1, c2, c3);
+  MPX_REQUIRE(B >= 0 && N >= 1 && npoint >= 0 && nsample > 0, "mpx_sa_mlp_factored: bad size");
+  MPX_REQUIRE(pre && ctr && idx && cnt, "mpx_sa_mlp_factored: NULL operand (hit counts are required)");
+  MPX_REQUIRE(out_stride >= c3, "mpx_sa_mlp_factored: bad stride");
+  MPX_REQUIRE((((uintptr_t)wpack | (uintptr_t)pre | (uintptr_t)ctr) & 15) == 0,
+              "mpx_sa_mlp_factored: operands must be 16-byte aligned");
+  if (B == 0 || npoint == 0) return 0;
+  const int64_t nq = (int64_t)B * npoint;
+  MPX_REQUIRE(nq / 4 + 1 < ((int64_t)1 << 31), "mpx_sa_mlp_factored: too many query points");
+  constexpr int Q = 8;
+  const int64_t nw = (nq + Q - 1) / Q;
+  const int bpe = (npoint % Q == 0 && B % 8 == 0) ? npoint / Q : 0;
+  hipLaunchKernelGGL((sa_mlp_packed_kernel<64, 128, 128, 256, Q, true>), dim3((unsigned)nw), dim3(64), 0,
+                     mpx_s(stream), nullptr, 0, nullptr, 0, nullptr, 0, idx, cnt, nq, N, npoint, nsample, wpack, out,
+                     out_stride, bpe, pre, ctr);
+  MPX_LAUNCH_CHECK("mpx_sa_mlp_factored");
 }
 
 MPX_EXPORT int64_t mpx_sa_pack_size(int C, int c1, int c2, int c3) {

@@ -19,7 +19,8 @@ import torch
 from torch import nn
 
 from . import _lib
-from .pointnet2 import PRECISIONS, PointnetSAModule, SAWeights, groupnorm_leaky, launch_sa, linear, sa_mlp_fused
+from .pointnet2 import (FACTORED_SHAPE, PRECISIONS, PointnetSAModule, SAWeights, groupnorm_leaky, launch_sa, linear,
+                        sa_mlp_factored, sa_mlp_fused)
 from .utils import unnormalize_franka_joints
 
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
@@ -149,7 +150,10 @@ class MPiNetsPointNet(nn.Module):
                  sa1.nsample, lib.ptr(nbr1), lib.ptr(cnt1))
         c1 = sa1.convs()
         w1 = sa1._packed.get(c1, 1, sa1.precision)
-        f1 = torch.empty((B, sa1.npoint, c1[-1].out_channels), dtype=torch.float32, device=dev)
+        # SA1 output rows carry [f1 (64) | xyz1 (3) | 0]: the operand of SA2's per-point first-layer GEMM
+        C1o = c1[-1].out_channels
+        f1buf = torch.empty((B, sa1.npoint, C1o + 4), dtype=torch.float32, device=dev)
+        f1 = f1buf[:, :, :C1o]
         launch_sa(sa1.precision, lib.ptr(pc), 4, lib.ptr(xyz1), 3, lib.ptr(pc) + 12, 4, 1, nbr1,
                   cnt1 if sa1.elide_padding else None, B, N, sa1.npoint, sa1.nsample, w1,
                   tuple(c.out_channels for c in c1), lib.ptr(f1), f1.stride(1))
@@ -164,10 +168,17 @@ class MPiNetsPointNet(nn.Module):
         cnt2 = torch.empty((B, sa2.npoint), dtype=torch.int32, device=dev)
         lib.call("mpx_ball_query", lib.ptr(sa3_in), K3, lib.ptr(xyz1), 3, B, sa1.npoint, sa2.npoint,
                  float(sa2.radius), sa2.nsample, lib.ptr(nbr2), lib.ptr(cnt2))
-        w2 = sa2._packed.get(c2, f1.size(2), sa2.precision)
-        launch_sa(sa2.precision, lib.ptr(xyz1), 3, lib.ptr(sa3_in), K3, lib.ptr(f1), f1.stride(1), f1.size(2), nbr2,
-                  cnt2 if sa2.elide_padding else None, B, sa1.npoint, sa2.npoint, sa2.nsample, w2,
-                  tuple(c.out_channels for c in c2), lib.ptr(sa3_in) + 12, K3)
+        if sa2.precision == "fp32" and sa2.factored and (C1o,) + tuple(c.out_channels for c in c2) == FACTORED_SHAPE:
+            f1buf[:, :, C1o:C1o + 3] = xyz1
+            f1buf[:, :, C1o + 3] = 0
+            sa_mlp_factored(f1buf.view(B * sa1.npoint, C1o + 4), sa3_in.view(B * sa2.npoint, K3)[:, :4], nbr2,
+                            cnt2 if sa2.elide_padding else torch.full_like(cnt2, sa2.nsample), sa2._packed, c2, C1o,
+                            sa1.npoint, lib.ptr(sa3_in) + 12, K3)
+        else:
+            w2 = sa2._packed.get(c2, C1o, sa2.precision)
+            launch_sa(sa2.precision, lib.ptr(xyz1), 3, lib.ptr(sa3_in), K3, lib.ptr(f1), f1.stride(1), C1o, nbr2,
+                      cnt2 if sa2.elide_padding else None, B, sa1.npoint, sa2.npoint, sa2.nsample, w2,
+                      tuple(c.out_channels for c in c2), lib.ptr(sa3_in) + 12, K3)
         # ---- SA3 (group-all): three GEMMs over B*128 rows + max over each environment's rows ------------
         c3 = sa3.convs()
         h = sa3_in.view(B * sa2.npoint, K3)
@@ -222,6 +233,13 @@ class MotionPolicyNetwork(nn.Module):
         assert precision in PRECISIONS, precision
         for sa in self.point_cloud_encoder.SA_modules:
             sa.precision = precision
+        return self
+
+    def set_factored(self, on: bool) -> "MotionPolicyNetwork":
+        """Evaluate SA2's first layer per point / per query (``mpx_sa_mlp_factored``, default on) or per
+        (query, neighbour) row like the reference's op order (``mpx_sa_mlp``); the results agree to ~1e-7."""
+        for sa in self.point_cloud_encoder.SA_modules:
+            sa.factored = bool(on)
         return self
 
     def set_elide_padding(self, on: bool) -> "MotionPolicyNetwork":

@@ -103,6 +103,21 @@ class SAWeights:
 
     def __init__(self):
         self.packs = {}
+        self._fact = None
+
+    def factored(self, convs: List[nn.Conv2d], C: int):
+        """First layer split for ``mpx_sa_mlp_factored``: (w_point [c1, Kp] over rows [feat | xyz | 0],
+        w_centre [c1, 4] over rows [xyz | 0], -b1)."""
+        c0 = convs[0]
+        ver = (c0.weight._version, c0.bias._version, c0.weight.data_ptr())
+        if self._fact is None or self._fact[0] != ver:
+            w = c0.weight.detach().reshape(c0.out_channels, -1).float()
+            assert w.size(1) == 3 + C
+            z = lambda n: torch.zeros((w.size(0), n), dtype=torch.float32, device=w.device)
+            wp = torch.cat((w[:, 3:], w[:, :3], z((-(3 + C)) % 4)), dim=1).contiguous()
+            wc = torch.cat((w[:, :3], z(1)), dim=1).contiguous()
+            self._fact = (ver, (wp, wc, (-c0.bias.detach().float()).contiguous()))
+        return self._fact[1]
 
     def get(self, convs: List[nn.Conv2d], C: int, precision: str = "fp32") -> torch.Tensor:
         assert precision in PRECISIONS, precision
@@ -167,6 +182,23 @@ def sa_mlp_fused(xyz: torch.Tensor, new_xyz: torch.Tensor, feat: torch.Tensor, f
     launch_sa(precision, _lib.ptr(xyz), S, _lib.ptr(new_xyz), new_xyz.stride(1), _lib.ptr(feat), feat_stride, C, idx, cnt,
               B, N, npoint, nsample, wpack, widths, _lib.ptr(out), out.stride(1))
     return out
+
+
+def sa_mlp_factored(point_rows: torch.Tensor, centre_rows: torch.Tensor, idx: torch.Tensor, cnt: torch.Tensor,
+                    packed: "SAWeights", convs: List[nn.Conv2d], C: int, N: int, out_ptr: int, out_stride: int) -> None:
+    """The (64+3,128,128,256) module with its first layer evaluated per point / per query instead of per
+    (query, neighbour) row (``mpx_sa_mlp_factored``).  ``point_rows`` [B*N, Kp] = [feat | xyz | 0] rows,
+    ``centre_rows`` [B*npoint, 4] = [xyz | anything finite] rows (row strides free)."""
+    B, npoint, nsample = idx.shape
+    wp, wc, nb1 = packed.factored(convs, C)
+    pre = linear(point_rows, wp, None)
+    ctr = linear(centre_rows, wc, nb1)
+    c1, c2, c3 = (c.out_channels for c in convs)
+    _lib.call("mpx_sa_mlp_factored", _lib.ptr(pre), _lib.ptr(ctr), _lib.ptr(idx), _lib.ptr(cnt), B, N, npoint, nsample,
+              _lib.ptr(packed.get(convs, C, "fp32")), C, c1, c2, c3, out_ptr, out_stride)
+
+
+FACTORED_SHAPE = (64, 128, 128, 256)
 
 
 # ---- module -------------------------------------------------------------------------------------------
@@ -249,6 +281,8 @@ class PointnetSAModule(nn.Module):
         self.precision = precision  # "fp32" (exact) | "bf16x3" (split-bf16 matrix cores, ~3e-7 on the policy output)
         # skip neighbourhood tiles that hold only ball-query padding (bit-identical output, see launch_sa)
         self.elide_padding = True
+        # evaluate the first layer per point / per query where the kernel supports it (fp32, SA2 shape)
+        self.factored = True
         if bn:
             raise NotImplementedError("bn=True is not used by the reference (model.py:366-383)")
         assert use_xyz, "the reference relies on use_xyz=True (3 extra input channels)"
@@ -281,6 +315,13 @@ class PointnetSAModule(nn.Module):
             if self.training and torch.is_grad_enabled():
                 fpm = features.transpose(1, 2).contiguous() if features.requires_grad else feat_pm
                 out = sa_module_train(convs, xyz, 3, new_xyz, 3, fpm, C, C, nbr, cnt, (B, N, self.npoint, self.nsample))
+                return new_xyz, out.transpose(1, 2).contiguous()
+            if self.precision == "fp32" and self.factored and (C,) + tuple(c.out_channels for c in convs) == FACTORED_SHAPE:
+                full = cnt if self.elide_padding else torch.full_like(cnt, self.nsample)
+                rows = torch.cat((feat_pm, xyz, torch.zeros_like(xyz[:, :, :1])), dim=2).view(B * N, C + 4)
+                ctr_rows = torch.nn.functional.pad(new_xyz, (0, 1)).view(B * self.npoint, 4)
+                out = torch.empty((B, self.npoint, convs[-1].out_channels), dtype=torch.float32, device=xyz.device)
+                sa_mlp_factored(rows, ctr_rows, nbr, full, self._packed, convs, C, N, _lib.ptr(out), out.stride(1))
                 return new_xyz, out.transpose(1, 2).contiguous()
             wpack = self._packed.get(convs, C, self.precision)
             out = sa_mlp_fused(xyz, new_xyz, feat_pm, C, C, nbr, wpack, tuple(c.out_channels for c in convs),

@@ -260,6 +260,41 @@ def test_padding_elision_is_bit_identical(precision):
     assert c1.min() >= 1 and c2.max() <= 128
 
 
+def test_factored_first_layer_matches_direct_form(oracle):
+    """SA2's first layer per point / per query (mpx_sa_mlp_factored) vs per (query, neighbour) row (mpx_sa_mlp):
+    same result up to the rounding of one re-associated sum, both within the north-star 1e-5 of the oracle."""
+    from mpinets_amd.model import MotionPolicyNetwork
+    from mpinets_amd.pointnet2 import PointnetSAModule
+    from mpinets_amd.scenes import make_problem_batch
+
+    torch.manual_seed(7)
+    mdl = MotionPolicyNetwork().to(dev()).eval()
+    prob = make_problem_batch(3, seed=4, device=dev(), kinds=("tabletop", "dresser"), M1=40, device_clouds=True)
+    a, b = {}, {}
+    with torch.no_grad():
+        dq_f = mdl.set_factored(True)(prob["xyz"], prob["q_norm"], aux=a)
+        dq_d = mdl.set_factored(False)(prob["xyz"], prob["q_norm"], aux=b)
+    mdl.set_factored(True)
+    f2f, f2d = a["sa3_in"][:, :, 3:259], b["sa3_in"][:, :, 3:259]
+    assert not torch.equal(f2f, f2d)  # two different kernels really ran
+    assert (f2f - f2d).abs().max().item() <= 2e-6 * f2d.abs().max().item()
+    sd = {k: v.detach().cpu().numpy() for k, v in mdl.state_dict().items()}
+    ref, _ = oracle.policy_forward(sd, prob["xyz"].cpu().numpy(), prob["q_norm"].cpu().numpy())
+    assert np.abs(dq_f.cpu().numpy() - ref).max() < 1e-5 and np.abs(dq_d.cpu().numpy() - ref).max() < 1e-5
+    print("factored vs oracle %.2e, direct vs oracle %.2e" % (np.abs(dq_f.cpu().numpy() - ref).max(),
+                                                            np.abs(dq_d.cpu().numpy() - ref).max()))
+    # the module-level API (reference shapes) takes the same route
+    sa2 = mdl.point_cloud_encoder.SA_modules[1]
+    xyz1, f1 = a["xyz1"].contiguous(), a["f1"].transpose(1, 2).contiguous()
+    with torch.no_grad():
+        _, o_f = sa2(xyz1, f1)
+        sa2.factored = False
+        _, o_d = sa2(xyz1, f1)
+        sa2.factored = True
+    assert (o_f - o_d).abs().max().item() <= 2e-6 * o_d.abs().max().item()
+    np.testing.assert_allclose(o_f.transpose(1, 2).cpu().numpy(), f2f.cpu().numpy(), rtol=0, atol=1e-6)
+
+
 def test_linear_rowmax_equals_linear_then_rowmax():
     from mpinets_amd import _lib
     from mpinets_amd.pointnet2 import linear
