@@ -125,9 +125,8 @@ __device__ __forceinline__ float comp(const float4 &q, int i) {
 // chunk c+1 is in flight while chunk c feeds the matrix pipe.  The empty asm statements are
 // compiler barriers for memory operations only -- without them hipcc hoists every load of the
 // fully unrolled layer to its top and spills.
-template <int NG, class F>
+template <int NG, int CH = 4, class F>
 __device__ __forceinline__ void stream_weights(__amdgpu_buffer_rsrc_t rsrc, int voff, int base, F &&body) {
-  constexpr int CH = 4;
   constexpr int NC = (NG + CH - 1) / CH;
   float4 buf[2][CH];
 #pragma unroll
