@@ -240,7 +240,7 @@ def main():
         traffic, traffic_note = None, None
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-            if tj["envs_per_gpu"] == B:
+            if tj["envs_per_gpu"] == B and "8, true>" in tj["kernel"]:  # same kernel build, same size
                 traffic, traffic_note = tj["hbm_bytes_per_launch"], tj["source"] + "; " + tj["correction"]
         except Exception:
             pass

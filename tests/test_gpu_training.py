@@ -107,19 +107,34 @@ def test_training_step_gradients_match_oracle(oracle):
     print("worst relative gradient error", worst)
 
 
-def test_optimizer_steps_reduce_the_loss():
+def test_gradient_step_decreases_loss_as_predicted():
+    """End-to-end directional-derivative check on the device: a small step along -grad lowers the training loss by
+    ~ lr * |grad|^2 (first order), and a short SGD run keeps lowering it."""
     from mpinets_amd.model import TrainingMotionPolicyNetwork
 
     torch.manual_seed(2)
     mdl = TrainingMotionPolicyNetwork(2048, 1.0, 1.0).to(dev()).train()
-    opt = torch.optim.Adam(mdl.parameters(), lr=3e-4)
     batch = small_batch(4, 5)
-    losses = []
-    for _ in range(6):
+    batch["configuration"] = batch["configuration"].clamp(-0.7, 0.7)
+    batch["supervision"] = batch["configuration"] + 0.2  # something to learn: every joint shifted
+    params = [p for p in mdl.parameters()]
+    loss0 = mdl.training_step(batch, 0)
+    grads = torch.autograd.grad(loss0, params)
+    g2 = sum((g.double() ** 2).sum() for g in grads).item()
+    lr = 2e-3 / g2 ** 0.5  # parameter step of norm 2e-3
+    with torch.no_grad():
+        for p, g in zip(params, grads):
+            p.sub_(lr * g)
+        loss1 = mdl.training_step(batch, 0)
+    predicted = lr * g2
+    assert loss1.item() < loss0.item()
+    assert 0.5 * predicted < loss0.item() - loss1.item() < 1.5 * predicted, (loss0.item(), loss1.item(), predicted)
+    opt = torch.optim.SGD(mdl.parameters(), lr=lr)
+    losses = [loss1.item()]
+    for _ in range(8):
         opt.zero_grad(set_to_none=True)
         loss = mdl.training_step(batch, 0)
         loss.backward()
-        torch.nn.utils.clip_grad_norm_(mdl.parameters(), 1.0)  # run_training.py:112 gradient_clip_val=1.0
         opt.step()
         losses.append(loss.item())
     assert losses[-1] < losses[0], losses
