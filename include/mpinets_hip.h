@@ -168,6 +168,22 @@ int mpx_segment_max(const float *y, int C, const int64_t *offsets, int64_t Q, fl
 int mpx_segment_max_grad(const float *grad_out, int grad_stride, const int64_t *arg, int64_t Q, int C,
                          float *grad_y, mpx_stream_t stream);
 
+/* ---- batch assembly from the dataset arrays (row N2; mpinets/data_loader.py:141-280, 390-417) ------- */
+
+/* Per-sample joint quantities of PointCloudBase.get_inputs for a whole batch.  trajectories
+ * [n_traj, L, 7] (the HDF5 `hybrid_solutions` / `global_solutions` array, resident in HBM), traj_idx
+ * int64 [B], timestep int32 [B] (NULL = 0: the validation dataset).  Outputs: q [B,7] = the waypoint
+ * (+ N(0, noise_scale) joint noise clamped to limits when noise_scale > 0; Philox keyed by (seed,
+ * sample)), q_norm = normalize(q), sup_norm (optional) = normalize(waypoint min(t+1, L-1)),
+ * target_pose [B,4,4] / target_pos [B,3] = right_gripper FK of the LAST waypoint.                  */
+int mpx_batch_configs(const float *trajectories, int64_t n_traj, int L, const int64_t *traj_idx,
+                      const int32_t *timestep, const float *limits, float noise_scale, uint64_t seed,
+                      int B, float finger, float *q, float *q_norm, float *sup_norm, float *target_pose,
+                      float *target_pos, mpx_stream_t stream);
+/* dst[b, :] = src[idx[b], :] for rows of row_floats floats (primitive rows of the sampled scenes)  */
+int mpx_gather_rows(const float *src, const int64_t *idx, int B, int row_floats, float *dst,
+                    mpx_stream_t stream);
+
 /* ---- scene point clouds: mpinets/geometry.py:571-608 (construct_mixed_point_cloud), batched ----- */
 
 /* For every environment: area-proportional pool sizes int(p_i*N)+500, N pool slots drawn without

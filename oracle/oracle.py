@@ -212,6 +212,42 @@ def trajectory_metrics(traj, lengths, targets, limits, finger: float = 0.025) ->
     return out
 
 
+# ---------------------------------------------------------------- batch assembly (row N2)
+def batch_configs(traj, traj_idx, timestep, limits, noise_scale: float = 0.0, seed: int = 0, finger: float = 0.025):
+    """Restates the joint part of PointCloudBase.get_inputs (data_loader.py:155-185) + the supervision row of
+    PointCloudInstanceDataset.__getitem__ (:403-417) for a list of samples; noise = Box-Muller on Philox4x32-10
+    blocks (counter (blk, sample, 7, 0), key = seed), the engine's documented generator."""
+    traj, lim = _f(traj), _f(limits)
+    L = traj.shape[1]
+    B = len(traj_idx)
+    q = np.empty((B, 7), np.float32)
+    sup = np.empty((B, 7), np.float32)
+    fin = np.empty((B, 7), np.float32)
+    lo, hi = lim[:, 0], lim[:, 1]
+    for b in range(B):
+        ti = int(traj_idx[b])
+        t = 0 if timestep is None else int(np.clip(timestep[b], 0, L - 1))
+        ts = min(t + 1, L - 1)
+        v = traj[ti, t].copy()
+        if noise_scale > 0:
+            z = np.empty(8, np.float32)
+            for blk in range(2):
+                r = philox4x32([blk, b, 7, 0], [seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF])
+                for pr in range(2):
+                    u1 = np.float32(1.0) - np.float32(r[2 * pr] >> 8) * np.float32(2.0 ** -24)
+                    u2 = np.float32(r[2 * pr + 1] >> 8) * np.float32(2.0 ** -24)
+                    rad = np.sqrt(np.float32(-2.0) * np.log(u1, dtype=np.float32), dtype=np.float32)
+                    s_, c_ = (float(v[0]) for v in sincos(np.array([np.float32(6.28318530717958647692) * u2], np.float32)))
+                    z[4 * blk + 2 * pr], z[4 * blk + 2 * pr + 1] = rad * c_, rad * s_
+            v = np.minimum(np.maximum(np.float32(noise_scale) * z[:7] + v, lo), hi).astype(np.float32)
+        q[b], sup[b], fin[b] = v, traj[ti, ts], traj[ti, L - 1]
+    norm = lambda x: ((x - lo) / (hi - lo) * np.float32(2.0) + np.float32(-1.0)).astype(np.float32)
+    T = franka_fk(fin, finger)
+    pose = frames_to_4x4(T[:, 14])
+    return {"q": q, "configuration": norm(q), "supervision": norm(sup), "target_pose": pose,
+            "target_position": pose[:, :3, 3].copy()}
+
+
 # ---------------------------------------------------------------- losses (row N1), torch CPU autograd
 def fk_frames_torch(q, finger: float = 0.025):
     """Differentiable restatement of the Franka chain (same public URDF constants as orc_franka_fk):

@@ -57,3 +57,22 @@ def test_fk_torch_restatement_equals_c_oracle(oracle):
     T = oracle.franka_fk(q)
     np.testing.assert_allclose(R.numpy().reshape(16, 15, 9), T[..., :9], atol=2e-6)
     np.testing.assert_allclose(t.numpy(), T[..., 9:], atol=2e-6)
+
+
+def test_batch_config_restatement_properties(oracle):
+    """Row N2 oracle: no noise -> the stored waypoint; noise is clamped to the limits; supervision = next waypoint
+    (last one re-used); target = FK of the LAST waypoint (data_loader.py:155-185, 403-417)."""
+    from mpinets_amd import franka_tables as ft
+
+    rng = np.random.default_rng(3)
+    lim = ft.JOINT_LIMITS_REAL
+    traj = (lim[:, 0] + rng.random((4, 6, 7)) * (lim[:, 1] - lim[:, 0])).astype(np.float32)
+    traj[2, 1] = lim[:, 1]  # on the upper limits: noise can only push it inside or get clamped
+    o = oracle.batch_configs(traj, [0, 2, 3], [0, 1, 5], lim, 0.0, 1)
+    np.testing.assert_array_equal(o["q"], traj[[0, 2, 3], [0, 1, 5]])
+    np.testing.assert_allclose(o["supervision"][0], oracle.normalize(traj[0, 1][None], lim)[0], atol=1e-6)
+    np.testing.assert_allclose(o["supervision"][2], oracle.normalize(traj[3, 5][None], lim)[0], atol=1e-6)
+    np.testing.assert_allclose(o["target_pose"][1], oracle.frames_to_4x4(oracle.franka_fk(traj[2, 5][None])[:, 14])[0])
+    n = oracle.batch_configs(traj, [2] * 50, [1] * 50, lim, 0.05, 7)
+    assert (n["q"] <= lim[:, 1] + 1e-6).all() and (n["q"] >= lim[:, 0] - 1e-6).all() and np.abs(n["configuration"]).max() <= 1 + 1e-6
+    assert (n["q"] < lim[:, 1]).mean() > 0.3 and len(np.unique(n["q"][:, 0])) > 10  # different noise per sample
