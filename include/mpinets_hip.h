@@ -184,6 +184,26 @@ int mpx_batch_configs(const float *trajectories, int64_t n_traj, int L, const in
 int mpx_gather_rows(const float *src, const int64_t *idx, int B, int row_floats, float *dst,
                     mpx_stream_t stream);
 
+/* ---- partial-view scene clouds from a depth camera (row N4; run_inference.py:194-257) ------------- */
+
+/* Analytic ray casting of the primitives from cam_poses [B,4,4] (world-from-camera, OpenGL axes: x right,
+ * y up, looking along -z, as the reference's evaluation poses are given), pinhole intrinsics in pixels,
+ * image W x H.  depth [B, H*W] = distance along the pixel's ray to the nearest cuboid / cylinder, or -1 when
+ * nothing is hit within far_clip or one of the robot's spheres (sph_centers [B,S,3] from mpx_franka_spheres,
+ * sph_radii [S]; S = 0: no robot) is in front -- the reference removes the robot's pixels.
+ * Replaces PyBullet's rasteriser + depth buffer (robofin Bullet.get_pointcloud_from_camera).       */
+int mpx_depth_render(const float *cam_poses, float fx, float fy, float cx, float cy, int W, int H, int B,
+                     const float *cub_frames, const float *cub_dims, int M1, const float *cyl_frames,
+                     const float *cyl_radii, const float *cyl_heights, int M2, const float *sph_centers,
+                     const float *sph_radii, int S, float far_clip, float *depth, mpx_stream_t stream);
+/* np.random.choice(len(cloud), n_out, replace=False) of run_inference.py:78-85 on the device: every valid
+ * pixel gets a Philox4x32-10 key (seed, environment, pixel); the n_out smallest keys are written as world
+ * points in key order to out (strides in floats).  count [B] = valid pixels; an environment with fewer than
+ * n_out of them is left untouched (the caller raises like numpy).  n_out <= 8128.                    */
+int mpx_depth_select(const float *depth, const float *cam_poses, float fx, float fy, float cx, float cy,
+                     int W, int H, int B, int n_out, uint64_t seed, float *out, int64_t out_batch_stride,
+                     int out_point_stride, int32_t *count, mpx_stream_t stream);
+
 /* ---- scene point clouds: mpinets/geometry.py:571-608 (construct_mixed_point_cloud), batched ----- */
 
 /* For every environment: area-proportional pool sizes int(p_i*N)+500, N pool slots drawn without

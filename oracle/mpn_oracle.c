@@ -688,3 +688,144 @@ ORC_API void orc_trajectory_metrics(const float *traj, const int32_t *lengths, c
   }
   free(T1);
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Depth-camera scene clouds (row N4).  The reference renders with PyBullet and back-projects the
+ * depth image (run_inference.py:194-257; robofin Bullet.get_pointcloud_from_camera, absent):
+ * PARITY UNPINNED.  This restates the engine's documented definition: analytic ray casting of the
+ * primitives from an OpenGL-convention camera (x right, y up, looks along -z -- the convention of the
+ * reference's evaluation poses), robot pixels (collision spheres) and misses dropped, then the n_out
+ * valid pixels with the smallest Philox keys, in key order (ties by pixel id).
+ * frames here are the 12-float [R | t] rows of orc_prim_frames.
+ * ---------------------------------------------------------------------------------------- */
+static void orc_pixel_ray(const float *P, float fx, float fy, float cx, float cy, int u, int v, float *d) {
+  float xc = ((float)u + 0.5f - cx) / fx, yc = -(((float)v + 0.5f - cy) / fy), zc = -1.0f;
+  float wx = P[0] * xc, wy = P[4] * xc, wz = P[8] * xc;
+  wx = fmaf(P[1], yc, wx), wy = fmaf(P[5], yc, wy), wz = fmaf(P[9], yc, wz);
+  wx = fmaf(P[2], zc, wx), wy = fmaf(P[6], zc, wy), wz = fmaf(P[10], zc, wz);
+  float n = sqrtf(fmaf(wz, wz, fmaf(wy, wy, wx * wx)));
+  d[0] = wx / n, d[1] = wy / n, d[2] = wz / n;
+}
+static void orc_rot12(const float *f, const float *x, float *o) {
+  for (int r = 0; r < 3; ++r) o[r] = fmaf(f[3 * r + 2], x[2], fmaf(f[3 * r + 1], x[1], f[3 * r] * x[0]));
+}
+static void orc_proj12(const float *f, const float *x, float *o) {
+  for (int r = 0; r < 3; ++r) {
+    float a = f[3 * r] * x[0];
+    a = fmaf(f[3 * r + 1], x[1], a);
+    a = fmaf(f[3 * r + 2], x[2], a);
+    o[r] = a + f[9 + r];
+  }
+}
+static int orc_zero(float x) { return fabsf(x) <= 1e-8f; }
+
+static float orc_ray_cuboid(const float *f, const float *h, const float *o, const float *d) {
+  float lo[3], ld[3], tn = -INFINITY, tf = INFINITY;
+  orc_proj12(f, o, lo);
+  orc_rot12(f, d, ld);
+  for (int a = 0; a < 3; ++a) {
+    if (fabsf(ld[a]) < 1e-12f) {
+      if (fabsf(lo[a]) > h[a]) return INFINITY;
+    } else {
+      float t1 = (-h[a] - lo[a]) / ld[a], t2 = (h[a] - lo[a]) / ld[a];
+      tn = fmaxf(tn, fminf(t1, t2));
+      tf = fminf(tf, fmaxf(t1, t2));
+    }
+  }
+  return (tn <= tf && tn > 0.0f) ? tn : INFINITY;
+}
+static float orc_ray_cylinder(const float *f, float r, float hh, const float *o, const float *d) {
+  float l[3], e[3], best = INFINITY;
+  orc_proj12(f, o, l);
+  orc_rot12(f, d, e);
+  float a = fmaf(e[1], e[1], e[0] * e[0]);
+  if (a > 1e-12f) {
+    float b = fmaf(l[1], e[1], l[0] * e[0]), c = fmaf(l[1], l[1], l[0] * l[0]) - r * r;
+    float disc = b * b - a * c;
+    if (disc >= 0.0f) {
+      float s = (-b - sqrtf(disc)) / a;
+      if (s > 0.0f && fabsf(fmaf(s, e[2], l[2])) <= hh) best = s;
+    }
+  }
+  if (fabsf(e[2]) > 1e-12f) {
+    for (int k = 0; k < 2; ++k) {
+      float s = ((k ? -hh : hh) - l[2]) / e[2];
+      float px = fmaf(s, e[0], l[0]), py = fmaf(s, e[1], l[1]);
+      if (s > 0.0f && s < best && fmaf(py, py, px * px) <= r * r) best = s;
+    }
+  }
+  return best;
+}
+static float orc_ray_sphere(const float *c, float r, const float *o, const float *d) {
+  float m[3] = {o[0] - c[0], o[1] - c[1], o[2] - c[2]};
+  float b = fmaf(m[2], d[2], fmaf(m[1], d[1], m[0] * d[0]));
+  float cc = fmaf(m[2], m[2], fmaf(m[1], m[1], m[0] * m[0])) - r * r;
+  float disc = b * b - cc;
+  if (disc < 0.0f) return INFINITY;
+  float s = -b - sqrtf(disc);
+  return s > 0.0f ? s : INFINITY;
+}
+
+ORC_API void orc_depth_render(const float *cam, float fx, float fy, float cx, float cy, int W, int H, int B,
+                              const float *cub_f, const float *cub_d, int M1, const float *cyl_f, const float *cyl_r,
+                              const float *cyl_h, int M2, const float *sph_c, const float *sph_r, int S,
+                              float far_clip, float *depth) {
+  for (int b = 0; b < B; ++b) {
+    const float *P = cam + 16 * (size_t)b;
+    const float o[3] = {P[3], P[7], P[11]};
+    for (int pix = 0; pix < W * H; ++pix) {
+      float d[3], best = far_clip;
+      orc_pixel_ray(P, fx, fy, cx, cy, pix % W, pix / W, d);
+      for (int m = 0; m < M1; ++m) {
+        size_t pm = (size_t)b * M1 + m;
+        const float *dm = cub_d + 3 * pm;
+        if (orc_zero(dm[0]) || orc_zero(dm[1]) || orc_zero(dm[2])) continue;
+        float h[3] = {dm[0] / 2.0f, dm[1] / 2.0f, dm[2] / 2.0f};
+        best = fminf(best, orc_ray_cuboid(cub_f + 12 * pm, h, o, d));
+      }
+      for (int m = 0; m < M2; ++m) {
+        size_t pm = (size_t)b * M2 + m;
+        if (orc_zero(cyl_r[pm]) || orc_zero(cyl_h[pm])) continue;
+        best = fminf(best, orc_ray_cylinder(cyl_f + 12 * pm, cyl_r[pm], cyl_h[pm] / 2.0f, o, d));
+      }
+      int robot = 0;
+      for (int s = 0; s < S; ++s)
+        if (orc_ray_sphere(sph_c + ((size_t)b * S + s) * 3, sph_r[s], o, d) < best) robot = 1;
+      depth[(size_t)b * W * H + pix] = (robot || !(best < far_clip)) ? -1.0f : best;
+    }
+  }
+}
+
+static int orc_cmp_u64(const void *a, const void *b) {
+  uint64_t x = *(const uint64_t *)a, y = *(const uint64_t *)b;
+  return x < y ? -1 : (x > y ? 1 : 0);
+}
+
+/* out [B, n_out, 3]; count [B] = valid pixels; an environment with fewer than n_out valid pixels is left untouched */
+ORC_API void orc_depth_select(const float *depth, const float *cam, float fx, float fy, float cx, float cy, int W,
+                              int H, int B, int n_out, uint32_t k0, uint32_t k1, float *out, int32_t *count) {
+  uint64_t *keys = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)W * H);
+  for (int b = 0; b < B; ++b) {
+    const float *dp = depth + (size_t)b * W * H, *P = cam + 16 * (size_t)b;
+    int n = 0;
+    for (int pix = 0; pix < W * H; ++pix) {
+      if (dp[pix] < 0.0f) continue;
+      uint32_t r[4];
+      orc_philox((uint32_t)pix, (uint32_t)b, 9u, 0u, k0, k1, r);
+      keys[n++] = ((uint64_t)r[0] << 32) | (uint32_t)pix;
+    }
+    count[b] = n;
+    if (n < n_out) continue;
+    qsort(keys, (size_t)n, sizeof(uint64_t), orc_cmp_u64);
+    for (int i = 0; i < n_out; ++i) {
+      int pix = (int)(uint32_t)keys[i];
+      float d[3];
+      orc_pixel_ray(P, fx, fy, cx, cy, pix % W, pix / W, d);
+      float *o = out + ((size_t)b * n_out + i) * 3;
+      o[0] = fmaf(dp[pix], d[0], P[3]);
+      o[1] = fmaf(dp[pix], d[1], P[7]);
+      o[2] = fmaf(dp[pix], d[2], P[11]);
+    }
+  }
+  free(keys);
+}

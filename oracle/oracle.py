@@ -212,6 +212,37 @@ def trajectory_metrics(traj, lengths, targets, limits, finger: float = 0.025) ->
     return out
 
 
+# ---------------------------------------------------------------- depth-camera clouds (row N4)
+def depth_render(cam_poses, intr, W, H, cub, cyl, sph_centers=None, sph_radii=None, far_clip: float = 10.0):
+    """cam_poses [B,4,4] world-from-camera (OpenGL axes); intr = (fx, fy, cx, cy); cub = (centers, dims, quats),
+    cyl = (centers, radii, heights, quats) -> depth [B, H*W] (-1 = no obstacle / robot in front)."""
+    cam = _f(cam_poses).reshape(-1, 16)
+    B = cam.shape[0]
+    cf, cd = prim_frames(cub[0], cub[2]).reshape(B, -1, 12), _f(cub[1]).reshape(B, -1, 3)
+    yf = prim_frames(cyl[0], cyl[3]).reshape(B, -1, 12)
+    yr, yh = _f(cyl[1]).reshape(B, -1), _f(cyl[2]).reshape(B, -1)
+    sc = None if sph_centers is None else _f(sph_centers).reshape(B, -1, 3)
+    sr = None if sph_radii is None else _f(sph_radii)
+    S = 0 if sc is None else sc.shape[1]
+    depth = np.empty((B, W * H), np.float32)
+    c = ctypes.c_float
+    lib().orc_depth_render(_p(cam), c(intr[0]), c(intr[1]), c(intr[2]), c(intr[3]), W, H, B, _p(cf), _p(cd),
+                           cf.shape[1], _p(yf), _p(yr), _p(yh), yf.shape[1], _p(sc), _p(sr), S, c(far_clip), _p(depth))
+    return depth
+
+
+def depth_select(depth, cam_poses, intr, W, H, n_out: int, seed: int):
+    cam = _f(cam_poses).reshape(-1, 16)
+    B = cam.shape[0]
+    out = np.zeros((B, n_out, 3), np.float32)
+    count = np.zeros(B, np.int32)
+    c = ctypes.c_float
+    lib().orc_depth_select(_p(_f(depth)), _p(cam), c(intr[0]), c(intr[1]), c(intr[2]), c(intr[3]), W, H, B, n_out,
+                           ctypes.c_uint32(seed & 0xFFFFFFFF), ctypes.c_uint32((seed >> 32) & 0xFFFFFFFF), _p(out),
+                           _p(count))
+    return out, count
+
+
 # ---------------------------------------------------------------- batch assembly (row N2)
 def batch_configs(traj, traj_idx, timestep, limits, noise_scale: float = 0.0, seed: int = 0, finger: float = 0.025):
     """Restates the joint part of PointCloudBase.get_inputs (data_loader.py:155-185) + the supervision row of

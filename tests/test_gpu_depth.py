@@ -1,0 +1,107 @@
+"""Row N4: depth-camera scene clouds (analytic ray cast + on-device subset draw) vs the oracle restatement."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def problem(B, kinds, seed):
+    from mpinets_amd.geometry import TorchCuboids, TorchCylinders
+    from mpinets_amd.scenes import make_scenes, random_configurations
+
+    scn = make_scenes(B, seed, kinds, 16, 8)
+    t = {k: torch.from_numpy(v).to(dev()) for k, v in scn.items()}
+    cub = TorchCuboids(t["cuboid_centers"], t["cuboid_dims"], t["cuboid_quats"])
+    cyl = TorchCylinders(t["cylinder_centers"], t["cylinder_radii"], t["cylinder_heights"], t["cylinder_quats"])
+    q = torch.from_numpy(random_configurations(B, seed + 1)).to(dev())
+    return scn, t, cub, cyl, q
+
+
+def test_depth_image_and_cloud_match_oracle(oracle):
+    from mpinets_amd.depth import DepthCamera, camera_pose
+    from mpinets_amd.robot import FrankaCollisionSampler
+
+    B = 3
+    kinds = ("tabletop", "cubby", "tabletop")
+    scn, t, cub, cyl, q = problem(B, ("tabletop", "cubby"), 2)
+    kinds = ("tabletop", "cubby", "tabletop")
+    cam = DepthCamera(160, 120)  # small image: the scalar oracle walks every pixel x primitive
+    poses = torch.from_numpy(np.stack([camera_pose(k) for k in kinds])).to(dev())
+    cs = FrankaCollisionSampler(dev(), with_base_link=True)
+    depth = cam.render(poses, cub, cyl, q=q, collision_sampler=cs)
+    sc = cs.sphere_centers(q).cpu().numpy()
+    ref = oracle.depth_render(poses.cpu().numpy(), cam.intrinsics, 160, 120,
+                              (scn["cuboid_centers"], scn["cuboid_dims"], scn["cuboid_quats"]),
+                              (scn["cylinder_centers"], scn["cylinder_radii"], scn["cylinder_heights"], scn["cylinder_quats"]),
+                              sc, cs.radii.cpu().numpy(), cam.far_clip)
+    got = depth.reshape(B, -1).cpu().numpy()
+    valid = ref >= 0
+    assert 0.05 < valid.mean() < 0.98  # the cameras see the scene, and not only the scene
+    assert ((got >= 0) != valid).mean() < 1e-4  # silhouette pixels may flip by rounding
+    both = (got >= 0) & valid
+    np.testing.assert_allclose(got[both], ref[both], rtol=0, atol=5e-6)
+    # without the robot more pixels are valid (its spheres hide / remove some)
+    no_robot = cam.render(poses, cub, cyl)
+    assert (no_robot >= 0).sum() > (depth >= 0).sum()
+    # subset draw: same keys, same order as the oracle's sort
+    n_out = 500
+    pts = cam.sample_cloud(depth, poses, n_out, seed=77)
+    opts, ocount = oracle.depth_select(got, poses.cpu().numpy(), cam.intrinsics, 160, 120, n_out, 77)
+    np.testing.assert_array_equal(cam.last_counts.cpu().numpy(), ocount)
+    np.testing.assert_allclose(pts.cpu().numpy(), opts, rtol=0, atol=2e-6)
+    # every point lies on an obstacle surface of its own scene (engine SDF == 0) and is visible, i.e. in front
+    sd = torch.minimum(cub.sdf(pts), cyl.sdf(pts)).abs()
+    assert sd.max().item() < 2e-5
+    p2 = cam.sample_cloud(depth, poses, n_out, seed=78).cpu().numpy()
+    assert not np.array_equal(p2, pts.cpu().numpy())
+
+
+def test_subset_is_uniform_without_replacement_and_errors():
+    from mpinets_amd.depth import DepthCamera
+
+    cam = DepthCamera(64, 48)
+    B, HW = 2, 64 * 48
+    poses = torch.eye(4, device=dev()).repeat(B, 1, 1)
+    depth = torch.full((B, 48, 64), -1.0, device=dev())
+    depth[0, :, :32] = 1.0 + torch.arange(32, device=dev()) * 0.01  # a distinct depth per column: points identify pixels
+    depth[1, 10:40, 5:60] = 2.0
+    n_out = 1000
+    seen = np.zeros((48, 32), np.int64)
+    for seed in range(40):
+        pts = cam.sample_cloud(depth, poses, n_out, seed=seed)
+        p = pts[0].cpu().numpy()
+        # invert the pinhole: pixel from the point (camera at the origin looking along -z)
+        u = np.rint(p[:, 0] / -p[:, 2] * cam.fx + cam.cx - 0.5).astype(int)
+        v = np.rint(-p[:, 1] / -p[:, 2] * cam.fy + cam.cy - 0.5).astype(int)
+        assert len(set(zip(u.tolist(), v.tolist()))) == n_out  # without replacement
+        assert u.min() >= 0 and u.max() < 32 and v.min() >= 0 and v.max() < 48  # only valid pixels
+        seen[v, u] += 1
+    freq = seen / 40.0  # every pixel is chosen with probability n_out / 1536
+    assert abs(freq.mean() - n_out / 1536) < 1e-9 and freq.std() < 0.12
+    with pytest.raises(ValueError):
+        cam.sample_cloud(depth, poses, 1600, seed=0)  # image 0 has only 1536 valid pixels
+
+
+def test_depth_clouds_feed_the_policy():
+    from mpinets_amd.depth import depth_point_clouds
+    from mpinets_amd.model import MotionPolicyNetwork
+    from mpinets_amd.scenes import make_problem_batch
+
+    B = 4
+    prob = make_problem_batch(B, seed=3, device=dev(), kinds=("tabletop", "cubby"), M1=16, M2=8)
+    q0 = (prob["q_norm"] + 1) / 2 * 0  # any configuration: neutral-ish robot from the slab's own q is fine
+    from mpinets_amd.utils import unnormalize_franka_joints
+
+    q0 = unnormalize_franka_joints(prob["q_norm"])
+    kinds = ["tabletop", "cubby", "tabletop", "cubby"]
+    depth_point_clouds(prob, q0, kinds, 4096, seed=5, out=prob["xyz"][:, 2048:6144])
+    torch.manual_seed(0)
+    mdl = MotionPolicyNetwork().to(dev()).eval()
+    with torch.no_grad():
+        dq = mdl(prob["xyz"], prob["q_norm"])
+    assert dq.shape == (B, 7) and torch.isfinite(dq).all()

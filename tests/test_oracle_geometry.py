@@ -95,3 +95,31 @@ def test_joint_normalisation_arithmetic(golden, oracle):
     back = oracle.normalize(golden["utils/unnormalized"], ft.JOINT_LIMITS_REAL)
     np.testing.assert_allclose(back, golden["utils/renormalized"], rtol=0, atol=1e-6)
     np.testing.assert_allclose(back, golden["utils/q_norm"], rtol=0, atol=1e-5)
+
+
+def test_depth_render_known_answers(oracle):
+    """Row N4 oracle: a camera at the origin looking along -z (identity pose) at a box / cylinder / robot sphere."""
+    I = np.eye(4, dtype=np.float32)[None]
+    W, H, f = 65, 49, 40.0
+    intr = (f, f, W / 2.0, H / 2.0)
+    quat = np.array([[[1.0, 0, 0, 0]]], np.float32)
+    cub = (np.array([[[0, 0, -3.0]]], np.float32), np.array([[[1.0, 1.0, 2.0]]], np.float32), quat)
+    none_cyl = (np.zeros((1, 1, 3), np.float32), np.zeros((1, 1, 1), np.float32), np.zeros((1, 1, 1), np.float32), quat)
+    d = oracle.depth_render(I, intr, W, H, cub, none_cyl).reshape(H, W)
+    c = d[H // 2, W // 2]  # centre pixel: straight down the axis, front face at z = -2
+    assert abs(c - 2.0) < 1e-6
+    assert d[0, 0] == -1 and (d >= 0).sum() > 100  # corners miss, the box fills the middle
+    # a pixel off-axis hits the same front face: its ray length is 2 / cos(angle)
+    u, v = W // 2 + 6, H // 2 - 4
+    x, y = (u + 0.5 - intr[2]) / f, -(v + 0.5 - intr[3]) / f
+    assert abs(d[v, u] - 2.0 * np.sqrt(1 + x * x + y * y)) < 1e-5
+    # cylinder on the axis (its own z along the view direction): the near cap at distance 4 - 0.5
+    cyl = (np.array([[[0, 0, -4.0]]], np.float32), np.array([[[0.3]]], np.float32), np.array([[[1.0]]], np.float32), quat)
+    none_cub = (np.zeros((1, 1, 3), np.float32), np.zeros((1, 1, 3), np.float32), quat)
+    assert abs(oracle.depth_render(I, intr, W, H, none_cub, cyl).reshape(H, W)[H // 2, W // 2] - 3.5) < 1e-6
+    # a robot sphere in front of the box removes those pixels; behind the box it does not
+    front = oracle.depth_render(I, intr, W, H, cub, none_cyl, np.array([[[0, 0, -1.0]]], np.float32), np.array([0.1], np.float32))
+    back = oracle.depth_render(I, intr, W, H, cub, none_cyl, np.array([[[0, 0, -6.0]]], np.float32), np.array([0.1], np.float32))
+    assert front.reshape(H, W)[H // 2, W // 2] == -1 and back.reshape(H, W)[H // 2, W // 2] == c
+    pts, cnt = oracle.depth_select(d.reshape(1, -1), I, intr, W, H, 50, 3)
+    assert cnt[0] == (d >= 0).sum() and np.allclose(pts[0, :, 2].max(), -2.0, atol=1e-5) and len(np.unique(pts[0], axis=0)) == 50
