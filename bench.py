@@ -72,6 +72,41 @@ def cpu_baseline(prob, model, n_env: int):
                       f"numpy float64 MLPs on {cores} BLAS threads), {dt:.1f} s"}
 
 
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+
+
+def stage_table(prof, steps, B, sa1_ms, sa1_exec, sa2_ms, sa2_exec):
+    """achieved / peak per stage of the step: HBM stages in GB/s of algorithmic bytes, MFMA stages in TFLOP/s of
+    executed FLOPs, FPS / ball query in G point-pair distance evaluations per second (VALU / latency bound: their
+    HBM traffic, the 100 KB slab read once, is negligible)."""
+    ms = lambda k: float(np.sum(prof[k])) / steps
+    lin_ms = ms("mpx_linear") + ms("mpx_linear_rowmax")
+    lin_flops = 2.0 * B * (512 * 68 * 128 + 128 * 4 * 128            # SA2 first layer, per point / per query
+                           + 128 * (260 * 512 + 512 * 512 + 512 * 1024)  # group-all module
+                           + 1024 * 4096 + 4096 * 2048 + 2048 * 2048    # fc head
+                           + 8 * 32 + 32 * 64 + 64 * 128 + 128 * 128 + 128 * 64  # q encoder
+                           + 2112 * 512 + 512 * 256 + 256 * 128 + 128 * 7)       # decoder
+    pairs = B * (511 * 6272 + 127 * 512)
+    bq_pairs = B * (512 * 6272 + 128 * 512)
+    hbm = lambda by, t: {"bound": "hbm", "ms": t, "achieved": by / (t * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": by / (t * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    mf = lambda fl, t: {"bound": "mfma", "ms": t, "achieved": fl / (t * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": fl / (t * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS}
+    return {
+        "fk_robot_cloud": dict(hbm(B * 2048 * 12.0, ms("mpx_franka_cloud")), note="24,576 B written per env"),
+        "sphere_sdf_collision": dict(hbm(B * 1250.0, ms("mpx_franka_collision")),
+                                     note="~1.25 KB per env-waypoint: launch / latency bound at T = 1, not HBM"),
+        "fps": {"bound": "valu/latency", "ms": ms("mpx_fps"), "achieved": pairs / (ms("mpx_fps") * 1e-3) / 1e9,
+                "unit": "G point-distance updates/s", "note": "511 + 127 dependent picks per env"},
+        "ball_query": {"bound": "valu", "ms": ms("mpx_ball_query"),
+                       "achieved": bq_pairs / (ms("mpx_ball_query") * 1e-3) / 1e9, "unit": "G point-pair tests/s"},
+        "sa1_grouped_mlp": mf(sa1_exec, sa1_ms), "sa2_grouped_mlp": mf(sa2_exec, sa2_ms),
+        "dense_layers": dict(mf(lin_flops, lin_ms), note="SA2 layer 1 (factored) + group-all module + heads"),
+        "groupnorm_leaky": {"bound": "hbm", "ms": ms("mpx_groupnorm_leaky")},
+        "joint_step": {"bound": "latency", "ms": ms("mpx_joint_step")},
+    }
+
+
 # multiply-adds per (query, neighbour) row of SA2 inside the fused kernel: layers 2 and 3 (128x128 + 128x256);
 # layer 1 (67x128) runs once per point / per query as plain GEMMs (mpx_sa_mlp_factored)
 SA2_ROW_MACS = 128 * 128 + 128 * 256
@@ -116,7 +151,8 @@ def main():
         eng.step()
     torch.cuda.synchronize()
     shard.barrier()
-    _lib.profile_start("mpx_sa_mlp", "mpx_sa_mlp_factored", "mpx_fps", "mpx_ball_query", "mpx_linear", "mpx_linear_rowmax")
+    _lib.profile_start("mpx_sa_mlp", "mpx_sa_mlp_factored", "mpx_fps", "mpx_ball_query", "mpx_linear", "mpx_linear_rowmax",
+                        "mpx_franka_cloud", "mpx_franka_collision", "mpx_joint_step", "mpx_groupnorm_leaky")
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -176,10 +212,25 @@ def main():
                                sub(prob["cylinder_heights"], 1024), sub(prob["cylinder_quats"], 1024))
         c4_ms = timed(lambda: eng.collision.check(traj, eng.cuboids, eng.cylinders))
         c2_ms = timed(lambda: eng.collision.check(q1k, cub1k, cyl1k, return_sdf=True))
+        c2_cpu = None
+        if args.cpu_envs > 0:  # the same config-2 work on the host: oracle port, single thread
+            from mpinets_amd import franka_tables as ft
+            from oracle import oracle as orc
+
+            orc.build()
+            c_, r_, l_, _ = ft.collision_sphere_table(False)
+            qh = q1k.cpu().numpy()
+            ph = {k: prob[k][:1024].cpu().numpy() for k in prob if k.startswith(("cuboid_", "cylinder_"))}
+            th = time.perf_counter()
+            ctr = orc.transform_table(orc.franka_fk(qh), c_, l_)
+            orc.collision_flags(ctr[:, None], r_, (ph["cuboid_centers"], ph["cuboid_dims"], ph["cuboid_quats"]),
+                                (ph["cylinder_centers"], ph["cylinder_radii"], ph["cylinder_heights"], ph["cylinder_quats"]))
+            c2_cpu = 1024 / (time.perf_counter() - th)
         extra = {
             "c4_collision_validation": {"envs": B, "waypoints": 50, "ms": c4_ms, "env_waypoints_per_s": B * 50 / c4_ms * 1e3,
                                         "what": "FK + 56-sphere SDF vs 16 cuboids + 16 cylinders, has_collision[B] (model.py:293-314)"},
             "c2_fk_sdf_1024": {"envs": 1024, "ms": c2_ms, "env_steps_per_s": 1024 / c2_ms * 1e3,
+                               "cpu_port_env_steps_per_s": c2_cpu, "cpu_cores": 1,
                                "what": "FK + sphere SDF, flags + min-sdf [1024,56] written"},
         }
 
@@ -283,6 +334,8 @@ def main():
                 "ball_query": float(np.sum(prof["mpx_ball_query"])) / args.steps,
                 "linear_all": float(np.sum(prof["mpx_linear"]) + np.sum(prof["mpx_linear_rowmax"])) / args.steps,
             },
+            # per-stage achieved / peak with the ALGORITHMIC work of SURVEY.md section 8(d) (per env-step, x B envs)
+            "stages": stage_table(prof, args.steps, B, sa1_ms, sa1_exec, sa2_ms, sa2_exec),
             "result_check": {"gathered_q": list(q_all.shape), "collision_rate": float((f_all != 0).float().mean())},
         }
         if extra is not None:

@@ -1,0 +1,26 @@
+"""Small-batch step latency (development aid). usage: latency_timing.py B [B ...]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "motion-policy-networks_amd")]
+import torch
+
+from mpinets_amd.model import MotionPolicyNetwork
+from mpinets_amd.rollout import RolloutEngine
+from mpinets_amd.scenes import make_problem_batch
+
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+mdl = MotionPolicyNetwork().to(dev).eval()
+for B in [int(a) for a in sys.argv[1:]] or [1, 256]:
+    eng = RolloutEngine(mdl, make_problem_batch(B, seed=0, device=dev, scene_pool=64, device_clouds=True))
+    eng.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(50):
+        eng.step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / 50 * 1e3
+    print(f"B={B}: {ms:.3f} ms/step ({1e3/ms:.0f} Hz), 50-step rollout {50*ms:.1f} ms, {B*1e3/ms:.0f} env-steps/s")
