@@ -429,10 +429,29 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CF == 1
     }
   }
 
+  // The weights of the layers this kernel evaluates are ONE contiguous stream of 16-byte-per-lane groups (4 MFMA
+  // steps each) in wpack: it is walked through a two-deep register ring that never drains -- the first chunk of a
+  // layer is requested while the previous layer still feeds the matrix pipe, and the last chunk of a tile already
+  // prefetches the first chunk of the next tile (same addresses).  Only the very first chunk of a wave is exposed.
+  constexpr int G1 = FACT ? 0 : Cfg::S1 / 4, G2 = Cfg::S2 / 4, G3 = Cfg::S3 / 4, GT = G1 + G2 + G3;
+  constexpr int CH = 4, NC0 = (GT + CH - 1) / CH, NC = NC0 + (NC0 & 1);  // even: the ring parity repeats per tile
+  constexpr int GPT = Cfg::KS2 / 4;                                      // weight groups per layer-3 output tile
+  float4 ring[2][CH];
+  auto fetch = [&](int c, int base) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < CH; ++u)
+      if (c * CH + u < GT) ring[c & 1][u] = bload16(wrsrc, wvoff, base + (c * CH + u) * 1024);
+  };
+  {
+    int wb = (int)(FACT ? Cfg::W2_OFF : Cfg::W1_OFF) * 4;
+    asm volatile("" : "+s"(wb));
+    fetch(0, wb);
+  }
+
   for (int rt = 0; rt < total; rt += 32) {
-    int w1o = (int)Cfg::W1_OFF * 4, w2o = (int)Cfg::W2_OFF * 4, w3o = (int)Cfg::W3_OFF * 4;
+    int wb = (int)(FACT ? Cfg::W2_OFF : Cfg::W1_OFF) * 4;
     int b1o = (int)Cfg::B1_OFF * 4, b2o = (int)Cfg::B2_OFF * 4;
-    asm volatile("" : "+s"(w1o), "+s"(w2o), "+s"(w3o), "+s"(b1o), "+s"(b2o));
+    asm volatile("" : "+s"(wb), "+s"(b1o), "+s"(b2o));
 
     float x0[Cfg::KS0];
     f32x16 a1[Cfg::OT1];
@@ -466,50 +485,53 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CF == 1
       k_next = idx[(q0 + q_next) * nsample + off];
     }
 
+    f32x16 a2[Cfg::OT2], a3;
     if constexpr (!FACT) {
 #pragma unroll
       for (int ot = 0; ot < Cfg::OT1; ++ot) a1[ot] = bias_tile(wrsrc, b1o, ot, half);
-      stream_weights<Cfg::S1 / 4>(wrsrc, wvoff, w1o, [&](int g, const float4 &w) __attribute__((always_inline)) {
+    } else {
+#pragma unroll
+      for (int ot = 0; ot < Cfg::OT2; ++ot) a2[ot] = bias_tile(wrsrc, b2o, ot, half);
+    }
+
+    // one weight group = 4 MFMA steps of whichever layer it belongs to (g is a compile-time constant after unrolling)
+    auto step = [&](int g, const float4 &w) __attribute__((always_inline)) {
+      if (g < G1) {  // ---- layer 1: H1^T = W1 . X^T
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int s = 4 * g + u, t = s / Cfg::OT1, ot = s % Cfg::OT1;
           a1[ot] = mfma32(comp(w, u), x0[t], a1[ot]);
         }
-      });
+        if (g == G1 - 1) {
 #pragma unroll
-      for (int ot = 0; ot < Cfg::OT1; ++ot)
+          for (int ot = 0; ot < Cfg::OT1; ++ot)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) a1[ot][r] = fmaxf(a1[ot][r], 0.0f);
-    }
-
-    f32x16 a2[Cfg::OT2];
+            for (int r = 0; r < 16; ++r) a1[ot][r] = fmaxf(a1[ot][r], 0.0f);
 #pragma unroll
-    for (int ot = 0; ot < Cfg::OT2; ++ot) a2[ot] = bias_tile(wrsrc, b2o, ot, half);
-    stream_weights<Cfg::S2 / 4>(wrsrc, wvoff, w2o, [&](int g, const float4 &w) __attribute__((always_inline)) {
+          for (int ot = 0; ot < Cfg::OT2; ++ot) a2[ot] = bias_tile(wrsrc, b2o, ot, half);
+        }
+      } else if (g < G1 + G2) {  // ---- layer 2: H2^T = W2 . H1^T (H1 tiles are the B operands in place)
+        const int gg = g - G1;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int s = 4 * g + u, t = s / Cfg::OT2, ot = s % Cfg::OT2;
-        a2[ot] = mfma32(comp(w, u), a1[t >> 4][t & 15], a2[ot]);
-      }
-    });
+        for (int u = 0; u < 4; ++u) {
+          const int s = 4 * gg + u, t = s / Cfg::OT2, ot = s % Cfg::OT2;
+          a2[ot] = mfma32(comp(w, u), a1[t >> 4][t & 15], a2[ot]);
+        }
+        if (gg == G2 - 1) {
 #pragma unroll
-    for (int ot = 0; ot < Cfg::OT2; ++ot)
+          for (int ot = 0; ot < Cfg::OT2; ++ot)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) a2[ot][r] = fmaxf(a2[ot][r], 0.0f);
-
-    // the next tile's rows are fetched now: layer 3 below is long enough to cover the latency and
-    // layer 2's accumulators (the register peak) are gone
-    if (rt + 32 < total) gather(q_gather, k_gather);
-
-    // ---- layer 3 (roles flipped), pooled per query as each output tile completes ------------------------------
-    // a lane holds, for its channel, four groups of 4 consecutive rows (group g = 2j + half = rows 4g..4g+3);
-    // groups never straddle queries, so: max inside each group, then merge the 8 groups in row order and
-    // flush the running maximum whenever the (wave-uniform) query changes.
-    {
-      f32x16 a3;
-      constexpr int GPT = Cfg::KS2 / 4;
-      stream_weights<Cfg::S3 / 4>(wrsrc, wvoff, w3o, [&](int g, const float4 &w) __attribute__((always_inline)) {
-        const int ot = g / GPT, gg = g % GPT;
+            for (int r = 0; r < 16; ++r) a2[ot][r] = fmaxf(a2[ot][r], 0.0f);
+          // the next tile's rows are fetched now: layer 3 is long enough to cover the latency and layer 1/2's
+          // inputs (the register peak) are gone
+          if (rt + 32 < total) gather(q_gather, k_gather);
+        }
+      } else {
+        // ---- layer 3 (roles flipped), pooled per query as each output tile completes.  A lane holds, for its
+        // channel, four groups of 4 consecutive rows (group 2j + half = rows 4g..4g+3); groups never straddle
+        // queries, so: max inside each group, then merge the 8 groups in row order and flush the running maximum
+        // whenever the (wave-uniform) query changes.
+        const int g3 = g - G1 - G2, ot = g3 / GPT, gg = g3 % GPT;
         if (gg == 0) a3 = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -531,7 +553,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CF == 1
             if ((grp & 1) == half) run[ot] = fmaxf(run[ot], gm[grp >> 1]);
           }
         }
-      });
+      }
+    };
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      fetch((c + 1) % NC, wb);  // the last chunk of a tile requests the first chunk of the next one
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int u = 0; u < CH; ++u)
+        if (c * CH + u < GT) step(c * CH + u, ring[c & 1][u]);
     }
   }
 #pragma unroll
