@@ -297,6 +297,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CF == 1
                          int out_stride, int bpe, const float *__restrict__ pre_rows, const float *__restrict__ ctr) {
   using Cfg = SaCfg<CF, C1, C2, C3>;
   __shared__ float ctr_s[FACT ? Q * C1 : 1];
+  // biases in LDS: they initialise the accumulators at every tile and are added at every flush -- as global loads
+  // their latency sits on the critical path of each tile
+  __shared__ __attribute__((aligned(16))) float b1_s[C1], b2_s[C2], b3_s[C3];
   static_assert(Q >= 1 && Q <= 32, "queries per wave");
   const int lane = threadIdx.x & 63;
   const int half = lane >> 5, col = lane & 31;
@@ -345,7 +348,23 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CF == 1
   const __amdgpu_buffer_rsrc_t wrsrc =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(wpack), 0, (int)(Cfg::TOTAL * 4), 0x00020000);
   const int wvoff = lane * 16;
-  const float *bias3 = wpack + Cfg::B3_OFF;
+  for (int i = threadIdx.x; i < C1; i += 64) b1_s[i] = wpack[Cfg::B1_OFF + i];
+  for (int i = threadIdx.x; i < C2; i += 64) b2_s[i] = wpack[Cfg::B2_OFF + i];
+  for (int i = threadIdx.x; i < C3; i += 64) b3_s[i] = wpack[Cfg::B3_OFF + i];
+  __syncthreads();
+  // register r of a tile holds channel ot*32 + (r&3) + 8*(r>>2) + 4*half
+  auto bias_lds = [&](const float *bs, int ot) __attribute__((always_inline)) {
+    f32x16 v;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 q = *reinterpret_cast<const float4 *>(bs + ot * 32 + 8 * g + 4 * half);
+      v[4 * g + 0] = q.x;
+      v[4 * g + 1] = q.y;
+      v[4 * g + 2] = q.z;
+      v[4 * g + 3] = q.w;
+    }
+    return v;
+  };
 
   const int qbase = (int)q0;  // query ids fit 31 bits (checked by the launcher)
   float run[Cfg::OT3];  // running max of the query being merged, per output tile (this lane's half of the rows)
@@ -359,7 +378,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CF == 1
     float v = run[ot];
     v = fmaxf(v, __shfl_xor(v, 32));
     const int ch = ot * 32 + col;
-    v = fmaxf(v + bias3[ch], 0.0f);
+    v = fmaxf(v + b3_s[ch], 0.0f);
     if (half == 0) out[(int64_t)(qbase + qi) * out_stride + ch] = v;
     run[ot] = -__builtin_inff();
   };
@@ -450,8 +469,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CF == 1
 
   for (int rt = 0; rt < total; rt += 32) {
     int wb = (int)(FACT ? Cfg::W2_OFF : Cfg::W1_OFF) * 4;
-    int b1o = (int)Cfg::B1_OFF * 4, b2o = (int)Cfg::B2_OFF * 4;
-    asm volatile("" : "+s"(wb), "+s"(b1o), "+s"(b2o));
+    asm volatile("" : "+s"(wb));
 
     float x0[Cfg::KS0];
     f32x16 a1[Cfg::OT1];
@@ -488,10 +506,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CF == 1
     f32x16 a2[Cfg::OT2], a3;
     if constexpr (!FACT) {
 #pragma unroll
-      for (int ot = 0; ot < Cfg::OT1; ++ot) a1[ot] = bias_tile(wrsrc, b1o, ot, half);
+      for (int ot = 0; ot < Cfg::OT1; ++ot) a1[ot] = bias_lds(b1_s, ot);
     } else {
 #pragma unroll
-      for (int ot = 0; ot < Cfg::OT2; ++ot) a2[ot] = bias_tile(wrsrc, b2o, ot, half);
+      for (int ot = 0; ot < Cfg::OT2; ++ot) a2[ot] = bias_lds(b2_s, ot);
     }
 
     // one weight group = 4 MFMA steps of whichever layer it belongs to (g is a compile-time constant after unrolling)
@@ -508,7 +526,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CF == 1
 #pragma unroll
             for (int r = 0; r < 16; ++r) a1[ot][r] = fmaxf(a1[ot][r], 0.0f);
 #pragma unroll
-          for (int ot = 0; ot < Cfg::OT2; ++ot) a2[ot] = bias_tile(wrsrc, b2o, ot, half);
+          for (int ot = 0; ot < Cfg::OT2; ++ot) a2[ot] = bias_lds(b2_s, ot);
         }
       } else if (g < G1 + G2) {  // ---- layer 2: H2^T = W2 . H1^T (H1 tiles are the B operands in place)
         const int gg = g - G1;
