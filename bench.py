@@ -121,7 +121,7 @@ def main():
     ap.add_argument("--fast-steps", type=int, default=3, help="steps of the secondary bf16x3 measurement (0 = skip)")
     ap.add_argument("--extra", type=int, default=1, help="also time BASELINE configs 2 and 4 (collision validation only)")
     ap.add_argument("--c5-steps", type=int, default=2, help="steps of the config-5-shaped extra (mixed scenes, scene re-render); 0 = skip")
-    ap.add_argument("--cpu-envs", type=int, default=8, help="env-steps in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-envs", type=int, default=64, help="env-steps in the CPU baseline sample (0 = skip)")
     ap.add_argument("--scene-pool", type=int, default=1024, help="distinct host-generated primitive sets tiled over the batch (clouds are drawn per env on the device)")
     args = ap.parse_args()
 
