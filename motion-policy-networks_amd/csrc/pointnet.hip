@@ -295,6 +295,274 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// ---- ball query through a column grid (exact; the large-cloud / small-radius case) ---------------------------
+// The brute-force kernel above tests every (query, point) pair: 512 x 6272 for the first set-abstraction module,
+// of which ~10 per query are hits (radius 5 cm).  Here one workgroup owns one environment: the cloud is bucketed
+// in LDS into G x G vertical columns of side h >= radius over (x, y) (counting sort), a thread walks the 3 x 3
+// columns around its query -- every point within the radius lies there -- and appends its hits to the output row;
+// the rows are then sorted by point index inside the wave (bitonic network on the lanes), which restores exactly
+// the reference's "first nsample hits in index order" (+ padding with the first hit).  A query that collects more
+// than nsample hits needs the nsample SMALLEST indices: it is redone by one wave scanning the whole cloud in index
+// order with ballot-ordered compaction (rare: a dense cluster such as the target gripper cloud).
+// Same distance arithmetic, same strict comparison, so idx and cnt are bit-identical to the brute-force kernel.
+constexpr int BQG = 48;            // columns per side
+constexpr int BQG_THREADS = 512;
+constexpr int BQ_HC = 48;          // hits of a query kept in LDS (the rest of a long row goes through its global row)
+
+__device__ __forceinline__ int bq_cell(float v, float origin, float inv_h) {
+  const int c = (int)floorf((v - origin) * inv_h);
+  return c < 0 ? 0 : (c >= BQG ? BQG - 1 : c);
+}
+__device__ __forceinline__ int sort64(int v, int lane) {  // ascending bitonic sort of one key per lane
+#pragma unroll
+  for (int k = 2; k <= 64; k <<= 1)
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const int o = __shfl_xor(v, j);
+      const bool up = (lane & k) == 0, lower = (lane & j) == 0;
+      v = (lower == up) ? min(v, o) : max(v, o);
+    }
+  return v;
+}
+
+// GS-lane groups of a wave each sort one short row (n <= GS keys) and write it out with its padding
+template <int GS, class Fetch>
+__device__ __forceinline__ void bq_sort_rows(int j, int jn_left, const unsigned short *qcnt, Fetch &&fetch, int32_t *rows,
+                                             int nsample, int32_t *cnt_row, int lane) {
+  const int g = lane / GS, hl = lane % GS, jj = j + g;
+  const bool live = g < jn_left;
+  const int nn = live ? qcnt[jj] : 0;
+  int v = live ? fetch(jj, hl, nn) : 0x7FFFFFFF;
+#pragma unroll
+  for (int k = 2; k <= GS; k <<= 1)
+#pragma unroll
+    for (int s = k >> 1; s > 0; s >>= 1) {
+      const int o = __shfl_xor(v, s);
+      const bool up = (hl & k) == 0, lower = (hl & s) == 0;
+      v = (lower == up) ? min(v, o) : max(v, o);
+    }
+  const int first = nn > 0 ? __shfl(v, g * GS) : 0;
+  if (live) {
+    int32_t *rr = rows + (size_t)jj * nsample;
+    rr[hl] = hl < nn ? v : first;
+    for (int l = hl + GS; l < nsample; l += GS) rr[l] = first;
+    if (cnt_row && hl == 0) cnt_row[jj] = nn;
+  }
+}
+
+__global__ void __launch_bounds__(BQG_THREADS)
+    ball_query_grid_kernel(const float *__restrict__ new_xyz, int new_stride, const float *__restrict__ xyz, int stride,
+                           int N, int npoint, float radius2, float inv_h, int nsample, int32_t *__restrict__ idx,
+                           int32_t *__restrict__ cnt_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float *sx = reinterpret_cast<float *>(smem), *sy = sx + N, *sz = sy + N;
+  int *ccount = reinterpret_cast<int *>(sz + N);                                    // [G*G] counts, then cursors
+  unsigned short *cstart = reinterpret_cast<unsigned short *>(ccount + BQG * BQG);  // [G*G + 1]
+  unsigned short *order = cstart + BQG * BQG + 2;                                   // [N] point ids by column
+  unsigned short *qcnt = order + ((N + 1) & ~1);                                    // [npoint] hits per query
+  unsigned short *ovf = qcnt + ((npoint + 1) & ~1);                                 // [npoint] overflowing queries
+  unsigned short *hbuf = ovf + ((npoint + 1) & ~1);                                 // [npoint][BQ_HC] first hits of a row
+  __shared__ float red[2 * (BQG_THREADS / 64)];
+  __shared__ int scan_s[BQG_THREADS / 64];
+  __shared__ int n_ovf;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float *pts = xyz + (size_t)b * N * stride;
+  const float *ctr = new_xyz + (size_t)b * npoint * new_stride;
+  int32_t *rows = idx + (size_t)b * npoint * nsample;
+
+  // ---- cloud -> LDS, lower corner of its (x, y) bounding box
+  float mnx = __builtin_inff(), mny = __builtin_inff();
+  for (int k = tid; k < N; k += BQG_THREADS) {
+    const float px = pts[(size_t)k * stride], py = pts[(size_t)k * stride + 1], pz = pts[(size_t)k * stride + 2];
+    sx[k] = px, sy[k] = py, sz[k] = pz;
+    mnx = fminf(mnx, px), mny = fminf(mny, py);
+  }
+  for (int i = tid; i < BQG * BQG; i += BQG_THREADS) ccount[i] = 0;
+  if (tid == 0) n_ovf = 0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mnx = fminf(mnx, __shfl_xor(mnx, o)), mny = fminf(mny, __shfl_xor(mny, o));
+  if (lane == 0) red[2 * wave] = mnx, red[2 * wave + 1] = mny;
+  __syncthreads();
+  float ox = red[0], oy = red[1];
+#pragma unroll
+  for (int w = 1; w < BQG_THREADS / 64; ++w) ox = fminf(ox, red[2 * w]), oy = fminf(oy, red[2 * w + 1]);
+
+  // ---- counting sort of the point ids by column
+  for (int k = tid; k < N; k += BQG_THREADS)
+    atomicAdd(&ccount[bq_cell(sx[k], ox, inv_h) * BQG + bq_cell(sy[k], oy, inv_h)], 1);
+  __syncthreads();
+  {
+    constexpr int PER = (BQG * BQG + BQG_THREADS - 1) / BQG_THREADS;
+    int local[PER], sum = 0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int c = tid * PER + i;
+      local[i] = c < BQG * BQG ? ccount[c] : 0;
+      sum += local[i];
+    }
+    int inc = sum;  // inclusive scan over the workgroup
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(inc, o);
+      if (lane >= o) inc += t;
+    }
+    if (lane == 63) scan_s[wave] = inc;
+    __syncthreads();
+    int base = inc - sum;
+    for (int w = 0; w < wave; ++w) base += scan_s[w];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int c = tid * PER + i;
+      if (c < BQG * BQG) {
+        cstart[c] = (unsigned short)base;
+        ccount[c] = base;  // running cursor for the scatter
+        base += local[i];
+      }
+    }
+    if (tid == BQG_THREADS - 1) cstart[BQG * BQG] = (unsigned short)N;
+  }
+  __syncthreads();
+  for (int k = tid; k < N; k += BQG_THREADS) {
+    const int at = atomicAdd(&ccount[bq_cell(sx[k], ox, inv_h) * BQG + bq_cell(sy[k], oy, inv_h)], 1);
+    order[at] = (unsigned short)k;
+  }
+  __syncthreads();
+
+  auto col_range = [&](float cx, float cy, int &x0, int &x1, int &y0, int &y1) __attribute__((always_inline)) {
+    const int ix = (int)floorf((cx - ox) * inv_h), iy = (int)floorf((cy - oy) * inv_h);
+    x0 = min(max(ix - 1, 0), BQG - 1), x1 = min(max(ix + 1, 0), BQG - 1);
+    y0 = min(max(iy - 1, 0), BQG - 1), y1 = min(max(iy + 1, 0), BQG - 1);
+  };
+
+  // ---- one thread per query: hits of the 3 x 3 columns around it, appended unsorted to its row
+  for (int j = tid; j < npoint; j += BQG_THREADS) {
+    const float cx = ctr[(size_t)j * new_stride], cy = ctr[(size_t)j * new_stride + 1], cz = ctr[(size_t)j * new_stride + 2];
+    int x0, x1, y0, y1;
+    col_range(cx, cy, x0, x1, y0, y1);
+    int32_t *out = rows + (size_t)j * nsample;
+    int cnt = 0;
+    bool over = false;
+    auto hit = [&](int k) __attribute__((always_inline)) {
+      if (cnt < BQ_HC) hbuf[j * BQ_HC + cnt] = (unsigned short)k;
+      else if (cnt < nsample) out[cnt] = k;
+      else over = true;
+      ++cnt;
+    };
+    for (int gx = x0; gx <= x1; ++gx) {
+      // columns y0..y1 of one x are adjacent in the sorted order: one contiguous range
+      const int e0 = cstart[gx * BQG + y0], e1 = cstart[gx * BQG + y1 + 1];
+      int e = e0;
+      for (; e + 4 <= e1; e += 4) {  // four candidates in flight: the id -> coordinate LDS reads are dependent
+        int k[4];
+        float d2[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) k[u] = order[e + u];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float dx = cx - sx[k[u]], dy = cy - sy[k[u]], dz = cz - sz[k[u]];
+          d2[u] = mpx_fma(dz, dz, mpx_fma(dy, dy, dx * dx));
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (d2[u] < radius2) hit(k[u]);
+      }
+      for (; e < e1; ++e) {
+        const int k = order[e];
+        const float dx = cx - sx[k], dy = cy - sy[k], dz = cz - sz[k];
+        if (mpx_fma(dz, dz, mpx_fma(dy, dy, dx * dx)) < radius2) hit(k);
+      }
+    }
+    if (over) ovf[atomicAdd(&n_ovf, 1)] = (unsigned short)j;
+    qcnt[j] = (unsigned short)(cnt < nsample ? cnt : nsample);
+  }
+  __threadfence_block();
+  __syncthreads();
+
+  // ---- queries with more than nsample hits: whole cloud in index order, ballot-ordered compaction (sorted by construction)
+  const int novf = n_ovf;
+  for (int o = wave; o < novf; o += BQG_THREADS / 64) {
+    const int j = ovf[o];
+    const float cx = ctr[(size_t)j * new_stride], cy = ctr[(size_t)j * new_stride + 1], cz = ctr[(size_t)j * new_stride + 2];
+    int32_t *out = rows + (size_t)j * nsample;
+    int have = 0;
+    for (int k0 = 0; k0 < N && have < nsample; k0 += 64) {
+      const int k = k0 + lane;
+      bool hit = false;
+      if (k < N) {
+        const float dx = cx - sx[k], dy = cy - sy[k], dz = cz - sz[k];
+        hit = mpx_fma(dz, dz, mpx_fma(dy, dy, dx * dx)) < radius2;
+      }
+      const unsigned long long m = __ballot(hit);
+      const int pos = have + __popcll(m & ((1ull << lane) - 1ull));
+      if (hit && pos < nsample) {
+        if (pos < BQ_HC) hbuf[j * BQ_HC + pos] = (unsigned short)k;
+        else out[pos] = k;
+      }
+      have += __popcll(m);
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+
+  // ---- per row: sort the hits by point index, pad with the first one, write the count
+  auto fetch = [&](int j, int e, int n) __attribute__((always_inline)) {  // element e of row j (or +inf)
+    if (e >= n) return 0x7FFFFFFF;
+    return e < BQ_HC ? (int)hbuf[j * BQ_HC + e] : rows[(size_t)j * nsample + e];
+  };
+  for (int j0 = wave * 64; j0 < npoint; j0 += BQG_THREADS) {
+    const int jn = min(64, npoint - j0);
+    int q = 0;
+    while (q < jn) {
+      const int j = j0 + q, n = qcnt[j];
+      const int n2 = q + 1 < jn ? qcnt[j + 1] : 0;
+      int m4 = max(n, n2);
+      if (q + 2 < jn) m4 = max(m4, (int)qcnt[j + 2]);
+      if (q + 3 < jn) m4 = max(m4, (int)qcnt[j + 3]);
+      int32_t *crow = cnt_out ? cnt_out + (size_t)b * npoint : nullptr;
+      if (m4 <= 16) {  // four short rows at once, one per 16 lanes
+        bq_sort_rows<16>(j, jn - q, qcnt, fetch, rows, nsample, crow, lane);
+        q += 4;
+        continue;
+      }
+      if (n <= 32 && n2 <= 32) {  // two rows, one per half-wave
+        bq_sort_rows<32>(j, jn - q, qcnt, fetch, rows, nsample, crow, lane);
+        q += 2;
+        continue;
+      }
+      int32_t *row = rows + (size_t)j * nsample;
+      int a = fetch(j, lane, n), bb = 0x7FFFFFFF;
+      if (n > 64) {  // two keys per lane: elements lane and lane + 64 of a 128-key network
+        bb = fetch(j, lane + 64, n);
+#pragma unroll
+        for (int k = 2; k <= 128; k <<= 1)
+#pragma unroll
+          for (int s = k >> 1; s > 0; s >>= 1) {
+            if (s == 64) {
+              const int lo = min(a, bb), hi = max(a, bb);
+              a = lo, bb = hi;
+            } else {
+              const int oa = __shfl_xor(a, s), ob = __shfl_xor(bb, s);
+              const bool lower = (lane & s) == 0;
+              const bool upa = (lane & k) == 0, upb = ((lane + 64) & k) == 0;
+              a = (lower == upa) ? min(a, oa) : max(a, oa);
+              bb = (lower == upb) ? min(bb, ob) : max(bb, ob);
+            }
+          }
+      } else if (n > 1) {
+        a = sort64(a, lane);
+      }
+      const int first = n > 0 ? __shfl(a, 0) : 0;
+      for (int l = lane; l < nsample; l += 64) {
+        const int v = l < 64 ? a : bb;
+        row[l] = l < n ? v : first;
+      }
+      if (cnt_out && lane == 0) cnt_out[(size_t)b * npoint + j] = n;
+      ++q;
+    }
+  }
+  __syncthreads();
+}
+
 MPX_EXPORT int mpx_ball_query(const float *new_xyz, int new_stride, const float *xyz, int stride, int B, int N,
                               int npoint, float radius, int nsample, int32_t *idx, int32_t *cnt,
                               mpx_stream_t stream) {
@@ -303,6 +571,22 @@ MPX_EXPORT int mpx_ball_query(const float *new_xyz, int new_stride, const float 
   MPX_REQUIRE(B <= 65535, "mpx_ball_query: B > 65535 (slab the batch)");
   if (B == 0 || npoint == 0 || nsample == 0) return 0;
   const float r2 = radius * radius;  // float product, like the reference kernel
+  // large cloud, small radius (the first set-abstraction module): bucketed search, bit-identical output
+  static const int use_grid = getenv("MPX_BQ_GRID") ? atoi(getenv("MPX_BQ_GRID")) : 1;
+  if (use_grid && N >= 2048 && N <= 8192 && nsample <= 128 && nsample > BQ_HC && npoint <= 4096 && radius > 0.0f &&
+      radius * BQG < 4.0f) {  // columns of side ~radius must still resolve the scene (48 x radius < 4 m)
+    const size_t lds = (size_t)3 * N * 4 + (size_t)BQG * BQG * 4 + (size_t)(BQG * BQG + 2) * 2 +
+                       (size_t)((N + 1) & ~1) * 2 + (size_t)((npoint + 1) & ~1) * 2 * 2 + (size_t)npoint * BQ_HC * 2;
+    if (lds <= 158 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ball_query_grid_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      MPX_REQUIRE(e == hipSuccess, "mpx_ball_query: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
+      const float inv_h = 1.0f / (radius * 1.0001f);
+      hipLaunchKernelGGL(ball_query_grid_kernel, dim3(B), dim3(BQG_THREADS), lds, mpx_s(stream), new_xyz, new_stride, xyz,
+                         stride, N, npoint, r2, inv_h, nsample, idx, cnt);
+      MPX_LAUNCH_CHECK("mpx_ball_query");
+    }
+  }
   dim3 g(cdiv(npoint, 256), B), t(256);
   const bool al64 = stride == 4 && ((uintptr_t)xyz & 63) == 0 && N % 4 == 0;
   if (al64)

@@ -1,22 +1,20 @@
-"""How full are the ball-query neighbourhoods? (development aid)"""
+"""Neighbourhood-size statistics of the two ball queries on bench-like scenes (development aid)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "motion-policy-networks_amd")]
-import numpy as np, torch
+import torch
 from mpinets_amd.model import MotionPolicyNetwork
 from mpinets_amd.scenes import make_problem_batch
 dev = torch.device("cuda:0")
-torch.manual_seed(0)
 mdl = MotionPolicyNetwork().to(dev).eval()
-for kinds in (("tabletop",), ("cubby",), ("dresser",)):
-    prob = make_problem_batch(256, seed=3, device=dev, kinds=kinds, M1=40, device_clouds=True)
+for kinds, M1 in ((("tabletop",), 16), (("tabletop", "cubby", "dresser"), 40)):
+    prob = make_problem_batch(2048, seed=1, device=dev, kinds=kinds, M1=M1, scene_pool=512, device_clouds=True)
     aux = {}
     with torch.no_grad():
         mdl(prob["xyz"], prob["q_norm"], aux=aux)
-    for name in ("ball_idx1", "ball_idx2"):
-        nbr = aux[name]
-        cnt = (nbr != nbr[..., :1]).sum(-1) + 1   # unique slots (pads repeat the first hit)
-        tiles = (cnt + 31) // 32
-        c = cnt.float()
-        print(f"{kinds[0]:9s} {name}: cnt mean {c.mean():6.1f} median {c.median():5.0f} p90 {c.quantile(0.9):5.0f} max {c.max():4.0f} | "
-              f"tiles mean {tiles.float().mean():.3f} of 4  hist {[int((tiles==t).sum()) for t in (1,2,3,4)]}")
+    for name in ("ball_cnt1", "ball_cnt2"):
+        c = aux[name]
+        mx = c.max(dim=1).values.float()
+        print(kinds, name, "mean %.1f" % c.float().mean().item(), "per-env max: median %d p90 %d p99 %d max %d" % tuple(
+            int(torch.quantile(mx, q).item()) for q in (0.5, 0.9, 0.99, 1.0)),
+            "envs with max>48: %.3f  >56: %.3f  >64: %.3f" % tuple((mx > t).float().mean().item() for t in (48, 56, 64)))
