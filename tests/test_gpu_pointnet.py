@@ -81,6 +81,34 @@ def test_ball_query_bit_exact(oracle, B, N, npoint, radius, nsample, stride):
     assert (ref[:, -1] == 0).all() and (rcnt[:, -1] == 0).all()
 
 
+@pytest.mark.parametrize("N,npoint,stride", [(2048, 300, 3), (4096, 512, 4), (6272, 512, 4), (2047, 128, 4), (8192, 700, 3)])
+def test_ball_query_bucketed_path_edge_cases(oracle, N, npoint, stride):
+    """The large-cloud / small-radius path (column grid in LDS) must reproduce the reference order exactly:
+    a dense cluster (> nsample hits: the nsample SMALLEST indices), points far outside the grid extent, duplicated
+    points, points exactly on a cell border, empty neighbourhoods.  N = 2047 takes the brute-force kernel."""
+    from mpinets_amd.pointnet2 import ball_query
+
+    rng = np.random.default_rng(N + npoint)
+    B, r, ns = 3, 0.05, 128
+    x = np.zeros((B, N, stride), np.float32)
+    x[..., :3] = rng.uniform(-0.6, 0.9, (B, N, 3))
+    x[:, 100:500, :3] = np.float32([0.3, -0.2, 0.4]) + rng.normal(scale=0.012, size=(B, 400, 3))  # dense: ~400 hits
+    x[:, 500:520, :3] = x[:, 100:120, :3]                                    # duplicates of cluster points
+    x[:, 600:620, :3] = rng.uniform(5.0, 9.0, (B, 20, 3))                    # far outside the 48-column extent
+    x[:, 620:640, 0] = x[:, :1, 0].min() + 0.05 * 1.0001 * np.arange(20)     # on column borders
+    x[:, N - 5:, :3] = np.float32([-3.0, -3.0, 0.0])                         # moves the grid origin far away
+    centres = np.ascontiguousarray(x[:, rng.permutation(N)[:npoint], :3]).copy()
+    centres[:, 0] = [0.3, -0.2, 0.4]          # centre of the dense cluster
+    centres[:, 1] = x[:, 605, :3]             # in the far-away group
+    centres[:, 2] = 50.0                      # nothing around
+    centres[:, 3] = x[:, 625, :3]
+    idx, cnt = ball_query(r, ns, T(x), T(centres), return_counts=True)
+    ref, rcnt = oracle.ball_query(centres, x, r, ns, return_counts=True)
+    assert rcnt[:, 0].min() == ns and rcnt[:, 2].max() == 0
+    np.testing.assert_array_equal(cnt.cpu().numpy(), rcnt)
+    np.testing.assert_array_equal(idx.cpu().numpy(), ref)
+
+
 def test_group_points_matches_oracle(oracle):
     from mpinets_amd.pointnet2 import ball_query, furthest_point_sample, query_and_group
 
