@@ -91,14 +91,15 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PTS <
   float *nxyz = new_xyz ? new_xyz + (size_t)b * npoint * new_stride : nullptr;
   const unsigned bsmask = (1u << log2bs) - 1u;
 
-  float x[PTS], y[PTS], z[PTS], dist[PTS];
-  unsigned keylo[PTS];
+  // per point one 64-bit key {low: tie rank (constant), high: bits of its running min distance} kept in one
+  // register pair: the v_min overwrites the high half in place and the pair feeds v_max_f64 directly
+  float x[PTS], y[PTS], z[PTS];
+  u64 key[PTS];
 #pragma unroll
   for (int i = 0; i < PTS; ++i) {
     const int k = tid + i * nthr;
     x[i] = y[i] = z[i] = 0.0f;
-    dist[i] = 0.0f;  // a point that may never be picked keeps key == 0
-    keylo[i] = 0u;
+    key[i] = 0;  // a point that may never be picked keeps key == 0 (distance +0, rank 0)
     if (k < N) {
       x[i] = pts[(size_t)k * stride + 0];
       y[i] = pts[(size_t)k * stride + 1];
@@ -108,11 +109,10 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PTS <
       sz[k] = z[i];
       const float mag = mpx_fma(z[i], z[i], mpx_fma(y[i], y[i], x[i] * x[i]));
       if (!(mag <= 1e-3f)) {
-        dist[i] = 1e10f;
         // tie order of the reference: smaller (bitrev(k mod bs), k / bs) wins -> larger key wins.
         // brev of a < 2^9 value lands in the top 9 bits: keeping the top 16 preserves the order.
         const unsigned rank = (__brev((unsigned)k & bsmask) & 0xFFFF0000u) | ((unsigned)k >> log2bs);
-        keylo[i] = 0xFFFFFFFFu - rank;
+        key[i] = pack64(0xFFFFFFFFu - rank, __float_as_uint(1e10f));
       }
     }
   }
@@ -136,10 +136,10 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PTS <
       const float dx = x[i] - x1, dy = y[i] - y1, dz = z[i] - z1;
       const float d = mpx_fma(dz, dz, mpx_fma(dy, dy, dx * dx));
       float d2;  // min(d, temp[k]) as one v_min_f32 (fminf() adds a canonicalising v_max per call)
-      asm("v_min_f32 %0, %1, %2" : "=v"(d2) : "v"(d), "v"(dist[i]));
-      dist[i] = d2;
-      // a point that is not a candidate has keylo == 0 and dist == +0, so its whole key is 0
-      best = umax64(best, pack64(keylo[i], __float_as_uint(d2)));
+      asm("v_min_f32 %0, %1, %2" : "=v"(d2) : "v"(d), "v"(__uint_as_float((unsigned)(key[i] >> 32))));
+      // a point that is not a candidate has rank 0 and distance +0, so its whole key is 0
+      key[i] = pack64((unsigned)key[i], __float_as_uint(d2));
+      best = umax64(best, key[i]);
     }
     best = wave_max64(best);
     u64 *slot = slots + (j & 1) * 16;
