@@ -5,12 +5,15 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json metric, "at 8192 envs"): every rank owns 8192 independent synthetic
-tabletop planning problems (weak scaling; no collective on the step, one final gather).  One STEP
-= one pass of the hot path over the whole batch with inputs resident in HBM:
-policy forward (FPS 6272->512, ball query, fused grouped MLP, FPS 512->128, ball query, fused MLP,
-group-all MLP, heads) -> joint update -> FK + robot-cloud refresh in place -> swept-sphere SDF
-collision check of the new configuration.  fp32 end to end (fp32 MFMA for every contraction).
+Workload (BASELINE.json metric "at 8192 envs" = the per-GPU share of its largest configuration, configs[4]:
+"mixed tabletop/cubby/dresser 65536 envs, closed-loop point-cloud re-render + policy step, 8 GPUs"): every
+rank owns 8192 independent synthetic planning problems, one third each tabletop / cubby / dresser-like scenes
+(weak scaling; no collective on the step, one final gather).  One STEP = one pass of the hot path over the
+whole batch with inputs resident in HBM:
+scene cloud re-rendered from the primitives (4096 points per environment) -> policy forward (FPS 6272->512,
+ball query, fused grouped MLP, FPS 512->128, ball query, fused MLP, group-all MLP, heads) -> joint update ->
+FK + robot-cloud refresh in place -> swept-sphere SDF collision check of the new configuration.
+fp32 end to end (fp32 MFMA for every contraction).
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (the SA2 fused grouped MLP),
 timed live with HIP events on the launch stream inside the timed region; `cpu_baseline` is the
@@ -102,6 +105,8 @@ def stage_table(prof, steps, B, sa1_ms, sa1_exec, sa2_ms, sa2_exec):
                        "achieved": bq_pairs / (ms("mpx_ball_query") * 1e-3) / 1e9, "unit": "G point-pair tests/s"},
         "sa1_grouped_mlp": mf(sa1_exec, sa1_ms), "sa2_grouped_mlp": mf(sa2_exec, sa2_ms),
         "dense_layers": dict(mf(lin_flops, lin_ms), note="SA2 layer 1 (factored) + group-all module + heads"),
+        "scene_cloud_rerender": dict(hbm(B * 4096 * 12.0, ms("mpx_scene_cloud")),
+                                     note="49,152 B written per env; the per-env urn (one lane) is the long pole, not HBM"),
         "groupnorm_leaky": {"bound": "hbm", "ms": ms("mpx_groupnorm_leaky")},
         "joint_step": {"bound": "latency", "ms": ms("mpx_joint_step")},
     }
@@ -120,7 +125,7 @@ def main():
     ap.add_argument("--envs", type=int, default=8192, help="environments per GPU")
     ap.add_argument("--fast-steps", type=int, default=3, help="steps of the secondary bf16x3 measurement (0 = skip)")
     ap.add_argument("--extra", type=int, default=1, help="also time BASELINE configs 2 and 4 (collision validation only)")
-    ap.add_argument("--c5-steps", type=int, default=2, help="steps of the config-5-shaped extra (mixed scenes, scene re-render); 0 = skip")
+    ap.add_argument("--static-steps", type=int, default=2, help="steps of the extra without scene re-render on tabletop-only scenes (BASELINE config 3 shape at this batch size); 0 = skip")
     ap.add_argument("--cpu-envs", type=int, default=64, help="env-steps in the CPU baseline sample (0 = skip)")
     ap.add_argument("--scene-pool", type=int, default=1024, help="distinct host-generated primitive sets tiled over the batch (clouds are drawn per env on the device)")
     args = ap.parse_args()
@@ -143,16 +148,16 @@ def main():
     torch.manual_seed(0)  # identical random-init weights on every rank (replicated, like a checkpoint)
     model = MotionPolicyNetwork().to(dev).eval()
     envs = shard.env_range(rank, n_gpus, B)
-    prob = make_problem_batch(B, seed=1000 + rank, device=dev, kinds=("tabletop",), M1=16, M2=16,
+    prob = make_problem_batch(B, seed=1000 + rank, device=dev, kinds=("tabletop", "cubby", "dresser"), M1=40, M2=16,
                               scene_pool=args.scene_pool, device_clouds=True)
-    eng = RolloutEngine(model, prob)
+    eng = RolloutEngine(model, prob, rerender_scene=True, scene_seed=17 + rank)
 
     for _ in range(args.warmup):
         eng.step()
     torch.cuda.synchronize()
     shard.barrier()
     _lib.profile_start("mpx_sa_mlp", "mpx_sa_mlp_factored", "mpx_fps", "mpx_ball_query", "mpx_linear", "mpx_linear_rowmax",
-                        "mpx_franka_cloud", "mpx_franka_collision", "mpx_joint_step", "mpx_groupnorm_leaky")
+                        "mpx_franka_cloud", "mpx_franka_collision", "mpx_joint_step", "mpx_groupnorm_leaky", "mpx_scene_cloud")
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -228,42 +233,41 @@ def main():
             c2_cpu = 1024 / (time.perf_counter() - th)
         extra = {
             "c4_collision_validation": {"envs": B, "waypoints": 50, "ms": c4_ms, "env_waypoints_per_s": B * 50 / c4_ms * 1e3,
-                                        "what": "FK + 56-sphere SDF vs 16 cuboids + 16 cylinders, has_collision[B] (model.py:293-314)"},
+                                        "what": "FK + 56-sphere SDF vs 40 cuboids + 16 cylinders (zero-padded), has_collision[B] (model.py:293-314)"},
             "c2_fk_sdf_1024": {"envs": 1024, "ms": c2_ms, "env_steps_per_s": 1024 / c2_ms * 1e3,
                                "cpu_port_env_steps_per_s": c2_cpu, "cpu_cores": 1,
                                "what": "FK + sphere SDF, flags + min-sdf [1024,56] written"},
         }
 
-    # ---- extra: BASELINE config 5 shape -- mixed tabletop / cubby / dresser scenes, scene cloud re-rendered
-    # from the primitives at every step, then the same closed-loop policy step (all ranks, weak scaling)
-    c5 = None
-    if args.extra and args.c5_steps > 0:
-        prob5 = make_problem_batch(B, seed=5000 + rank, device=dev, kinds=("tabletop", "cubby", "dresser"), M1=40,
-                                   M2=16, scene_pool=args.scene_pool, device_clouds=True)
-        eng5 = RolloutEngine(model, prob5, rerender_scene=True, scene_seed=17 + rank)
-        eng5.step()
+    # ---- extra: the same closed-loop step WITHOUT the scene re-render, on tabletop-only scenes (16 cuboids + 16
+    # cylinders): the reference's rollout re-samples only the robot points (model.py:180-181); all ranks, weak scaling
+    static = None
+    if args.extra and args.static_steps > 0:
+        prob_s = make_problem_batch(B, seed=5000 + rank, device=dev, kinds=("tabletop",), M1=16, M2=16,
+                                    scene_pool=args.scene_pool, device_clouds=True)
+        eng_s = RolloutEngine(model, prob_s)
+        eng_s.step()
         torch.cuda.synchronize()
         shard.barrier()
-        names5 = ("mpx_scene_cloud", "mpx_sa_mlp", "mpx_sa_mlp_factored", "mpx_fps", "mpx_ball_query", "mpx_linear", "mpx_linear_rowmax")
-        _lib.profile_start(*names5)
-        t5 = time.perf_counter()
-        for _ in range(args.c5_steps):
-            eng5.step()
+        names_s = ("mpx_sa_mlp", "mpx_sa_mlp_factored", "mpx_fps", "mpx_ball_query", "mpx_linear", "mpx_linear_rowmax")
+        _lib.profile_start(*names_s)
+        ts0 = time.perf_counter()
+        for _ in range(args.static_steps):
+            eng_s.step()
         torch.cuda.synchronize()
         shard.barrier()
-        el5 = shard.max_over_ranks(time.perf_counter() - t5, dev)
-        prof5 = _lib.profile_stop()
-        c5 = {"envs_per_gpu": B, "steps": args.c5_steps, "ms_per_step": el5 / args.c5_steps * 1e3,
-              "env_steps_per_s": B * n_gpus * args.c5_steps / el5, "dtype": "f32",
-              "collision_rate": float((eng5.flags != 0).float().mean().item()),
-              "kernels_ms_per_step": {k[4:]: float(np.sum(v)) / args.c5_steps for k, v in prof5.items()},
-              "mean_distinct_neighbours": [float(c.float().mean().item()) for c in model.point_cloud_encoder.last_counts],
-              "what": "mixed tabletop/cubby/dresser scenes (40 cuboids + 16 cylinders, zero-padded); every step: "
-                      "scene cloud re-render (4096 pts from the primitives) + policy forward + joint update + FK "
-                      "cloud refresh + collision check"}
-        del eng5, prob5
+        el_s = shard.max_over_ranks(time.perf_counter() - ts0, dev)
+        prof_s = _lib.profile_stop()
+        static = {"envs_per_gpu": B, "steps": args.static_steps, "ms_per_step": el_s / args.static_steps * 1e3,
+                  "env_steps_per_s": B * n_gpus * args.static_steps / el_s, "dtype": "f32",
+                  "collision_rate": float((eng_s.flags != 0).float().mean().item()),
+                  "kernels_ms_per_step": {k[4:]: float(np.sum(v)) / args.static_steps for k, v in prof_s.items()},
+                  "mean_distinct_neighbours": [float(c.float().mean().item()) for c in model.point_cloud_encoder.last_counts],
+                  "what": "tabletop scenes (16 cuboids + 16 cylinders, zero-padded), static scene cloud; every step: policy "
+                          "forward + joint update + FK cloud refresh + collision check"}
+        del eng_s, prob_s
         if extra is not None:
-            extra["c5_mixed_rerender"] = c5
+            extra["tabletop_static_scene"] = static
 
     if rank == 0:
         # SA1 = mpx_sa_mlp; SA2 = mpx_sa_mlp_factored (first layer evaluated per point / per query by two
@@ -309,9 +313,10 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"closed-loop policy step, {B} tabletop envs per GPU: PointNet++ forward "
-                            "(2048 robot + 4096 scene + 128 target pts) + joint update + FK robot-cloud refresh "
-                            "+ 56-sphere SDF collision check vs 16 cuboids + 16 cylinders",
+                "workload": f"BASELINE configs[4] per-GPU share: closed-loop step over {B} mixed tabletop / cubby / "
+                            "dresser envs per GPU: scene cloud re-render (4096 pts from the primitives) + PointNet++ "
+                            "forward (2048 robot + 4096 scene + 128 target pts) + joint update + FK robot-cloud "
+                            "refresh + 56-sphere SDF collision check vs 40 cuboids + 16 cylinders (zero-padded)",
                 "envs_per_gpu": B, "global_envs": B * n_gpus, "points_per_env": int(prob["xyz"].size(1)),
                 "parallelism": f"env-sharded x{n_gpus}, no collective on the step",
                 "weights": "random-init (seed 0)",

@@ -199,7 +199,7 @@ int mpx_depth_render(const float *cam_poses, float fx, float fy, float cx, float
 /* np.random.choice(len(cloud), n_out, replace=False) of run_inference.py:78-85 on the device: every valid
  * pixel gets a Philox4x32-10 key (seed, environment, pixel); the n_out smallest keys are written as world
  * points in key order to out (strides in floats).  count [B] = valid pixels; an environment with fewer than
- * n_out of them is left untouched (the caller raises like numpy).  n_out <= 8128.                    */
+ * n_out of them is left untouched (the caller raises like numpy).  n_out <= 4096.                    */
 int mpx_depth_select(const float *depth, const float *cam_poses, float fx, float fy, float cx, float cy,
                      int W, int H, int B, int n_out, uint64_t seed, float *out, int64_t out_batch_stride,
                      int out_point_stride, int32_t *count, mpx_stream_t stream);
@@ -207,8 +207,9 @@ int mpx_depth_select(const float *depth, const float *cam_poses, float fx, float
 /* ---- scene point clouds: mpinets/geometry.py:571-608 (construct_mixed_point_cloud), batched ----- */
 
 /* For every environment: area-proportional pool sizes int(p_i*N)+500, N pool slots drawn without
- * replacement in random order (only the owning obstacle matters: an urn process), one fresh
- * uniform surface sample per slot, labels = shuffled 1..K.  Counter RNG Philox4x32-10 keyed by
+ * replacement in random order (every slot gets a Philox key, the N smallest keys win in key order;
+ * only the owning obstacle matters), one fresh uniform surface sample per slot, labels = shuffled
+ * 1..K.  N <= 4096.  Counter RNG Philox4x32-10 keyed by
  * (seed, environment): results depend on nothing else.  Zero-volume primitives are skipped;
  * obstacle ids count cuboids first, then cylinders.  An environment without obstacles gets
  * ids 0xFFFF and zero points (the reference returns an empty array, geometry.py:586-587).

@@ -9,6 +9,7 @@
 // PyBullet rasterises meshes and quantises depth; this is the exact-geometry equivalent (parity unpinned).
 #include "depth_device.h"
 #include "philox.h"
+#include "select_device.h"
 
 enum { STREAM_DEPTH = 9 };
 
@@ -46,86 +47,27 @@ __global__ void __launch_bounds__(256)
   depth[(size_t)b * W * H + pix] = (robot || !(best < far_clip)) ? -1.0f : best;
 }
 
-__device__ __forceinline__ uint32_t pixel_key(uint32_t pix, uint32_t env, uint32_t k0, uint32_t k1) {
-  return philox4x32(pix, env, STREAM_DEPTH, 0u, k0, k1).c[0];
-}
-
 // One workgroup per environment: picks n_out of the valid pixels (smallest Philox keys; ties by pixel id) and
 // writes their world points in key order.  count[b] = number of valid pixels; if it is < n_out nothing is written.
-constexpr int SEL_THREADS = 1024, SEL_CAP = 8192, SEL_SLACK = 64;
-
 __global__ void __launch_bounds__(SEL_THREADS)
     depth_select_kernel(const float *__restrict__ depth, const float *__restrict__ cam, float fx, float fy, float cx,
                         float cy, int W, int H, int n_out, uint32_t k0, uint32_t k1, float *__restrict__ out,
                         int64_t obs, int ops, int32_t *__restrict__ count) {
   __shared__ unsigned long long sel[SEL_CAP];
   __shared__ int hist[2048];
-  __shared__ int s_prefix, s_need, s_n;
+  __shared__ int s3[3];
   const int b = blockIdx.x, tid = threadIdx.x, HW = W * H;
   const float *dp = depth + (size_t)b * HW;
-  uint32_t prefix = 0;  // key bits fixed so far
-  int need = n_out;     // how many still to take from the keys matching the prefix
-  // three radix levels: 11 + 11 + 10 bits
-  const int shift[3] = {21, 10, 0}, bits[3] = {11, 11, 10};
-  int total_valid = 0;
-  for (int lvl = 0; lvl < 3; ++lvl) {
-    for (int i = tid; i < 2048; i += SEL_THREADS) hist[i] = 0;
-    __syncthreads();
-    const uint32_t hi_mask = lvl == 0 ? 0u : (0xFFFFFFFFu << (shift[lvl] + bits[lvl]));
-    for (int pix = tid; pix < HW; pix += SEL_THREADS) {
-      if (dp[pix] < 0.0f) continue;
-      const uint32_t key = pixel_key(pix, b, k0, k1);
-      if ((key & hi_mask) == prefix) atomicAdd(&hist[(key >> shift[lvl]) & ((1u << bits[lvl]) - 1u)], 1);
-    }
-    __syncthreads();
-    if (tid == 0) {
-      int cum = 0, bin = 0;
-      const int nb = 1 << bits[lvl];
-      int tot = 0;
-      for (int i = 0; i < nb; ++i) tot += hist[i];
-      if (lvl == 0) s_n = tot;
-      // first bin where the running count reaches `need`
-      for (bin = 0; bin < nb; ++bin) {
-        if (cum + hist[bin] >= need) break;
-        cum += hist[bin];
-      }
-      s_prefix = (int)(prefix | ((uint32_t)(bin < nb ? bin : nb - 1) << shift[lvl]));
-      s_need = need - cum;
-    }
-    __syncthreads();
-    prefix = (uint32_t)s_prefix;
-    need = s_need;
-    if (lvl == 0) total_valid = s_n;
-    __syncthreads();
-  }
-  if (tid == 0) count[b] = total_valid;
-  if (total_valid < n_out) return;  // np.random.choice would raise: the host reports it
-  // prefix is now the n_out-th smallest key T; take every key <= T (ties beyond `need` are cut after the sort)
-  if (tid == 0) s_n = 0;
-  for (int i = tid; i < SEL_CAP; i += SEL_THREADS) sel[i] = ~0ull;
-  __syncthreads();
-  for (int pix = tid; pix < HW; pix += SEL_THREADS) {
-    if (dp[pix] < 0.0f) continue;
-    const uint32_t key = pixel_key(pix, b, k0, k1);
-    if (key <= prefix) {
-      const int at = atomicAdd(&s_n, 1);
-      if (at < SEL_CAP) sel[at] = ((unsigned long long)key << 32) | (uint32_t)pix;
-    }
-  }
-  __syncthreads();
-  // bitonic sort of the SEL_CAP slots (unused ones hold ~0 and sink to the end)
-  for (int k = 2; k <= SEL_CAP; k <<= 1)
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = tid; i < SEL_CAP; i += SEL_THREADS) {
-        const int l = i ^ j;
-        if (l > i) {
-          const unsigned long long a = sel[i], c = sel[l];
-          const bool up = (i & k) == 0;
-          if ((a > c) == up) sel[i] = c, sel[l] = a;
-        }
-      }
-      __syncthreads();
-    }
+  const int valid = mpx_select_smallest(
+      HW, n_out,
+      [&](int g, uint32_t (&key)[4], bool (&valid)[4]) {  // one Philox block keys four consecutive pixels
+        const Philox r = philox4x32((uint32_t)g, (uint32_t)b, STREAM_DEPTH, 0u, k0, k1);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) key[u] = r.c[u], valid[u] = 4 * g + u < HW && dp[min(4 * g + u, HW - 1)] >= 0.0f;
+      },
+      sel, hist, s3);
+  if (tid == 0) count[b] = valid;
+  if (valid < n_out) return;  // np.random.choice would raise: the host reports it
   const float *P = cam + 16 * (size_t)b;
   for (int i = tid; i < n_out; i += SEL_THREADS) {
     const int pix = (int)(uint32_t)sel[i];
@@ -156,8 +98,7 @@ MPX_EXPORT int mpx_depth_select(const float *depth, const float *cam_poses, floa
                                 int W, int H, int B, int n_out, uint64_t seed, float *out, int64_t out_batch_stride,
                                 int out_point_stride, int32_t *count, mpx_stream_t stream) {
   MPX_REQUIRE(B >= 0 && W > 0 && H > 0, "mpx_depth_select: bad size");
-  MPX_REQUIRE(n_out >= 1 && n_out <= SEL_CAP - SEL_SLACK, "mpx_depth_select: n_out must be in [1, %d]",
-              SEL_CAP - SEL_SLACK);
+  MPX_REQUIRE(n_out >= 1 && n_out <= SEL_MAX_OUT, "mpx_depth_select: n_out must be in [1, %d]", SEL_MAX_OUT);
   MPX_REQUIRE(out_point_stride >= 3 && count, "mpx_depth_select: bad output");
   if (B == 0) return 0;
   hipLaunchKernelGGL(depth_select_kernel, dim3(B), dim3(SEL_THREADS), 0, mpx_s(stream), depth, cam_poses, fx, fy, cx,

@@ -7,10 +7,10 @@
 // shuffled 1..K (:594-595).  Its samples come from NumPy's global RNG inside geometrout, so only
 // the DISTRIBUTION can be matched.  This kernel draws from exactly that distribution with a counter
 // RNG (Philox4x32-10 keyed by (seed, environment)):
-//   * picking N of the pool slots without replacement in random order, and asking only which
-//     obstacle each slot belongs to, is an urn process: position j takes obstacle i with
-//     probability remaining_i / remaining_total.  One lane runs the urn of one environment
-//     (64 environments per wave) and writes obstacle ids [B,N] (uint16);
+//   * picking N of the pool slots without replacement in random order: every pool slot gets a
+//     Philox key, the N smallest keys win and their order is the output order (one workgroup per
+//     environment: radix select + LDS sort, select_device.h); only the obstacle owning each slot
+//     matters, written as obstacle ids [B,N] (uint16);
 //   * pool samples are i.i.d., so each output point is a fresh uniform sample on its obstacle's
 //     surface: one thread per point, written straight into the slab rows (x,y,z[,label]).
 // Zero-volume primitives are skipped exactly like data_loader.py:248,256 (is_zero_volume).
@@ -18,104 +18,101 @@
 // The same algorithm is restated in oracle/mpn_oracle.c (orc_scene_*), bit-exact on the ids.
 #include "common.h"
 #include "philox.h"
+#include "select_device.h"
 
 constexpr int MAX_OBS = 96;
 enum { STREAM_URN = 1, STREAM_LABEL = 2, STREAM_POINT = 3 };
 
-// ---- kernel 1: per-environment allocation, label shuffle and urn ------------------------------------
-// block 64 (one wave), one environment per lane; per-lane state in LDS (remaining[MAX_OBS] uint16).
-__global__ void __launch_bounds__(64)
+// ---- kernel 1: per-environment allocation, label shuffle and the draw of N pool slots ----------------------
+// one workgroup per environment
+__device__ __forceinline__ double obstacle_area(int m, int M1, const float *cd, const float *yr, const float *yh) {
+  if (m < M1) {
+    const float *d = cd + 3 * m;
+    if (__builtin_fabsf(d[0]) <= 1e-8f || __builtin_fabsf(d[1]) <= 1e-8f || __builtin_fabsf(d[2]) <= 1e-8f) return 0.0;
+    return 2.0 * ((double)d[0] * d[1] + (double)d[0] * d[2] + (double)d[1] * d[2]);
+  }
+  const float r = yr[m - M1], h = yh[m - M1];
+  if (__builtin_fabsf(r) <= 1e-8f || __builtin_fabsf(h) <= 1e-8f) return 0.0;
+  return 2.0 * 3.14159265358979323846 * (double)r * (double)h + 2.0 * 3.14159265358979323846 * (double)r * (double)r;
+}
+
+__global__ void __launch_bounds__(SEL_THREADS)
     scene_assign_kernel(const float *__restrict__ cub_dims, int M1, const float *__restrict__ cyl_radii,
                         const float *__restrict__ cyl_heights, int M2, int B, int N, uint32_t seed_lo,
                         uint32_t seed_hi, uint16_t *__restrict__ assign, uint8_t *__restrict__ labels,
                         int32_t *__restrict__ n_obstacles) {
-  __shared__ uint16_t rem_s[64 * MAX_OBS];
-  __shared__ uint8_t lab_s[64 * MAX_OBS];
-  const int lane = threadIdx.x;
-  const int b = blockIdx.x * 64 + lane;
-  if (b >= B) return;
-  uint16_t *rem = rem_s + lane * MAX_OBS;
-  uint8_t *lab = lab_s + lane * MAX_OBS;
+  __shared__ unsigned long long sel[SEL_CAP];
+  __shared__ int hist[2048];
+  __shared__ int s3[3];
+  __shared__ int off_s[MAX_OBS + 1];  // pool offsets: obstacle m owns slots [off[m], off[m+1])
+  __shared__ int K_s;
+  const int b = blockIdx.x, tid = threadIdx.x;
   const int M = M1 + M2;
-  // areas (double, like numpy) of the non-zero-volume obstacles; others get area 0 and pool 0
-  double total = 0.0;
-  int K = 0;
-  for (int m = 0; m < M; ++m) {
-    double a = 0.0;
-    if (m < M1) {
-      const float *d = cub_dims + ((size_t)b * M1 + m) * 3;
-      if (!(__builtin_fabsf(d[0]) <= 1e-8f || __builtin_fabsf(d[1]) <= 1e-8f || __builtin_fabsf(d[2]) <= 1e-8f))
-        a = 2.0 * ((double)d[0] * d[1] + (double)d[0] * d[2] + (double)d[1] * d[2]);
-    } else {
-      const float r = cyl_radii[(size_t)b * M2 + (m - M1)], h = cyl_heights[(size_t)b * M2 + (m - M1)];
-      if (!(__builtin_fabsf(r) <= 1e-8f || __builtin_fabsf(h) <= 1e-8f))
-        a = 2.0 * 3.14159265358979323846 * (double)r * (double)h + 2.0 * 3.14159265358979323846 * (double)r * (double)r;
-    }
-    total += a;
-    K += a > 0.0;
-  }
-  if (n_obstacles) n_obstacles[b] = K;
+  const float *cd = cub_dims + (size_t)b * M1 * 3, *yr = cyl_radii + (size_t)b * M2, *yh = cyl_heights + (size_t)b * M2;
   uint16_t *arow = assign + (size_t)b * N;
-  if (K == 0) {  // geometry.py:586-587 returns an empty cloud; ids 0xFFFF mark "no obstacle"
-    for (int j = 0; j < N; ++j) arow[j] = 0xFFFFu;
+  __shared__ double area_s[MAX_OBS];
+  __shared__ double total_s;
+  __shared__ int pool_s[MAX_OBS];
+  __shared__ uint8_t lab_s[MAX_OBS], who_s[MAX_OBS];  // label per obstacle; the live obstacles in order
+  if (tid < M) area_s[tid] = obstacle_area(tid, M1, cd, yr, yh);  // double, like numpy; zero-volume -> 0
+  __syncthreads();
+  if (tid == 0) {
+    double total = 0.0;
+    for (int m = 0; m < M; ++m) total += area_s[m];
+    total_s = total;
+  }
+  __syncthreads();
+  if (tid < M) {
+    const double a = area_s[tid];
+    pool_s[tid] = a > 0.0 ? (int)((a / total_s) * (double)N) + 500 : 0;  // int(prop*num_points) + 500
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int pool = 0, live = 0;
+    for (int m = 0; m < M; ++m) {
+      off_s[m] = pool;
+      pool += pool_s[m];
+      lab_s[m] = 0;
+      if (pool_s[m]) {
+        who_s[live] = (uint8_t)m;
+        lab_s[m] = (uint8_t)(++live);
+      }
+    }
+    off_s[M] = pool;
+    K_s = live;
+    if (n_obstacles) n_obstacles[b] = live;
+    // labels: Fisher-Yates shuffle of 1..K over the live obstacles, walked from the back (random.shuffle,
+    // geometry.py:594-595)
+    uint32_t ctr = 0;
+    for (int i = live - 1; i > 0; --i) {
+      const Philox r = philox4x32(ctr++, (uint32_t)b, STREAM_LABEL, 0, seed_lo, seed_hi);
+      const int jpos = (int)(((uint64_t)r.c[0] * (uint32_t)(i + 1)) >> 32);  // uniform in [0, i]
+      const uint8_t tmp = lab_s[who_s[i]];
+      lab_s[who_s[i]] = lab_s[who_s[jpos]];
+      lab_s[who_s[jpos]] = tmp;
+    }
+  }
+  __syncthreads();
+  if (labels && tid < M) labels[(size_t)b * M + tid] = K_s ? lab_s[tid] : 0;
+  __syncthreads();
+  if (K_s == 0) {  // geometry.py:586-587 returns an empty cloud; ids 0xFFFF mark "no obstacle"
+    for (int j = tid; j < N; j += SEL_THREADS) arow[j] = 0xFFFFu;
     return;
   }
-  uint32_t pool = 0;
-  for (int m = 0; m < M; ++m) {
-    double a = 0.0;
-    if (m < M1) {
-      const float *d = cub_dims + ((size_t)b * M1 + m) * 3;
-      if (!(__builtin_fabsf(d[0]) <= 1e-8f || __builtin_fabsf(d[1]) <= 1e-8f || __builtin_fabsf(d[2]) <= 1e-8f))
-        a = 2.0 * ((double)d[0] * d[1] + (double)d[0] * d[2] + (double)d[1] * d[2]);
-    } else {
-      const float r = cyl_radii[(size_t)b * M2 + (m - M1)], h = cyl_heights[(size_t)b * M2 + (m - M1)];
-      if (!(__builtin_fabsf(r) <= 1e-8f || __builtin_fabsf(h) <= 1e-8f))
-        a = 2.0 * 3.14159265358979323846 * (double)r * (double)h + 2.0 * 3.14159265358979323846 * (double)r * (double)r;
-    }
-    uint32_t n = 0;
-    if (a > 0.0) n = (uint32_t)(int)((a / total) * (double)N) + 500u;  // int(prop*num_points) + 500
-    rem[m] = (uint16_t)n;
-    pool += n;
-  }
-  // labels: Fisher-Yates shuffle of 1..K over the live obstacles (random.shuffle, geometry.py:594-595)
-  {
-    int live = 0;
-    for (int m = 0; m < M; ++m) lab[m] = rem[m] ? (uint8_t)(++live) : 0;
-    int i = K - 1;
-    uint32_t ctr = 0;
-    // walk live obstacles from the back
-    for (int m = M - 1; m >= 0 && i > 0; --m) {
-      if (!rem[m]) continue;
-      const Philox r = philox4x32(ctr++, (uint32_t)b, STREAM_LABEL, 0, seed_lo, seed_hi);
-      int jpos = (int)(((uint64_t)r.c[0] * (uint32_t)(i + 1)) >> 32);  // uniform in [0, i]
-      // find the jpos-th live obstacle
-      int t = -1;
-      for (int mm = 0; mm < M; ++mm)
-        if (rem[mm] && ++t == jpos) {
-          const uint8_t tmp = lab[m];
-          lab[m] = lab[mm];
-          lab[mm] = tmp;
-          break;
-        }
-      --i;
-    }
-    if (labels)
-      for (int m = 0; m < M; ++m) labels[(size_t)b * M + m] = lab[m];
-  }
-  // the urn: position j takes obstacle m with probability rem[m] / pool
-  for (int j0 = 0; j0 < N; j0 += 4) {
-    const Philox r = philox4x32((uint32_t)(j0 >> 2), (uint32_t)b, STREAM_URN, 0, seed_lo, seed_hi);
-    for (int u = 0; u < 4 && j0 + u < N; ++u) {
-      uint32_t pick = (uint32_t)(((uint64_t)r.c[u] * pool) >> 32);  // uniform in [0, pool)
-      int m = 0;
-      while (pick >= rem[m]) {
-        pick -= rem[m];
-        ++m;
-      }
-      rem[m] -= 1;
-      pool -= 1;
-      arow[j0 + u] = (uint16_t)m;
-    }
+  const int T = off_s[M];
+  mpx_select_smallest(
+      T, N,
+      [&](int g, uint32_t (&key)[4], bool (&valid)[4]) {  // one Philox block keys four consecutive slots
+        const Philox r = philox4x32((uint32_t)g, (uint32_t)b, STREAM_URN, 0, seed_lo, seed_hi);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) key[u] = r.c[u], valid[u] = 4 * g + u < T;
+      },
+      sel, hist, s3);  // T >= N + 500 always
+  for (int j = tid; j < N; j += SEL_THREADS) {
+    const int slot = (int)(uint32_t)sel[j];
+    int m = 0;
+    while (slot >= off_s[m + 1]) ++m;
+    arow[j] = (uint16_t)m;
   }
 }
 
@@ -210,13 +207,13 @@ MPX_EXPORT int mpx_scene_cloud(const float *cub_centers, const float *cub_dims, 
                                mpx_stream_t stream) {
   MPX_REQUIRE(B >= 0 && M1 >= 0 && M2 >= 0 && num_points >= 0, "mpx_scene_cloud: negative size");
   MPX_REQUIRE(M1 + M2 <= MAX_OBS, "mpx_scene_cloud: more than %d primitives per environment", MAX_OBS);
-  MPX_REQUIRE(num_points <= 60000, "mpx_scene_cloud: num_points > 60000 (pool sizes are 16-bit)");
+  MPX_REQUIRE(num_points <= SEL_MAX_OUT, "mpx_scene_cloud: num_points > %d (the draw is ordered in LDS)", SEL_MAX_OUT);
   MPX_REQUIRE(B <= 65535, "mpx_scene_cloud: B > 65535 (slab the batch)");
   MPX_REQUIRE(out_point_stride >= (write_label ? 4 : 3), "mpx_scene_cloud: out_point_stride too small");
   MPX_REQUIRE(assign != nullptr, "mpx_scene_cloud: assign scratch [B,num_points] uint16 is required");
   if (B == 0 || num_points == 0) return 0;
   const uint32_t lo = (uint32_t)seed, hi = (uint32_t)(seed >> 32);
-  hipLaunchKernelGGL(scene_assign_kernel, dim3(cdiv(B, 64)), dim3(64), 0, mpx_s(stream), cub_dims, M1, cyl_radii,
+  hipLaunchKernelGGL(scene_assign_kernel, dim3(B), dim3(SEL_THREADS), 0, mpx_s(stream), cub_dims, M1, cyl_radii,
                      cyl_heights, M2, B, num_points, lo, hi, assign, labels, n_obstacles);
   hipLaunchKernelGGL(scene_points_kernel, dim3(cdiv(num_points, 256), B), dim3(256), 0, mpx_s(stream), cub_centers,
                      cub_dims, cub_quats, M1, cyl_centers, cyl_radii, cyl_heights, cyl_quats, M2, num_points, lo,

@@ -484,6 +484,11 @@ static double obstacle_area(int m, int M1, const float *cd, const float *yr, con
   return 2.0 * PI * (double)r * (double)h + 2.0 * PI * (double)r * (double)r;
 }
 
+static int orc_cmp_u64_fwd(const void *a, const void *b) {
+  uint64_t x = *(const uint64_t *)a, y = *(const uint64_t *)b;
+  return x < y ? -1 : (x > y ? 1 : 0);
+}
+
 /* assign uint16 [B,N]; labels uint8 [B,M1+M2]; n_obstacles int32 [B] */
 ORC_API void orc_scene_assign(const float *cub_dims, int M1, const float *cyl_radii, const float *cyl_heights,
                               int M2, int B, int N, uint64_t seed, uint16_t *assign, uint8_t *labels,
@@ -533,20 +538,23 @@ ORC_API void orc_scene_assign(const float *cub_dims, int M1, const float *cyl_ra
         }
       --i;
     }
-    for (int j0 = 0; j0 < N; j0 += 4) {
-      uint32_t r[4];
-      orc_philox((uint32_t)(j0 >> 2), (uint32_t)b, 1u, 0u, k0, k1, r);
-      for (int u = 0; u < 4 && j0 + u < N; ++u) {
-        uint32_t pick = (uint32_t)(((uint64_t)r[u] * pool) >> 32);
-        int m = 0;
-        while (pick >= rem[m]) {
-          pick -= rem[m];
-          ++m;
-        }
-        rem[m] -= 1;
-        pool -= 1;
-        arow[j0 + u] = (uint16_t)m;
+    /* N of the pool slots, uniformly without replacement, in uniform order (np.random.choice, geometry.py:608):
+       every slot gets a Philox key, the N smallest (key, slot) pairs in ascending order; only the owner counts */
+    {
+      uint64_t *keys = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)pool);
+      for (uint32_t s = 0; s < pool; ++s) {
+        uint32_t r[4];
+        orc_philox(s >> 2, (uint32_t)b, 1u, 0u, k0, k1, r); /* one block keys four consecutive slots */
+        keys[s] = ((uint64_t)r[s & 3] << 32) | s;
       }
+      qsort(keys, (size_t)pool, sizeof(uint64_t), orc_cmp_u64_fwd);
+      for (int j = 0; j < N; ++j) {
+        uint32_t slot = (uint32_t)keys[j], acc = 0;
+        int m = 0;
+        while (slot >= acc + rem[m]) acc += rem[m++];
+        arow[j] = (uint16_t)m;
+      }
+      free(keys);
     }
   }
   free(rem);
@@ -811,8 +819,8 @@ ORC_API void orc_depth_select(const float *depth, const float *cam, float fx, fl
     for (int pix = 0; pix < W * H; ++pix) {
       if (dp[pix] < 0.0f) continue;
       uint32_t r[4];
-      orc_philox((uint32_t)pix, (uint32_t)b, 9u, 0u, k0, k1, r);
-      keys[n++] = ((uint64_t)r[0] << 32) | (uint32_t)pix;
+      orc_philox((uint32_t)(pix >> 2), (uint32_t)b, 9u, 0u, k0, k1, r); /* one block keys four consecutive pixels */
+      keys[n++] = ((uint64_t)r[pix & 3] << 32) | (uint32_t)pix;
     }
     count[b] = n;
     if (n < n_out) continue;
