@@ -177,16 +177,19 @@ def main():
         eng.step()  # packs the bf16 operand blocks + warm-up
         torch.cuda.synchronize()
         shard.barrier()
-        _lib.profile_start("mpx_sa_mlp_bf16x3")
+        _lib.profile_start("mpx_sa_mlp_bf16x3", "mpx_linear_bf16x3", "mpx_linear_rowmax_bf16x3", "mpx_linear")
         tf0 = time.perf_counter()
         for _ in range(args.fast_steps):
             eng.step()
         torch.cuda.synchronize()
         shard.barrier()
         fel = shard.max_over_ranks(time.perf_counter() - tf0, dev)
-        fprof = _lib.profile_stop()["mpx_sa_mlp_bf16x3"]
+        fall = _lib.profile_stop()
+        fprof = fall["mpx_sa_mlp_bf16x3"]
         model.set_precision("fp32")
-        fast = (fel, float(np.mean(fprof[0::2])), float(np.mean(fprof[1::2])))
+        fdense = float(np.sum(fall["mpx_linear_bf16x3"]) + np.sum(fall["mpx_linear_rowmax_bf16x3"])
+                       + np.sum(fall["mpx_linear"])) / args.fast_steps
+        fast = (fel, float(np.mean(fprof[0::2])), float(np.mean(fprof[1::2])), fdense)
 
     # final host gather (the only cross-rank data movement): joint angles + collision flags
     q_all = shard.gather_to_rank0(eng.q)
@@ -346,14 +349,15 @@ def main():
         if extra is not None:
             out["extra_configs"] = extra
         if fast is not None:
-            fel, f1_ms, f2_ms = fast
+            fel, f1_ms, f2_ms, fdense_ms = fast
             out["fast_mode"] = {
-                "what": "same step with the two grouped MLPs on the bf16 matrix cores, each fp32 product evaluated as "
-                        "hi*hi + hi*lo + lo*hi (split-bf16, fp32 accumulate); opt-in via model.set_precision('bf16x3'); "
-                        "policy deltas stay within 1e-5 of the fp32 oracle (tests/test_gpu_policy.py: 8e-8 measured)",
+                "what": "same step with the grouped MLPs and the large dense layers on the bf16 matrix cores, each fp32 product "
+                        "evaluated as hi*hi + hi*lo + lo*hi (split-bf16, fp32 accumulate); opt-in via "
+                        "model.set_precision('bf16x3'); policy deltas stay within 1e-5 of the fp32 oracle "
+                        "(tests/test_gpu_policy.py: 2.6e-7 measured)",
                 "dtype": "bf16x3", "value": B * n_gpus * args.fast_steps / fel, "unit": "env-steps/s",
                 "steps": args.fast_steps, "ms_per_step": fel / args.fast_steps * 1e3,
-                "sa1_ms": f1_ms, "sa2_ms": f2_ms,
+                "sa1_ms": f1_ms, "sa2_ms": f2_ms, "dense_ms": fdense_ms,
                 "sa2_executed_tflops": tiles_lockstep(cnt2, 4) * 32 * 57728 * 2 / (f2_ms * 1e-3) / 1e12,
                 "sa2_frac_of_bf16_peak_2500": tiles_lockstep(cnt2, 4) * 32 * 57728 * 2 / (f2_ms * 1e-3) / 1e12 / 2500.0,
             }

@@ -119,6 +119,17 @@ int mpx_trajectory_metrics(const float *traj, const int32_t *lengths, const floa
                            float *orient_err_deg, float *path_pos, float *path_orient_deg,
                            int32_t *limit_violation, int32_t *self_collision, mpx_stream_t stream);
 
+/* ---- split-bf16 ("bf16x3") dense layers: the opt-in fast mode of mpx_linear / mpx_linear_rowmax ------
+ * Every fp32 product is evaluated as x_hi*w_hi + x_hi*w_lo + x_lo*w_hi on the bf16 matrix cores (fp32
+ * accumulate).  mpx_split_bf16 splits a weight matrix [N,K] once into two bf16 planes [N,Kp], Kp = K rounded up
+ * to 16 (zero padded); activations stay fp32 in HBM and are split while staged.  Same argument meaning as the
+ * fp32 entry points otherwise.                                                                          */
+int mpx_split_bf16(const float *w, int N, int K, void *w_hi, void *w_lo, mpx_stream_t stream);
+int mpx_linear_bf16x3(const float *x, int ldx, const void *w_hi, const void *w_lo, const float *bias, int M,
+                      int N, int K, int act, float *y, int ldy, mpx_stream_t stream);
+int mpx_linear_rowmax_bf16x3(const float *x, int ldx, const void *w_hi, const void *w_lo, const float *bias,
+                             int M, int N, int K, int rows, float *y, int ldy, mpx_stream_t stream);
+
 /* ---- training losses with analytic gradients (row N1; mpinets/loss.py:31-166) -------------------- */
 
 /* collision_loss (loss.py:48-95) on points [B,N,3] (strides in floats): per environment

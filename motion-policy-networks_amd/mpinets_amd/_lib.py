@@ -59,6 +59,9 @@ PROTOTYPES = {
     "mpx_sa_pack_bf16x3": [P, P, P, P, P, P, I, I, I, I, P, P],
     "mpx_linear": [P, I, P, P, I, I, I, I, P, I, P],
     "mpx_linear_rowmax": [P, I, P, P, I, I, I, I, P, I, P],
+    "mpx_split_bf16": [P, I, I, P, P, P],
+    "mpx_linear_bf16x3": [P, I, P, P, P, I, I, I, I, P, I, P],
+    "mpx_linear_rowmax_bf16x3": [P, I, P, P, P, I, I, I, I, P, I, P],
     "mpx_groupnorm_leaky": [P, P, P, I, I, I, F, P, P],
     "mpx_rowmax": [P, I, I, I, I, P, I, P],
 }

@@ -19,8 +19,8 @@ import torch
 from torch import nn
 
 from . import _lib
-from .pointnet2 import (FACTORED_SHAPE, PRECISIONS, PointnetSAModule, SAWeights, groupnorm_leaky, launch_sa, linear,
-                        sa_mlp_factored, sa_mlp_fused)
+from .pointnet2 import (FACTORED_SHAPE, PRECISIONS, PointnetSAModule, SAWeights, SplitWeights, groupnorm_leaky, launch_sa,
+                        linear, linear_x3, sa_mlp_factored, sa_mlp_fused)
 from .utils import unnormalize_franka_joints
 
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
@@ -48,6 +48,13 @@ class MPiNetsPointNet(nn.Module):
             nn.Linear(2048, 2048),
         )
         self._sa3_w0 = None  # first group-all layer with K padded 259 -> 260
+        self.dense_precision = "fp32"  # "bf16x3": the large dense layers on the bf16 matrix cores (set_precision)
+        self._split = SplitWeights()
+
+    def _lin(self, x, weight, bias, act=0, out=None, source=None):
+        if self.dense_precision == "bf16x3":
+            return linear_x3(x, weight, bias, act, self._split, out=out, source=source)
+        return linear(x, weight, bias, act, out=out)
 
     @staticmethod
     def _break_up_pc(pc: torch.Tensor):
@@ -66,11 +73,11 @@ class MPiNetsPointNet(nn.Module):
 
     def _fc(self, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         fc = self.fc_layer
-        h = linear(x, fc[0].weight, fc[0].bias)
+        h = self._lin(x, fc[0].weight, fc[0].bias)
         h = groupnorm_leaky(h, fc[1].weight, fc[1].bias, fc[1].num_groups, fc[1].eps, out=h)
-        h = linear(h, fc[3].weight, fc[3].bias)
+        h = self._lin(h, fc[3].weight, fc[3].bias)
         h = groupnorm_leaky(h, fc[4].weight, fc[4].bias, fc[4].num_groups, fc[4].eps, out=h)
-        return linear(h, fc[6].weight, fc[6].bias, out=out)
+        return self._lin(h, fc[6].weight, fc[6].bias, out=out)
 
     def forward_train(self, point_cloud: torch.Tensor, aux: Optional[dict] = None) -> torch.Tensor:
         """Differentiable forward (training_step, model.py:185-240): sampling / neighbour search / grouping /
@@ -182,18 +189,24 @@ class MPiNetsPointNet(nn.Module):
         # ---- SA3 (group-all): three GEMMs over B*128 rows + max over each environment's rows ------------
         c3 = sa3.convs()
         h = sa3_in.view(B * sa2.npoint, K3)
-        h = linear(h, self._sa3_first_weight(), c3[0].bias, ACT_RELU)
-        h = linear(h, c3[1].weight.view(c3[1].out_channels, -1), c3[1].bias, ACT_RELU)
+        h = self._lin(h, self._sa3_first_weight(), c3[0].bias, ACT_RELU, source=c3[0].weight)
+        h = self._lin(h, c3[1].weight.view(c3[1].out_channels, -1), c3[1].bias, ACT_RELU)
         # last layer + max over each environment's 128 points in one kernel (nothing [B*128,1024] is stored)
         w3 = c3[2].weight.view(c3[2].out_channels, -1)
         pooled = torch.empty((B, w3.size(0)), dtype=torch.float32, device=dev)
         if sa2.npoint == 128:
             for b0 in range(0, B, 65535):
                 nb = min(65535, B - b0)
-                lib.call("mpx_linear_rowmax", lib.ptr(h[b0 * 128:]), h.stride(0), lib.ptr(w3), lib.ptr(c3[2].bias),
-                         nb * 128, w3.size(0), w3.size(1), 128, lib.ptr(pooled[b0:]), pooled.stride(0))
+                if self.dense_precision == "bf16x3":
+                    w3h, w3l = self._split.get(w3)
+                    lib.call("mpx_linear_rowmax_bf16x3", lib.ptr(h[b0 * 128:]), h.stride(0), lib.ptr(w3h), lib.ptr(w3l),
+                             lib.ptr(c3[2].bias), nb * 128, w3.size(0), w3.size(1), 128, lib.ptr(pooled[b0:]),
+                             pooled.stride(0))
+                else:
+                    lib.call("mpx_linear_rowmax", lib.ptr(h[b0 * 128:]), h.stride(0), lib.ptr(w3), lib.ptr(c3[2].bias),
+                             nb * 128, w3.size(0), w3.size(1), 128, lib.ptr(pooled[b0:]), pooled.stride(0))
         else:
-            h = linear(h, w3, c3[2].bias, ACT_RELU)
+            h = self._lin(h, w3, c3[2].bias, ACT_RELU)
             for b0 in range(0, B, 65535):
                 nb = min(65535, B - b0)
                 lib.call("mpx_rowmax", lib.ptr(h[b0 * sa2.npoint:]), h.stride(0), nb, sa2.npoint, h.size(1),
@@ -233,6 +246,7 @@ class MotionPolicyNetwork(nn.Module):
         assert precision in PRECISIONS, precision
         for sa in self.point_cloud_encoder.SA_modules:
             sa.precision = precision
+        self.point_cloud_encoder.dense_precision = precision
         return self
 
     def set_factored(self, on: bool) -> "MotionPolicyNetwork":
@@ -288,7 +302,7 @@ class MotionPolicyNetwork(nn.Module):
         h = linear(h, fe[6].weight, fe[6].bias, ACT_LEAKY)
         linear(h, fe[8].weight, fe[8].bias, ACT_NONE, out=cat[:, 2048:])
         de = self.decoder
-        h = linear(cat, de[0].weight, de[0].bias, ACT_LEAKY)
+        h = self.point_cloud_encoder._lin(cat, de[0].weight, de[0].bias, ACT_LEAKY)
         h = linear(h, de[2].weight, de[2].bias, ACT_LEAKY)
         h = linear(h, de[4].weight, de[4].bias, ACT_LEAKY)
         if aux is not None:

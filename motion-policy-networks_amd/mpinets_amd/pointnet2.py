@@ -82,6 +82,46 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], 
     return out
 
 
+class SplitWeights:
+    """bf16 hi/lo planes of dense weight matrices for the ``bf16x3`` mode, refreshed when a parameter changes."""
+
+    def __init__(self):
+        self.cache = {}
+
+    def get(self, weight: torch.Tensor, source: Optional[torch.Tensor] = None):
+        """``source``: the parameter a derived matrix (padded / transposed copy) was made from -- its version
+        decides when the planes are stale."""
+        src = weight if source is None else source
+        key = (src.data_ptr(), tuple(weight.shape))
+        ver = (src._version, tuple(weight.shape))
+        hit = self.cache.get(key)
+        if hit is None or hit[0] != ver:
+            w = _lib.f32c(weight.detach())
+            N, K = w.shape
+            Kp = (K + 15) // 16 * 16
+            hi = torch.empty((N, Kp), dtype=torch.bfloat16, device=w.device)
+            lo = torch.empty((N, Kp), dtype=torch.bfloat16, device=w.device)
+            _lib.call("mpx_split_bf16", _lib.ptr(w), N, K, _lib.ptr(hi), _lib.ptr(lo))
+            hit = (ver, hi, lo, w)  # w kept alive: its data_ptr is the key
+            self.cache[key] = hit
+        return hit[1], hit[2]
+
+
+def linear_x3(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], act: int, split: SplitWeights,
+              out: Optional[torch.Tensor] = None, source: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``linear`` on the bf16 matrix cores (three split products per fp32 product, fp32 accumulate)."""
+    assert x.ndim == 2 and weight.ndim == 2 and x.size(1) == weight.size(1) and x.stride(1) == 1
+    M, K = x.shape
+    N = weight.size(0)
+    hi, lo = split.get(weight, source)
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    assert out.shape == (M, N) and out.stride(1) == 1
+    _lib.call("mpx_linear_bf16x3", _lib.ptr(x), x.stride(0), _lib.ptr(hi), _lib.ptr(lo), _lib.ptr(bias), M, N, K, act,
+              _lib.ptr(out), out.stride(0))
+    return out
+
+
 def groupnorm_leaky(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, groups: int, eps: float = 1e-5,
                     out: Optional[torch.Tensor] = None) -> torch.Tensor:
     assert x.ndim == 2 and x.is_contiguous()

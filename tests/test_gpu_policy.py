@@ -307,3 +307,39 @@ def test_linear_rowmax_equals_linear_then_rowmax():
     out = torch.full((5, 1024), -1.0, device=dev())
     _lib.call("mpx_linear_rowmax", _lib.ptr(x), 512, _lib.ptr(w), _lib.ptr(b), 640, 1024, 512, 128, _lib.ptr(out), 1024)
     assert torch.equal(out, ref)
+
+
+def test_linear_bf16x3_matches_fp32_layer():
+    """Split-bf16 dense layer vs float64: three products per fp32 product keep ~2^-16 relative accuracy per term."""
+    from mpinets_amd import _lib
+    from mpinets_amd.pointnet2 import SplitWeights, linear, linear_x3
+
+    rng = np.random.default_rng(11)
+    split = SplitWeights()
+    for (M, N, K) in [(128, 128, 16), (257, 200, 260), (5, 4096, 1024), (1000, 64, 2112), (640, 1024, 512)]:
+        x = rng.normal(size=(M, K)).astype(np.float32)
+        w = (rng.normal(size=(N, K)) / np.sqrt(K)).astype(np.float32)
+        b = rng.normal(size=N).astype(np.float32)
+        ref = x.astype(np.float64) @ w.astype(np.float64).T + b
+        for act in (0, 1, 2):
+            r = ref if act == 0 else (np.maximum(ref, 0) if act == 1 else np.where(ref >= 0, ref, 0.01 * ref))
+            y = linear_x3(T(x), T(w), T(b), act, split).cpu().numpy()
+            y32 = linear(T(x), T(w), T(b), act).cpu().numpy()
+            e3, e32 = np.abs(y - r).max(), np.abs(y32 - r).max()
+            # a split operand carries ~2^-17 relative error (x_hi + x_lo != x exactly) and x_lo*w_lo is dropped:
+            # ~1e-5 of sum |x||w| (here a few units), against ~1e-6 for the fp32 kernel
+            assert e3 <= 1e-4 and e32 <= 2e-5, (M, N, K, act, e3, e32)
+    # pooled variant == linear_x3 + ReLU + max over each 128-row group
+    x = T(rng.normal(size=(5 * 128, 512)).astype(np.float32))
+    w = T((rng.normal(size=(1024, 512)) * 0.05).astype(np.float32))
+    b = T(rng.normal(size=1024).astype(np.float32))
+    hi, lo = split.get(w)
+    out = torch.full((5, 1024), -1.0, device=dev())
+    _lib.call("mpx_linear_rowmax_bf16x3", _lib.ptr(x), 512, _lib.ptr(hi), _lib.ptr(lo), _lib.ptr(b), 640, 1024, 512, 128,
+              _lib.ptr(out), 1024)
+    ref = linear_x3(x, w, b, 1, split).reshape(5, 128, 1024).max(dim=1).values
+    assert torch.equal(out, ref)
+    # a changed parameter refreshes the planes
+    w.mul_(2.0)
+    y2 = linear_x3(x, w, b, 0, split)
+    np.testing.assert_allclose(y2.cpu().numpy(), (x.double() @ w.double().T + b.double()).cpu().numpy(), atol=3e-4)
