@@ -1,0 +1,133 @@
+"""BASELINE-size checks (8192 mixed environments per GPU) through properties that do not need the scalar oracle:
+index validity / order / radius of the neighbour search, farthest-point invariants, fused vs unfused collision
+sweep, FK cloud vs slab, run-to-run determinism; a few environments are also compared with the oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+B = 8192
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def problem():
+    from mpinets_amd.scenes import make_problem_batch
+
+    return make_problem_batch(B, seed=77, device=dev(), kinds=("tabletop", "cubby", "dresser"), M1=40, M2=16,
+                              scene_pool=512, device_clouds=True)
+
+
+@pytest.fixture(scope="module")
+def forward(problem):
+    from mpinets_amd.model import MotionPolicyNetwork
+
+    torch.manual_seed(0)
+    mdl = MotionPolicyNetwork().to(dev()).eval()
+    aux = {}
+    with torch.no_grad():
+        dq = mdl(problem["xyz"], problem["q_norm"], aux=aux)
+    return mdl, dq, aux
+
+
+def test_fps_invariants_at_full_size(problem, forward, oracle):
+    _, _, aux = forward
+    for key, n in (("fps_idx1", 6272), ("fps_idx2", 512)):
+        idx = aux[key].long()
+        assert idx.min() >= 0 and idx.max() < n and (idx[:, 0] == 0).all()
+        assert (torch.sort(idx, dim=1).values.diff(dim=1) > 0).all()  # no point is picked twice
+    # the sequence of minimum distances to the already-picked set never increases (farthest-point property)
+    xyz = problem["xyz"][:256, :, :3]
+    picks = torch.gather(xyz, 1, aux["fps_idx1"][:256].long()[:, :, None].expand(-1, -1, 3))
+    d = torch.cdist(picks.double(), picks.double())  # [256,512,512]
+    tri = torch.tril(torch.ones(512, 512, device=dev(), dtype=torch.bool), diagonal=-1)
+    mind = torch.where(tri, d, torch.full_like(d, float("inf"))).min(dim=2).values[:, 1:]  # pick j vs picks < j
+    assert (mind[:, 1:] <= mind[:, :-1] + 1e-6).all(), (mind[:, 1:] - mind[:, :-1]).max().item()
+    # and a few environments bit-for-bit against the scalar oracle
+    sel = [0, 4097, 8191]
+    np.testing.assert_array_equal(aux["fps_idx1"][sel].cpu().numpy(), oracle.fps(problem["xyz"][sel].cpu().numpy(), 512))
+
+
+@pytest.mark.parametrize("stage", [1, 2])
+def test_ball_query_properties_at_full_size(problem, forward, oracle, stage):
+    _, _, aux = forward
+    if stage == 1:
+        cloud, centres, r, N = problem["xyz"][:, :, :3], aux["xyz1"], 0.05, 6272
+    else:
+        cloud, centres, r, N = aux["xyz1"], aux["sa3_in"][:, :, :3], 0.3, 512
+    idx, cnt = aux[f"ball_idx{stage}"], aux[f"ball_cnt{stage}"]
+    assert idx.min() >= 0 and idx.max() < N and cnt.min() >= 0 and cnt.max() <= 128
+    slot = torch.arange(128, device=dev())[None, None, :]
+    real = slot < cnt[:, :, None]
+    # real slots: strictly increasing point indices; padding: copies of the first hit (or 0 when nothing was hit)
+    inc = (idx[:, :, 1:] > idx[:, :, :-1]) | ~real[:, :, 1:]
+    assert inc.all()
+    first = torch.where(cnt > 0, idx[:, :, 0], torch.zeros_like(idx[:, :, 0]))
+    assert (torch.where(real, first[:, :, None].expand_as(idx), idx) == first[:, :, None]).all()
+    # every real slot is inside the radius (same fp32 expression as the kernels), checked on a slice of the batch
+    for b0 in range(0, B, 2048):
+        sl = slice(b0, b0 + 256)
+        nb = torch.gather(cloud[sl], 1, idx[sl].long().reshape(256, -1)[:, :, None].expand(-1, -1, 3)).reshape(256, -1, 128, 3)
+        d = centres[sl][:, :, None, :] - nb
+        d2 = torch.addcmul(torch.addcmul(d[..., 0] * d[..., 0], d[..., 1], d[..., 1]), d[..., 2], d[..., 2])
+        assert (d2[real[sl]] < r * r * (1 + 1e-6)).all()
+        # the count is the number of points within the radius (capped at nsample)
+        dist2 = torch.cdist(centres[sl].double(), cloud[sl].double()) ** 2
+        within = (dist2 < r * r).sum(dim=2)
+        close = ((dist2 - r * r).abs() < 1e-7).any(dim=2)  # pairs sitting on the sphere: rounding may differ
+        ok = (torch.minimum(within, torch.tensor(128, device=dev())) == cnt[sl]) | close
+        assert ok.all()
+    sel = [1, 5000]
+    if stage == 1:
+        ref, rcnt = oracle.ball_query(centres[sel].cpu().numpy(), problem["xyz"][sel].cpu().numpy(), r, 128, return_counts=True)
+        np.testing.assert_array_equal(idx[sel].cpu().numpy(), ref)
+        np.testing.assert_array_equal(cnt[sel].cpu().numpy(), rcnt)
+
+
+def test_policy_step_is_deterministic_and_finite(problem, forward):
+    mdl, dq, aux = forward
+    with torch.no_grad():
+        dq2 = mdl(problem["xyz"], problem["q_norm"])
+    assert torch.equal(dq, dq2) and torch.isfinite(dq).all() and dq.shape == (B, 7)
+    assert torch.isfinite(aux["sa3_in"]).all() and (aux["f1"] >= 0).all()  # pooled ReLU outputs
+
+
+def test_collision_sweep_fused_equals_unfused_at_config4_size(problem):
+    """BASELINE config 4: 8192 trajectories x 50 waypoints; fused kernel vs sphere centres + SDF classes + threshold."""
+    from mpinets_amd.geometry import TorchCuboids, TorchCylinders
+    from mpinets_amd.robot import FrankaCollisionSampler
+    from mpinets_amd.scenes import linear_trajectories
+
+    traj = torch.from_numpy(linear_trajectories(B, 50, 3)).to(dev())
+    cub = TorchCuboids(problem["cuboid_centers"], problem["cuboid_dims"], problem["cuboid_quats"])
+    cyl = TorchCylinders(problem["cylinder_centers"], problem["cylinder_radii"], problem["cylinder_heights"],
+                         problem["cylinder_quats"])
+    cs = FrankaCollisionSampler(dev(), with_base_link=False)
+    fused = cs.check(traj, cub, cyl)
+    hit = torch.zeros(B, dtype=torch.bool, device=dev())
+    for radius, centres in cs.compute_spheres(traj.reshape(-1, 7)):  # the reference's loop (model.py:300-312)
+        c = centres.reshape(B, 50, -1, 3)
+        sdf = torch.minimum(cub.sdf_sequence(c), cyl.sdf_sequence(c))
+        hit |= (sdf <= radius).reshape(B, -1).any(dim=1)
+    assert torch.equal(fused, hit) and 0.02 < fused.float().mean().item() < 0.98
+
+
+def test_rollout_step_keeps_the_slab_consistent(problem):
+    from mpinets_amd.model import MotionPolicyNetwork
+    from mpinets_amd.rollout import RolloutEngine
+
+    torch.manual_seed(0)
+    mdl = MotionPolicyNetwork().to(dev()).eval()
+    prob = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in problem.items()}
+    scene_before = prob["xyz"][:, 2048:].clone()
+    eng = RolloutEngine(mdl, prob)
+    q = eng.step()
+    assert torch.equal(prob["xyz"][:, 2048:], scene_before)  # only the robot rows are rewritten (model.py:180-181)
+    again = torch.empty((B, 2048, 3), device=dev())
+    eng.sampler.sample_into(q, again, eng.subset)
+    assert torch.equal(prob["xyz"][:, :2048, :3], again) and (prob["xyz"][:, :2048, 3] == 0).all()
+    lim = eng.limits
+    assert (q >= lim[:, 0] - 1e-6).all() and (q <= lim[:, 1] + 1e-6).all()
