@@ -156,6 +156,17 @@ int mpx_franka_cloud_grad(const float *q, int B, float finger, const float *tabl
                           int64_t grad_batch_stride, int grad_point_stride, float *grad_q,
                           mpx_stream_t stream);
 
+/* ---- backward of the dense layers (row N1): y = act(x . W^T + b) ------------------------------------
+ * dX is the forward kernel on the transposed weights: mpx_linear(dZ, W^T).  mpx_act_backward forms
+ * dZ = dY * act'(y) from the layer OUTPUT y (contiguous, n elements).  mpx_linear_wgrad computes
+ * dW [N,K] = dZ^T . x and db [N] = column sums of dZ (optional) with the reduction over the M rows split across
+ * workgroups; the splits' partial tiles go through `scratch` (mpx_linear_wgrad_scratch(M,N,K) floats) and are
+ * added in a fixed order (deterministic).  N, K, ldx, lddy multiples of 4.                                  */
+int mpx_act_backward(const float *dy, const float *y, int64_t n, int act, float *dz, mpx_stream_t stream);
+int64_t mpx_linear_wgrad_scratch(int M, int N, int K);
+int mpx_linear_wgrad(const float *dy, int lddy, const float *x, int ldx, int M, int N, int K, float *dw,
+                     float *db, float *scratch, mpx_stream_t stream);
+
 /* ---- differentiable grouping + max-pool of the set-abstraction stack (row N1) --------------------
  * The reference trains through pointnet2_ops' QueryAndGroup / max-pool (model.py:366-383).  Here a
  * neighbourhood contributes only its distinct neighbours (cnt from mpx_ball_query; padding repeats

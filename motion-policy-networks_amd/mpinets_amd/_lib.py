@@ -62,10 +62,14 @@ PROTOTYPES = {
     "mpx_split_bf16": [P, I, I, P, P, P],
     "mpx_linear_bf16x3": [P, I, P, P, P, I, I, I, I, P, I, P],
     "mpx_linear_rowmax_bf16x3": [P, I, P, P, P, I, I, I, I, P, I, P],
+    "mpx_act_backward": [P, P, L, I, P, P],
+    "mpx_linear_wgrad_scratch": [I, I, I],
+    "mpx_linear_wgrad": [P, I, P, I, I, I, I, P, P, P, P],
     "mpx_groupnorm_leaky": [P, P, P, I, I, I, F, P, P],
     "mpx_rowmax": [P, I, I, I, I, P, I, P],
 }
-RESTYPES = {"mpx_last_error": c_char_p, "mpx_sa_pack_size": c_int64, "mpx_sa_pack_bf16x3_size": c_int64}
+RESTYPES = {"mpx_last_error": c_char_p, "mpx_sa_pack_size": c_int64, "mpx_sa_pack_bf16x3_size": c_int64,
+            "mpx_linear_wgrad_scratch": c_int64}
 
 _lib: Optional[ctypes.CDLL] = None
 

@@ -19,7 +19,7 @@ import torch
 from torch import nn
 
 from . import _lib
-from .pointnet2 import (FACTORED_SHAPE, PRECISIONS, PointnetSAModule, SAWeights, SplitWeights, groupnorm_leaky, launch_sa,
+from .pointnet2 import (FACTORED_SHAPE, PRECISIONS, linear_train, PointnetSAModule, SAWeights, SplitWeights, groupnorm_leaky, launch_sa,
                         linear, linear_x3, sa_mlp_factored, sa_mlp_fused)
 from .utils import unnormalize_franka_joints
 
@@ -110,13 +110,16 @@ class MPiNetsPointNet(nn.Module):
                              (B, sa1.npoint, sa2.npoint, sa2.nsample))
         h = torch.cat((xyz2, f2), dim=2)  # group-all: absolute coordinates | features
         for conv in sa3.convs():
-            h = torch.relu(torch.nn.functional.linear(h, conv.weight.view(conv.out_channels, -1), conv.bias))
+            h = linear_train(h, conv.weight.view(conv.out_channels, -1), conv.bias, ACT_RELU)
         pooled = h.max(dim=1).values
         self.last_counts = (cnt1, cnt2)
         if aux is not None:
             aux.update(fps_idx1=idx1, xyz1=xyz1, ball_idx1=nbr1, ball_cnt1=cnt1, f1=f1, fps_idx2=idx2, ball_idx2=nbr2,
                        ball_cnt2=cnt2, f3=pooled)
-        return self.fc_layer(pooled)
+        fc = self.fc_layer  # Linear -> GroupNorm -> LeakyReLU (x2) -> Linear; the norms stay torch ops
+        h = torch.nn.functional.leaky_relu(fc[1](linear_train(pooled, fc[0].weight, fc[0].bias)))
+        h = torch.nn.functional.leaky_relu(fc[4](linear_train(h, fc[3].weight, fc[3].bias)))
+        return linear_train(h, fc[6].weight, fc[6].bias)
 
     def _sa3_first_weight(self) -> torch.Tensor:
         conv = self.SA_modules[2].convs()[0]
@@ -290,7 +293,14 @@ class MotionPolicyNetwork(nn.Module):
         dev = xyz.device
         if self.training and torch.is_grad_enabled():  # differentiable path (training_step)
             pc_encoding = self.point_cloud_encoder(xyz, aux=aux)
-            return self.decoder(torch.cat((pc_encoding, self.feature_encoder(q)), dim=1))
+
+            def mlp(seq, x):  # Linear + LeakyReLU stacks: every layer is one fused forward / backward pair
+                layers = [m for m in seq if isinstance(m, nn.Linear)]
+                for i, lin in enumerate(layers):
+                    x = linear_train(x, lin.weight, lin.bias, ACT_LEAKY if i + 1 < len(layers) else ACT_NONE)
+                return x
+
+            return mlp(self.decoder, torch.cat((pc_encoding, mlp(self.feature_encoder, _lib.f32c(q))), dim=1))
         cat = torch.empty((B, 2048 + 64), dtype=torch.float32, device=dev)
         self.point_cloud_encoder(xyz, out=cat[:, :2048], aux=aux)
         fe = self.feature_encoder

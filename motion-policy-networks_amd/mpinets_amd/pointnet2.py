@@ -242,6 +242,62 @@ FACTORED_SHAPE = (64, 128, 128, 256)
 
 
 # ---- module -------------------------------------------------------------------------------------------
+# ---- training path (row N1): dense layers with hand-written forward AND backward kernels ------------------------
+class _LinearFn(torch.autograd.Function):
+    """y = act(x @ W.T + b) with ``mpx_linear`` forward; backward = ``mpx_act_backward`` + ``mpx_linear`` on W^T
+    (input gradient) + ``mpx_linear_wgrad`` (weight / bias gradients, deterministic split reduction)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act):
+        assert x.ndim == 2 and weight.ndim == 2 and x.size(1) == weight.size(1)
+        M, K = x.shape
+        N = weight.size(0)
+        Kp, Np = (K + 3) // 4 * 4, (N + 3) // 4 * 4
+        xp = _lib.f32c(x.detach())
+        wp = _lib.f32c(weight.detach())
+        if Kp != K:  # first layers (4, 67, 259, 7 inputs): zero columns change nothing
+            xp = torch.nn.functional.pad(xp, (0, Kp - K))
+            wp = torch.nn.functional.pad(wp, (0, Kp - K))
+        y = linear(xp, wp, None if bias is None else _lib.f32c(bias.detach()), act)
+        ctx.save_for_backward(xp, wp, y if act else None)
+        ctx.meta = (act, M, N, K, Np, Kp, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        xp, wp, y = ctx.saved_tensors
+        act, M, N, K, Np, Kp, has_bias = ctx.meta
+        g = _lib.f32c(g)
+        if act:
+            dz = torch.empty_like(g)
+            _lib.call("mpx_act_backward", _lib.ptr(g), _lib.ptr(y), g.numel(), act, _lib.ptr(dz))
+        else:
+            dz = g
+        if Np != N:  # the 7-wide output layer
+            dz = torch.nn.functional.pad(dz, (0, Np - N))
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            wt = torch.nn.functional.pad(wp, (0, 0, 0, Np - N)).t().contiguous() if Np != N else wp.t().contiguous()
+            gx = linear(dz, wt, None, 0)[:, :K]  # [M, Kp] -> [M, K]
+        if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
+            dw = torch.empty((Np, Kp), dtype=torch.float32, device=g.device)
+            db = torch.empty(Np, dtype=torch.float32, device=g.device) if has_bias else None
+            nscr = _lib.load().mpx_linear_wgrad_scratch(M, Np, Kp)
+            scratch = torch.empty(nscr, dtype=torch.float32, device=g.device)
+            _lib.call("mpx_linear_wgrad", _lib.ptr(dz), dz.stride(0), _lib.ptr(xp), xp.stride(0), M, Np, Kp, _lib.ptr(dw),
+                      _lib.ptr(db), _lib.ptr(scratch))
+            gw = dw[:N, :K]
+            gb = db[:N] if has_bias else None
+        return gx, gw, gb, None
+
+
+def linear_train(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], act: int = 0) -> torch.Tensor:
+    """Differentiable dense layer on the engine's kernels; ``x`` may have leading batch dimensions."""
+    lead = x.shape[:-1]
+    y = _LinearFn.apply(x.reshape(-1, x.size(-1)), weight, bias, act)
+    return y.reshape(lead + (weight.size(0),))
+
+
 # ---- training path (row N1): differentiable grouping + max-pool on packed distinct-neighbour rows ------
 class _PackRows(torch.autograd.Function):
     """QueryAndGroup(use_xyz=True) without the padding: -> rows [R, 3+C]; gradient flows to ``feat`` only."""
@@ -303,8 +359,8 @@ def sa_module_train(convs: List[nn.Conv2d], xyz: torch.Tensor, xyz_stride: int, 
     torch.cumsum(cnt.reshape(-1).clamp(min=1), 0, out=offsets[1:])
     R = int(offsets[-1].item())  # one host sync per module and step: the row count sizes the activations
     h = _PackRows.apply(feat, xyz, xyz_stride, new_xyz, new_stride, feat_stride, C, idx, cnt, offsets, R, dims)
-    for conv in convs:  # dense algebra: library GEMMs under autograd
-        h = torch.relu(torch.nn.functional.linear(h, conv.weight.view(conv.out_channels, -1), conv.bias))
+    for conv in convs:
+        h = linear_train(h, conv.weight.view(conv.out_channels, -1), conv.bias, 1)
     return _SegmentMax.apply(h, offsets, B * npoint).view(B, npoint, -1)
 
 
@@ -371,7 +427,7 @@ class PointnetSAModule(nn.Module):
         if self.training and torch.is_grad_enabled():
             h = torch.cat([xyz] + ([features.transpose(1, 2)] if features is not None else []), dim=2)
             for conv in convs:
-                h = torch.relu(torch.nn.functional.linear(h, conv.weight.view(conv.out_channels, -1), conv.bias))
+                h = linear_train(h, conv.weight.view(conv.out_channels, -1), conv.bias, 1)
             return None, h.max(dim=1).values.unsqueeze(-1)
         parts = [xyz]
         if features is not None:
