@@ -133,7 +133,6 @@ def groupnorm_leaky(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, g
 
 
 PRECISIONS = ("fp32", "bf16x3")
-SA_KERNEL = {"fp32": "mpx_sa_mlp", "bf16x3": "mpx_sa_mlp_bf16x3"}
 
 
 class SAWeights:
