@@ -297,6 +297,11 @@ int mpx_sa_mlp(const float *xyz, int stride, const float *new_xyz, int new_strid
 int mpx_sa_mlp_factored(const float *pre, const float *ctr, const int32_t *idx, const int32_t *cnt, int B,
                         int N, int npoint, int nsample, const float *wpack, int C, int c1, int c2, int c3,
                         float *out, int out_stride, mpx_stream_t stream);
+/* mpx_sa_mlp_factored on the bf16 matrix cores (split products, see mpx_sa_mlp_bf16x3): wpack from
+ * mpx_sa_pack_bf16x3 (its layer-1 blocks are not read); order (optional) from mpx_sort_queries.          */
+int mpx_sa_mlp_bf16x3_factored(const float *pre, const float *ctr, const int32_t *idx, const int32_t *cnt,
+                               const int32_t *order, int B, int N, int npoint, int nsample, const void *wpack,
+                               int C, int c1, int c2, int c3, float *out, int out_stride, mpx_stream_t stream);
 /* number of floats mpx_sa_pack_weights writes for this configuration (host call)            */
 int64_t mpx_sa_pack_size(int C, int c1, int c2, int c3);
 /* w1 [c1,3+C], w2 [c2,c1], w3 [c3,c2] row-major (Conv2d 1x1 weights), b* biases -> wpack    */

@@ -175,7 +175,7 @@ struct Stream {
   int lds_lane;                // lane * 16
   int cur;                     // ring slot holding the chunk being consumed (0/1)
   int next_cc;                 // cyclic index of the chunk to fetch next
-  int nch;
+  int nch, first;              // the walk covers chunks [first, nch)
   static_assert(CHUNK_BYTES == 2 * 64 * WAVES * 16, "two 16-byte pieces per thread per chunk");
   uint4 stage0, stage1;        // chunk (current + 1), in flight or landed (named members: an array
                                // member is not promoted to registers and lands in scratch)
@@ -186,7 +186,7 @@ struct Stream {
     const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff + 64 * WAVES * 16, 0);
     stage0 = make_uint4(a.x, a.y, a.z, a.w);
     stage1 = make_uint4(b.x, b.y, b.z, b.w);
-    next_cc = next_cc + 1 == nch ? 0 : next_cc + 1;
+    next_cc = next_cc + 1 == nch ? first : next_cc + 1;
   }
   __device__ __forceinline__ void put(int slot) {
     unsigned char *p = lds + slot * CHUNK_BYTES + lds_slice;
@@ -260,15 +260,20 @@ __device__ __forceinline__ f32x16 bias_tile_lds(const float *bias_lds, int ot, i
 // neighbour, and max-pooling is idempotent) are rounded up to multiples of 4 rows and packed back to
 // back into 32-row tiles.  `order` (optional) lists the queries sorted by row count so that the 8
 // lockstep waves of a workgroup carry (nearly) the same number of tiles; the workgroup runs max(tiles).
-template <int CF, int C1, int C2, int C3, int Q>
+// FACT: the first layer is evaluated per point / per query by the caller (see sa_mlp.hip): the kernel starts at
+// relu(pre[j] - ctr[i]) and walks only the chunks of layers 2 and 3.
+template <int CF, int C1, int C2, int C3, int Q, bool FACT>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
     sa_mlp_bf16_kernel(const float *__restrict__ xyz, int stride, const float *__restrict__ new_xyz, int new_stride,
                        const float *__restrict__ feat, int feat_stride, const int32_t *__restrict__ idx,
                        const int32_t *__restrict__ cnt, const int32_t *__restrict__ order, int64_t n_query, int N,
                        int npoint, int nsample, const unsigned char *__restrict__ wpack, float *__restrict__ out,
-                       int out_stride) {
+                       int out_stride, const float *__restrict__ pre_rows, const float *__restrict__ ctr) {
   using Cfg = BCfg<CF, C1, C2, C3>;
+  constexpr int FIRST = FACT ? Cfg::O2 / G : 0;  // first chunk of the walk
+  static_assert(!FACT || Cfg::O2 % G == 0, "layer 2 must start on a chunk boundary");
   __shared__ __attribute__((aligned(16))) unsigned char ring[2 * CHUNK_BYTES + 4 * (C1 + C2) + 64];
+  __shared__ __attribute__((aligned(16))) float ctr_s[FACT ? WAVES * Q * C1 : 4];
   float *bias_lds = reinterpret_cast<float *>(ring + 2 * CHUNK_BYTES);  // [b1 | b2]
   int *tiles_lds = reinterpret_cast<int *>(ring + 2 * CHUNK_BYTES + 4 * (C1 + C2));
   const int lane = threadIdx.x & 63;
@@ -311,8 +316,15 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
   ws.lds = ring;
   ws.lds_slice = threadIdx.x * 16;
   ws.lds_lane = lane * 16;
-  ws.next_cc = 0;
+  ws.first = FIRST;
+  ws.next_cc = FIRST;
   ws.nch = Cfg::NCH;
+  if constexpr (FACT) {  // this wave's per-query terms (lanes 0..31: one float4 of a 128-float row each)
+    for (int i = 0; i < nq; ++i)
+      for (int c4 = lane; c4 < C1 / 4; c4 += 64)
+        *reinterpret_cast<float4 *>(ctr_s + (wave * Q + i) * C1 + 4 * c4) =
+            *reinterpret_cast<const float4 *>(ctr + (int64_t)s_q[i] * C1 + 4 * c4);
+  }
   ws.start();  // (its barrier also publishes the biases and the per-wave row counts)
   int n_rows = 0;
 #pragma unroll
@@ -320,23 +332,36 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
   const float *bias3 = reinterpret_cast<const float *>(wpack + Cfg::B3_OFF);
 
   // row -> (global query id, neighbour index); rows past this wave's end repeat its last query's slot 0
+  int ql_tmp = 0;  // local index (0..Q-1) of the query found by the latest map_row
   auto map_row = [&](int p, int &qg, int &nb_off) {
     int qpre = 0, qcnt = s_cnt[0];
     qg = s_q[0];
+    ql_tmp = 0;
 #pragma unroll
     for (int i = 1; i < Q; ++i) {
       const bool ge = i < nq && p >= s_pre[i];
       qg = ge ? s_q[i] : qg;
+      ql_tmp = ge ? i : ql_tmp;
       qpre = ge ? s_pre[i] : qpre;
       qcnt = ge ? s_cnt[i] : qcnt;
     }
     const int slot = p - qpre;
     nb_off = slot < qcnt ? slot : 0;
   };
+  float raw_pre[FACT ? C1 / 2 : 1];  // FACT: this lane-half's 4-channel groups of the point's first-layer row
   auto gather = [&](RawIn<CF> &raw, int qg, int k) {
     const int64_t b = qg / npoint;
-    raw.load(xyz + (b * N + k) * (int64_t)stride, new_xyz + (int64_t)qg * new_stride,
-             feat + (b * N + k) * (int64_t)feat_stride, half);
+    if constexpr (FACT) {
+      const float *pa = pre_rows + (b * N + k) * (int64_t)C1 + 4 * half;
+#pragma unroll
+      for (int i = 0; i < C1 / 8; ++i) {
+        const float4 v = *reinterpret_cast<const float4 *>(pa + 8 * i);
+        raw_pre[4 * i + 0] = v.x, raw_pre[4 * i + 1] = v.y, raw_pre[4 * i + 2] = v.z, raw_pre[4 * i + 3] = v.w;
+      }
+    } else {
+      raw.load(xyz + (b * N + k) * (int64_t)stride, new_xyz + (int64_t)qg * new_stride,
+               feat + (b * N + k) * (int64_t)feat_stride, half);
+    }
   };
 
   float run[Cfg::OT3];  // running max of the query being merged, per output tile (this lane's half of the rows)
@@ -357,22 +382,44 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 
   // gather pipeline: neighbour index one tile ahead (issued at tile start), neighbour data issued in layer 3
   RawIn<CF> raw;
-  int q_cur, q_next = 0, k_next = 0;
+  int q_cur, q_next = 0, k_next = 0, ql_cur = 0, ql_next = 0;
   {
     int off;
     map_row(col, q_cur, off);
+    ql_cur = ql_tmp;
     const int k0 = idx[(int64_t)q_cur * nsample + off];
     gather(raw, q_cur, k0);
     if (n_rows > 32) {
       map_row(32 + col, q_next, off);
+      ql_next = ql_tmp;
       k_next = idx[(int64_t)q_next * nsample + off];
     }
   }
 
   for (int rt = 0; rt < n_rows; rt += 32) {
-    // ---- layer-1 operands from the prefetched row, split hi/lo -------------------------------------------
-    bf16x8 xh[Cfg::KS0], xl[Cfg::KS0];
-    {
+    // ---- layer-1 operands from the prefetched row, split hi/lo (direct form only) ---------------------------
+    bf16x8 xh[FACT ? 1 : Cfg::KS0], xl[FACT ? 1 : Cfg::KS0];
+    f32x16 a1[Cfg::OT1], a2[Cfg::OT2];
+    bf16x8 h1[Cfg::OT1][2], l1[Cfg::OT1][2];
+    if constexpr (FACT) {
+      // register r of tile ot = channel 32*ot + 8*(r>>2) + 4*half + (r&3) = group i = 4*ot + (r>>2) of raw_pre;
+      // the layer-2 operands (hi/lo bf16) are formed right here, one tile at a time: no fp32 tile stays alive
+      const float *cq = ctr_s + (wave * Q + ql_cur) * C1 + 4 * half;
+#pragma unroll
+      for (int ot = 0; ot < Cfg::OT1; ++ot) {
+        f32x16 t;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int i = 4 * ot + g;
+          const float4 c = *reinterpret_cast<const float4 *>(cq + 8 * i);
+          t[4 * g + 0] = raw_pre[4 * i + 0] - c.x;
+          t[4 * g + 1] = raw_pre[4 * i + 1] - c.y;
+          t[4 * g + 2] = raw_pre[4 * i + 2] - c.z;
+          t[4 * g + 3] = raw_pre[4 * i + 3] - c.w;
+        }
+        relu_split_tile(t, h1[ot], l1[ot]);
+      }
+    } else {
       float v[8 * Cfg::KS0];
 #pragma unroll
       for (int i = 0; i < 8 * Cfg::KS0; ++i) v[i] = 0.0f;
@@ -396,23 +443,26 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     const int q_tile = q_cur;  // query of this lane's row in the tile being computed
     const int q_gather = q_next, k_gather = k_next;
     q_cur = q_next;
+    ql_cur = ql_next;
     if (rt + 64 < n_rows) {  // index of the row after next: issued now, consumed a tile later
       int off;
       map_row(rt + 64 + col, q_next, off);
+      ql_next = ql_tmp;
       k_next = idx[(int64_t)q_next * nsample + off];
     }
     // The next tile's row data is fetched inside the chunk walk below, at the first chunk of layer 3
     // (register pressure peaks in layer 2; layer 3 is long enough to cover the latency).
-    constexpr int GATHER_CHUNK = Cfg::O3 / G;
+    constexpr int GATHER_CHUNK = Cfg::O3 / G + (FACT ? 1 : 0);  // FACT: one chunk later, when the layer-2 accumulators are gone
 
-    f32x16 a1[Cfg::OT1], a2[Cfg::OT2];
-    bf16x8 h1[Cfg::OT1][2], l1[Cfg::OT1][2], h2[Cfg::OT2][2], l2[Cfg::OT2][2];
+    bf16x8 h2[Cfg::OT2][2], l2[Cfg::OT2][2];
     f32x16 a3[Cfg::OPC][2];
+    if constexpr (!FACT) {
 #pragma unroll
-    for (int ot = 0; ot < Cfg::OT1; ++ot) a1[ot] = bias_tile_lds(bias_lds, ot, half);
+      for (int ot = 0; ot < Cfg::OT1; ++ot) a1[ot] = bias_tile_lds(bias_lds, ot, half);
+    }
 
 #pragma unroll
-    for (int c = 0; c < Cfg::NCH; ++c) {
+    for (int c = FIRST; c < Cfg::NCH; ++c) {
       if (c == GATHER_CHUNK && rt + 32 < n_rows) gather(raw, q_gather, k_gather);
       // ---- operands that become available / are first needed in this chunk ---------------------------------
       if (c * G == Cfg::O2) {
@@ -425,7 +475,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         if (!Cfg::is_real(st)) continue;
         if (st >= Cfg::O2 && st < Cfg::O3) {  // layer 2, first use of input tile s>>1 (ot == 0, even s)
           const int q = st - Cfg::O2, s = q / Cfg::OT2, ot = q % Cfg::OT2;
-          if (ot == 0 && (s & 1) == 0) relu_split_tile(a1[s >> 1], h1[s >> 1], l1[s >> 1]);
+          if (!FACT && ot == 0 && (s & 1) == 0) relu_split_tile(a1[s >> 1], h1[s >> 1], l1[s >> 1]);
         } else if (st >= Cfg::O3) {            // layer 3, first output tile walks the input tiles in order
           const int q = st - Cfg::O3, s = q % Cfg::KS2, ot = q / Cfg::KS2;
           if (ot == 0 && (s & 1) == 0) relu_split_tile(a2[s >> 1], h2[s >> 1], l2[s >> 1]);
@@ -437,7 +487,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
       }
       // operands are fetched SUB step-tiles at a time (register budget); within a sub-group three passes
       // (hi*hi, lo*hi, hi*lo) so that consecutive MFMAs hit different accumulators
-      constexpr int SUB = 4;
+      constexpr int SUB = FACT ? 1 : 4;
 #pragma unroll
       for (int g0 = 0; g0 < G; g0 += SUB) {
         bf16x8 wh[SUB], wl[SUB];
@@ -452,8 +502,10 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
             if (!Cfg::is_real(st)) continue;
             const bf16x8 w = pass == 1 ? wl[j] : wh[j];
             if (st < Cfg::O2) {
-              const int s = st / Cfg::OT1, ot = st % Cfg::OT1;
-              a1[ot] = mfma_bf16(w, pass == 2 ? xl[s] : xh[s], a1[ot]);
+              if constexpr (!FACT) {
+                const int s = st / Cfg::OT1, ot = st % Cfg::OT1;
+                a1[ot] = mfma_bf16(w, pass == 2 ? xl[s] : xh[s], a1[ot]);
+              }
             } else if (st < Cfg::O3) {
               const int q = st - Cfg::O2, s = q / Cfg::OT2, ot = q % Cfg::OT2;
               a2[ot] = mfma_bf16(w, pass == 2 ? l1[s >> 1][s & 1] : h1[s >> 1][s & 1], a2[ot]);
@@ -519,10 +571,31 @@ static int launch_sa_bf16(const float *xyz, int stride, const float *new_xyz, in
   MPX_REQUIRE(nq < ((int64_t)1 << 31), "mpx_sa_mlp_bf16x3: too many query points");
   constexpr int Q = CF == 1 ? 16 : 4;  // queries per wave
   const int64_t per_block = (int64_t)WAVES * Q;
-  hipLaunchKernelGGL((sa_mlp_bf16_kernel<CF, C1, C2, C3, Q>), dim3((unsigned)((nq + per_block - 1) / per_block)),
+  hipLaunchKernelGGL((sa_mlp_bf16_kernel<CF, C1, C2, C3, Q, false>), dim3((unsigned)((nq + per_block - 1) / per_block)),
                      dim3(64 * WAVES), 0, mpx_s(stream), xyz, stride, new_xyz, new_stride, feat, feat_stride, idx, cnt, order, nq, N, npoint, nsample,
-                     static_cast<const unsigned char *>(wpack), out, out_stride);
+                     static_cast<const unsigned char *>(wpack), out, out_stride, nullptr, nullptr);
   MPX_LAUNCH_CHECK("mpx_sa_mlp_bf16x3");
+}
+
+MPX_EXPORT int mpx_sa_mlp_bf16x3_factored(const float *pre, const float *ctr, const int32_t *idx, const int32_t *cnt,
+                                          const int32_t *order, int B, int N, int npoint, int nsample, const void *wpack,
+                                          int C, int c1, int c2, int c3, float *out, int out_stride, mpx_stream_t stream) {
+  MPX_REQUIRE(C == 64 && c1 == 128 && c2 == 128 && c3 == 256,
+              "mpx_sa_mlp_bf16x3_factored: built for the (64+3, 128, 128, 256) module (C=%d, %d, %d, %d)", C, c1, c2, c3);
+  MPX_REQUIRE(B >= 0 && N >= 1 && npoint >= 0 && nsample > 0, "mpx_sa_mlp_bf16x3_factored: bad size");
+  MPX_REQUIRE(pre && ctr && idx, "mpx_sa_mlp_bf16x3_factored: NULL operand");
+  MPX_REQUIRE(out_stride >= c3, "mpx_sa_mlp_bf16x3_factored: bad stride");
+  MPX_REQUIRE((((uintptr_t)wpack | (uintptr_t)pre | (uintptr_t)ctr) & 15) == 0,
+              "mpx_sa_mlp_bf16x3_factored: operands must be 16-byte aligned");
+  if (B == 0 || npoint == 0) return 0;
+  const int64_t nq = (int64_t)B * npoint;
+  MPX_REQUIRE(nq < ((int64_t)1 << 31), "mpx_sa_mlp_bf16x3_factored: too many query points");
+  constexpr int Q = 4;
+  const int64_t per_block = (int64_t)WAVES * Q;
+  hipLaunchKernelGGL((sa_mlp_bf16_kernel<64, 128, 128, 256, Q, true>), dim3((unsigned)((nq + per_block - 1) / per_block)),
+                     dim3(64 * WAVES), 0, mpx_s(stream), nullptr, 0, nullptr, 0, nullptr, 0, idx, cnt, order, nq, N, npoint,
+                     nsample, static_cast<const unsigned char *>(wpack), out, out_stride, pre, ctr);
+  MPX_LAUNCH_CHECK("mpx_sa_mlp_bf16x3_factored");
 }
 
 MPX_EXPORT int mpx_sa_mlp_bf16x3(const float *xyz, int stride, const float *new_xyz, int new_stride,

@@ -178,12 +178,12 @@ class MPiNetsPointNet(nn.Module):
         cnt2 = torch.empty((B, sa2.npoint), dtype=torch.int32, device=dev)
         lib.call("mpx_ball_query", lib.ptr(sa3_in), K3, lib.ptr(xyz1), 3, B, sa1.npoint, sa2.npoint,
                  float(sa2.radius), sa2.nsample, lib.ptr(nbr2), lib.ptr(cnt2))
-        if sa2.precision == "fp32" and sa2.factored and (C1o,) + tuple(c.out_channels for c in c2) == FACTORED_SHAPE:
+        if sa2.factored and (C1o,) + tuple(c.out_channels for c in c2) == FACTORED_SHAPE:
             f1buf[:, :, C1o:C1o + 3] = xyz1
             f1buf[:, :, C1o + 3] = 0
             sa_mlp_factored(f1buf.view(B * sa1.npoint, C1o + 4), sa3_in.view(B * sa2.npoint, K3)[:, :4], nbr2,
                             cnt2 if sa2.elide_padding else torch.full_like(cnt2, sa2.nsample), sa2._packed, c2, C1o,
-                            sa1.npoint, lib.ptr(sa3_in) + 12, K3)
+                            sa1.npoint, lib.ptr(sa3_in) + 12, K3, precision=sa2.precision, split=self._split)
         else:
             w2 = sa2._packed.get(c2, C1o, sa2.precision)
             launch_sa(sa2.precision, lib.ptr(xyz1), 3, lib.ptr(sa3_in), K3, lib.ptr(f1), f1.stride(1), C1o, nbr2,

@@ -224,15 +224,25 @@ def sa_mlp_fused(xyz: torch.Tensor, new_xyz: torch.Tensor, feat: torch.Tensor, f
 
 
 def sa_mlp_factored(point_rows: torch.Tensor, centre_rows: torch.Tensor, idx: torch.Tensor, cnt: torch.Tensor,
-                    packed: "SAWeights", convs: List[nn.Conv2d], C: int, N: int, out_ptr: int, out_stride: int) -> None:
+                    packed: "SAWeights", convs: List[nn.Conv2d], C: int, N: int, out_ptr: int, out_stride: int,
+                    precision: str = "fp32", split: Optional["SplitWeights"] = None) -> None:
     """The (64+3,128,128,256) module with its first layer evaluated per point / per query instead of per
-    (query, neighbour) row (``mpx_sa_mlp_factored``).  ``point_rows`` [B*N, Kp] = [feat | xyz | 0] rows,
-    ``centre_rows`` [B*npoint, 4] = [xyz | anything finite] rows (row strides free)."""
+    (query, neighbour) row (``mpx_sa_mlp_factored`` / ``mpx_sa_mlp_bf16x3_factored``).  ``point_rows`` [B*N, Kp] =
+    [feat | xyz | 0] rows, ``centre_rows`` [B*npoint, 4] = [xyz | anything finite] rows (row strides free)."""
     B, npoint, nsample = idx.shape
     wp, wc, nb1 = packed.factored(convs, C)
+    c1, c2, c3 = (c.out_channels for c in convs)
+    if precision == "bf16x3":
+        pre = linear_x3(point_rows, wp, None, 0, split, source=convs[0].weight)
+        ctr = linear(centre_rows, wc, nb1)  # K = 4: not worth the matrix cores
+        order = torch.empty(B * npoint, dtype=torch.int32, device=idx.device)
+        scratch = torch.empty(128, dtype=torch.int32, device=idx.device)
+        _lib.call("mpx_sort_queries", _lib.ptr(cnt), B * npoint, nsample, _lib.ptr(order), _lib.ptr(scratch))
+        _lib.call("mpx_sa_mlp_bf16x3_factored", _lib.ptr(pre), _lib.ptr(ctr), _lib.ptr(idx), _lib.ptr(cnt), _lib.ptr(order),
+                  B, N, npoint, nsample, _lib.ptr(packed.get(convs, C, "bf16x3")), C, c1, c2, c3, out_ptr, out_stride)
+        return
     pre = linear(point_rows, wp, None)
     ctr = linear(centre_rows, wc, nb1)
-    c1, c2, c3 = (c.out_channels for c in convs)
     _lib.call("mpx_sa_mlp_factored", _lib.ptr(pre), _lib.ptr(ctr), _lib.ptr(idx), _lib.ptr(cnt), B, N, npoint, nsample,
               _lib.ptr(packed.get(convs, C, "fp32")), C, c1, c2, c3, out_ptr, out_stride)
 
@@ -411,12 +421,15 @@ class PointnetSAModule(nn.Module):
                 fpm = features.transpose(1, 2).contiguous() if features.requires_grad else feat_pm
                 out = sa_module_train(convs, xyz, 3, new_xyz, 3, fpm, C, C, nbr, cnt, (B, N, self.npoint, self.nsample))
                 return new_xyz, out.transpose(1, 2).contiguous()
-            if self.precision == "fp32" and self.factored and (C,) + tuple(c.out_channels for c in convs) == FACTORED_SHAPE:
+            if self.factored and (C,) + tuple(c.out_channels for c in convs) == FACTORED_SHAPE:
                 full = cnt if self.elide_padding else torch.full_like(cnt, self.nsample)
                 rows = torch.cat((feat_pm, xyz, torch.zeros_like(xyz[:, :, :1])), dim=2).view(B * N, C + 4)
                 ctr_rows = torch.nn.functional.pad(new_xyz, (0, 1)).view(B * self.npoint, 4)
                 out = torch.empty((B, self.npoint, convs[-1].out_channels), dtype=torch.float32, device=xyz.device)
-                sa_mlp_factored(rows, ctr_rows, nbr, full, self._packed, convs, C, N, _lib.ptr(out), out.stride(1))
+                if not hasattr(self, "_split"):
+                    self._split = SplitWeights()
+                sa_mlp_factored(rows, ctr_rows, nbr, full, self._packed, convs, C, N, _lib.ptr(out), out.stride(1),
+                                precision=self.precision, split=self._split)
                 return new_xyz, out.transpose(1, 2).contiguous()
             wpack = self._packed.get(convs, C, self.precision)
             out = sa_mlp_fused(xyz, new_xyz, feat_pm, C, C, nbr, wpack, tuple(c.out_channels for c in convs),
