@@ -63,6 +63,14 @@ __device__ __forceinline__ void mpx_sincos(float x, float &s, float &c) {
   if (k >= 2) s = -s;
 }
 
+// max of a value with its partner lane 32 apart (lane i <-> i ^ 32), in every lane: one v_permlane32_swap (VALU)
+// instead of a ds_bpermute round trip through the LDS crossbar
+__device__ __forceinline__ float mpx_max_across_halves(float v) {
+  const unsigned u = __float_as_uint(v);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);  // r[0] = {lo, lo}, r[1] = {hi, hi}
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
 // 3x4 rigid transform: r[9] row-major rotation, t[3]
 struct Rigid {
   float r[9];

@@ -137,7 +137,7 @@ __global__ void __launch_bounds__(256)
           const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
           if (row < M) m = fmaxf(m, hb_act(acc[i][j][r] + bv, act));
         }
-      m = fmaxf(m, __shfl_xor(m, 32));
+      m = mpx_max_across_halves(m);
       if (half == 0) atomicMax(reinterpret_cast<int *>(y + (size_t)by * ldy + col), __float_as_int(m));
     }
   } else {

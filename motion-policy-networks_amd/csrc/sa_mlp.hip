@@ -264,7 +264,7 @@ __global__ void __launch_bounds__(256, 2)
 #pragma unroll
   for (int ot = 0; ot < Cfg::OT3; ++ot) {
     float v = omax[ot];
-    v = fmaxf(v, __shfl_xor(v, 32));
+    v = mpx_max_across_halves(v);
     const int ch = ot * 32 + col;
     v = fmaxf(v + bias3[ch], 0.0f);
     if (half == 0) orow[ch] = v;
@@ -376,7 +376,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CF == 1
   }
   auto flush = [&](int ot, int qi) __attribute__((always_inline)) {
     float v = run[ot];
-    v = fmaxf(v, __shfl_xor(v, 32));
+    v = mpx_max_across_halves(v);
     const int ch = ot * 32 + col;
     v = fmaxf(v + b3_s[ch], 0.0f);
     if (half == 0) out[(int64_t)(qbase + qi) * out_stride + ch] = v;

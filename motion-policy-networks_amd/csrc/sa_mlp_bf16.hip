@@ -373,7 +373,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
   }
   auto flush = [&](int ot, int qg) {
     float v = run[ot];
-    v = fmaxf(v, __shfl_xor(v, 32));
+    v = mpx_max_across_halves(v);
     const int ch = ot * 32 + col;
     v = fmaxf(v + bias3[ch], 0.0f);
     if (live && half == 0) out[(int64_t)qg * out_stride + ch] = v;
