@@ -5,7 +5,7 @@
 //                             writes its partial tile and mpx_reduce_partials adds them in a fixed order
 //                             (deterministic, no atomics).  Same fp32 MFMA inner loop as dense.hip: the 16-row slabs
 //                             of dY and X are transposed while they are staged into LDS so both operands are k-major.
-//   db = column sums of dY -> mpx_colsum (partials + the same reduction)
+//   db = column sums of dY -> accumulated by the first k-tile's workgroups from the slabs they stage anyway
 //   dZ = dY * act'(y)      -> mpx_act_backward (ReLU / LeakyReLU masks from the layer's OUTPUT)
 #include "common.h"
 
@@ -15,7 +15,7 @@ constexpr int WG_T = 128, WG_BK = 16, WG_LDT = WG_BK + 4;
 
 __global__ void __launch_bounds__(256)
     linear_wgrad_kernel(const float *__restrict__ dy, int lddy, const float *__restrict__ x, int ldx, int M, int N,
-                        int K, int rows_per_split, float *__restrict__ partial) {
+                        int K, int rows_per_split, float *__restrict__ partial, int with_bias) {
   __shared__ __attribute__((aligned(16))) float smem[2 * 2 * WG_T * WG_LDT];  // [As0 | As1 | Bs0 | Bs1]
   float(*As)[WG_T * WG_LDT] = reinterpret_cast<float(*)[WG_T * WG_LDT]>(smem);
   float(*Bs)[WG_T * WG_LDT] = reinterpret_cast<float(*)[WG_T * WG_LDT]>(smem + 2 * WG_T * WG_LDT);
@@ -56,6 +56,9 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
+  // bias gradient = column sums of dY: the workgroups of the first k-tile add up the slabs they stage anyway
+  const bool do_bias = with_bias && blockIdx.x == 0 && tid < WG_T;
+  float bsum = 0.0f;
   const int nslab = (me - mb + WG_BK - 1) / WG_BK;
   if (nslab > 0) {
     gload(mb);
@@ -85,11 +88,19 @@ __global__ void __launch_bounds__(256)
             const float bv = u == 0 ? b[j][v].x : (u == 1 ? b[j][v].y : (u == 2 ? b[j][v].z : b[j][v].w));
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
           }
+    if (do_bias) {
+#pragma unroll
+      for (int v = 0; v < WG_BK / 4; ++v) {
+        const float4 q = *reinterpret_cast<const float4 *>(&As[buf][tid * WG_LDT + 4 * v]);
+        bsum += (q.x + q.y) + (q.z + q.w);
+      }
+    }
     if (kb + 1 < nslab) sstore(buf ^ 1);
     __syncthreads();
   }
-  // partial[z][n][k]; C[row][col]: col = lane&31 (k), row = (r&3) + 8*(r>>2) + 4*half (n)
-  float *dst = partial + (size_t)blockIdx.z * N * K;
+  // per split: [N*K weight partials | N bias partials]; C[row][col]: col = lane&31 (k), row = (r&3) + 8*(r>>2) + 4*half (n)
+  float *dst = partial + (size_t)blockIdx.z * ((size_t)N * K + N);
+  if (do_bias && n0 + tid < N) dst[(size_t)N * K + n0 + tid] = bsum;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -103,25 +114,14 @@ __global__ void __launch_bounds__(256)
     }
 }
 
-// out[i] = sum_s partial[s][i], s ascending
+// out[i] = sum_s partial[s * stride + i], s ascending
 __global__ void __launch_bounds__(256)
-    reduce_partials_kernel(const float *__restrict__ partial, int S, int64_t n, float *__restrict__ out) {
+    reduce_partials_kernel(const float *__restrict__ partial, int S, int64_t stride, int64_t n, float *__restrict__ out) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   float acc = 0.0f;
-  for (int s = 0; s < S; ++s) acc += partial[(size_t)s * n + i];
+  for (int s = 0; s < S; ++s) acc += partial[(size_t)s * stride + i];
   out[i] = acc;
-}
-
-// partial[z][c] = sum of column c over this split's rows
-__global__ void __launch_bounds__(256)
-    colsum_kernel(const float *__restrict__ y, int ldy, int M, int N, int rows_per_split, float *__restrict__ partial) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= N) return;
-  const int mb = blockIdx.y * rows_per_split, me = min(M, mb + rows_per_split);
-  float acc = 0.0f;
-  for (int m = mb; m < me; ++m) acc += y[(size_t)m * ldy + c];
-  partial[(size_t)blockIdx.y * N + c] = acc;
 }
 
 // dz = dy * act'(y): ReLU -> y > 0; LeakyReLU(0.01) -> y >= 0 ? 1 : 0.01 (sign of the output = sign of the input)
@@ -154,13 +154,17 @@ MPX_EXPORT int mpx_linear_wgrad(const float *dy, int lddy, const float *x, int l
   const int rps = cdiv(cdiv(M, S), WG_BK) * WG_BK;
   MPX_REQUIRE(cdiv(N, WG_T) <= 65535 && S <= 65535, "mpx_linear_wgrad: grid too large");
   hipLaunchKernelGGL(linear_wgrad_kernel, dim3(cdiv(K, WG_T), cdiv(N, WG_T), S), dim3(256), 0, mpx_s(stream), dy, lddy, x,
-                     ldx, M, N, K, rps, scratch);
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv((int64_t)N * K, 256)), dim3(256), 0, mpx_s(stream), scratch, S,
-                     (int64_t)N * K, dw);
-  if (db) {
-    float *bpart = scratch + (size_t)S * N * K;
-    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 256), S), dim3(256), 0, mpx_s(stream), dy, lddy, M, N, rps, bpart);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(N, 256)), dim3(256), 0, mpx_s(stream), bpart, S, (int64_t)N, db);
+                     ldx, M, N, K, rps, scratch, db ? 1 : 0);
+  // dw [N*K] and db [N] are adjacent in every split's slice: one reduction (db lands right behind dw if the caller
+  // laid them out that way, else two launches)
+  if (db == dw + (size_t)N * K) {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(per, 256)), dim3(256), 0, mpx_s(stream), scratch, S, per, per, dw);
+  } else {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv((int64_t)N * K, 256)), dim3(256), 0, mpx_s(stream), scratch, S,
+                       per, (int64_t)N * K, dw);
+    if (db)
+      hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(N, 256)), dim3(256), 0, mpx_s(stream), scratch + (size_t)N * K,
+                         S, per, (int64_t)N, db);
   }
   MPX_LAUNCH_CHECK("mpx_linear_wgrad");
 }

@@ -289,8 +289,9 @@ class _LinearFn(torch.autograd.Function):
             wt = torch.nn.functional.pad(wp, (0, 0, 0, Np - N)).t().contiguous() if Np != N else wp.t().contiguous()
             gx = linear(dz, wt, None, 0)[:, :K]  # [M, Kp] -> [M, K]
         if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
-            dw = torch.empty((Np, Kp), dtype=torch.float32, device=g.device)
-            db = torch.empty(Np, dtype=torch.float32, device=g.device) if has_bias else None
+            both = torch.empty(Np * Kp + Np, dtype=torch.float32, device=g.device)  # dw | db: one reduction launch
+            dw = both[:Np * Kp].view(Np, Kp)
+            db = both[Np * Kp:] if has_bias else None
             nscr = _lib.load().mpx_linear_wgrad_scratch(M, Np, Kp)
             scratch = torch.empty(nscr, dtype=torch.float32, device=g.device)
             _lib.call("mpx_linear_wgrad", _lib.ptr(dz), dz.stride(0), _lib.ptr(xp), xp.stride(0), M, Np, Kp, _lib.ptr(dw),
