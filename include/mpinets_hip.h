@@ -167,6 +167,11 @@ int64_t mpx_linear_wgrad_scratch(int M, int N, int K);
 int mpx_linear_wgrad(const float *dy, int lddy, const float *x, int ldx, int M, int N, int K, float *dw,
                      float *db, float *scratch, mpx_stream_t stream);
 
+/* backward of mpx_groupnorm_leaky on [M, C]: dx, dgamma [C], dbeta [C]; stats = scratch of 2*M*groups floats    */
+int mpx_groupnorm_leaky_grad(const float *x, const float *gamma, const float *beta, const float *dy, int M,
+                             int C, int groups, float eps, float *dx, float *dgamma, float *dbeta,
+                             float *stats, mpx_stream_t stream);
+
 /* ---- differentiable grouping + max-pool of the set-abstraction stack (row N1) --------------------
  * The reference trains through pointnet2_ops' QueryAndGroup / max-pool (model.py:366-383).  Here a
  * neighbourhood contributes only its distinct neighbours (cnt from mpx_ball_query; padding repeats

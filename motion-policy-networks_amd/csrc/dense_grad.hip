@@ -134,6 +134,106 @@ __global__ void __launch_bounds__(256)
   dz[i] = act == MPX_ACT_RELU ? (o > 0.0f ? g : 0.0f) : (act == MPX_ACT_LEAKY ? (o >= 0.0f ? g : 0.01f * g) : g);
 }
 
+// ---- backward of GroupNorm(groups) + LeakyReLU(0.01) on [M, C] (mpx_groupnorm_leaky; model.py:386-391) -----------
+// xh = (x - mean) * rstd, o = xh * gamma + beta, y = leaky(o).  One wave per (row, group): recomputes the statistics,
+// forms do = dy * leaky'(o) and dx = rstd * (dxh - mean(dxh) - xh * mean(dxh * xh)) with dxh = do * gamma, and leaves
+// (mean, rstd) in `stats` for the parameter-gradient pass.
+__device__ __forceinline__ float gn_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+__global__ void __launch_bounds__(256)
+    groupnorm_leaky_dx_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
+                              const float *__restrict__ beta, const float *__restrict__ dy, int64_t n_rg, int C,
+                              int groups, float eps, float *__restrict__ dx, float *__restrict__ stats) {
+  const int lane = threadIdx.x & 63;
+  const int64_t rg = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (rg >= n_rg) return;
+  const int gs = C / groups;
+  const int64_t row = rg / groups;
+  const int g = (int)(rg % groups);
+  const int64_t base = row * C + (int64_t)g * gs;
+  constexpr int MAXV = 8;  // gs <= 512
+  float v[MAXV], s = 0.0f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + 64 * i;
+    v[i] = c < gs ? x[base + c] : 0.0f;
+    s += v[i];
+  }
+  const float mean = gn_wave_sum(s) / (float)gs;
+  float q = 0.0f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + 64 * i;
+    const float d = c < gs ? v[i] - mean : 0.0f;
+    q += d * d;
+  }
+  const float rstd = 1.0f / sqrtf(gn_wave_sum(q) / (float)gs + eps);
+  float dxh[MAXV], s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + 64 * i;
+    dxh[i] = 0.0f;
+    if (c < gs) {
+      const float xh = (v[i] - mean) * rstd, ga = gamma[g * gs + c];
+      const float o = xh * ga + beta[g * gs + c];
+      const float d_o = dy[base + c] * (o >= 0.0f ? 1.0f : 0.01f);
+      dxh[i] = d_o * ga;
+      s1 += dxh[i];
+      s2 += dxh[i] * xh;
+      v[i] = xh;
+    }
+  }
+  s1 = gn_wave_sum(s1) / (float)gs;
+  s2 = gn_wave_sum(s2) / (float)gs;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + 64 * i;
+    if (c < gs) dx[base + c] = rstd * (dxh[i] - s1 - v[i] * s2);
+  }
+  if (lane == 0) stats[2 * rg] = mean, stats[2 * rg + 1] = rstd;
+}
+
+// dgamma[c] = sum_rows do * xh, dbeta[c] = sum_rows do (rows in order: deterministic)
+__global__ void __launch_bounds__(256)
+    groupnorm_leaky_dparam_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
+                                  const float *__restrict__ beta, const float *__restrict__ dy,
+                                  const float *__restrict__ stats, int M, int C, int groups,
+                                  float *__restrict__ dgamma, float *__restrict__ dbeta) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const int g = c / (C / groups);
+  const float ga = gamma[c], be = beta[c];
+  float a = 0.0f, b = 0.0f;
+  for (int m = 0; m < M; ++m) {
+    const float mean = stats[2 * ((int64_t)m * groups + g)], rstd = stats[2 * ((int64_t)m * groups + g) + 1];
+    const float xh = (x[(int64_t)m * C + c] - mean) * rstd;
+    const float d_o = dy[(int64_t)m * C + c] * (xh * ga + be >= 0.0f ? 1.0f : 0.01f);
+    a += d_o * xh;
+    b += d_o;
+  }
+  dgamma[c] = a;
+  dbeta[c] = b;
+}
+
+MPX_EXPORT int mpx_groupnorm_leaky_grad(const float *x, const float *gamma, const float *beta, const float *dy, int M,
+                                        int C, int groups, float eps, float *dx, float *dgamma, float *dbeta,
+                                        float *stats, mpx_stream_t stream) {
+  MPX_REQUIRE(M >= 0 && C >= 1 && groups >= 1 && C % groups == 0, "mpx_groupnorm_leaky_grad: bad size");
+  MPX_REQUIRE(C / groups <= 512, "mpx_groupnorm_leaky_grad: group size %d > 512 unsupported", C / groups);
+  MPX_REQUIRE(dx && dgamma && dbeta && stats, "mpx_groupnorm_leaky_grad: NULL output");
+  if (M == 0) return 0;
+  const int64_t n = (int64_t)M * groups;
+  hipLaunchKernelGGL(groupnorm_leaky_dx_kernel, dim3(cdiv(n, 4)), dim3(256), 0, mpx_s(stream), x, gamma, beta, dy, n, C,
+                     groups, eps, dx, stats);
+  hipLaunchKernelGGL(groupnorm_leaky_dparam_kernel, dim3(cdiv(C, 256)), dim3(256), 0, mpx_s(stream), x, gamma, beta, dy,
+                     stats, M, C, groups, dgamma, dbeta);
+  MPX_LAUNCH_CHECK("mpx_groupnorm_leaky_grad");
+}
+
 MPX_EXPORT int64_t mpx_linear_wgrad_scratch(int M, int N, int K) {
   const int tiles = cdiv(N, WG_T) * cdiv(K, WG_T);
   int S = cdiv(1024, tiles);

@@ -19,7 +19,7 @@ import torch
 from torch import nn
 
 from . import _lib
-from .pointnet2 import (FACTORED_SHAPE, PRECISIONS, linear_train, PointnetSAModule, SAWeights, SplitWeights, groupnorm_leaky, launch_sa,
+from .pointnet2 import (FACTORED_SHAPE, PRECISIONS, groupnorm_leaky_train, linear_train, PointnetSAModule, SAWeights, SplitWeights, groupnorm_leaky, launch_sa,
                         linear, linear_x3, sa_mlp_factored, sa_mlp_fused)
 from .utils import unnormalize_franka_joints
 
@@ -116,9 +116,9 @@ class MPiNetsPointNet(nn.Module):
         if aux is not None:
             aux.update(fps_idx1=idx1, xyz1=xyz1, ball_idx1=nbr1, ball_cnt1=cnt1, f1=f1, fps_idx2=idx2, ball_idx2=nbr2,
                        ball_cnt2=cnt2, f3=pooled)
-        fc = self.fc_layer  # Linear -> GroupNorm -> LeakyReLU (x2) -> Linear; the norms stay torch ops
-        h = torch.nn.functional.leaky_relu(fc[1](linear_train(pooled, fc[0].weight, fc[0].bias)))
-        h = torch.nn.functional.leaky_relu(fc[4](linear_train(h, fc[3].weight, fc[3].bias)))
+        fc = self.fc_layer  # Linear -> GroupNorm -> LeakyReLU (x2) -> Linear
+        h = groupnorm_leaky_train(linear_train(pooled, fc[0].weight, fc[0].bias), fc[1])
+        h = groupnorm_leaky_train(linear_train(h, fc[3].weight, fc[3].bias), fc[4])
         return linear_train(h, fc[6].weight, fc[6].bias)
 
     def _sa3_first_weight(self) -> torch.Tensor:

@@ -301,6 +301,34 @@ class _LinearFn(torch.autograd.Function):
         return gx, gw, gb, None
 
 
+class _GroupNormLeakyFn(torch.autograd.Function):
+    """GroupNorm(groups) + LeakyReLU(0.01) on [M, C]: ``mpx_groupnorm_leaky`` forward, ``mpx_groupnorm_leaky_grad`` back."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, groups, eps):
+        xc, w, b = _lib.f32c(x.detach()), _lib.f32c(weight.detach()), _lib.f32c(bias.detach())
+        y = groupnorm_leaky(xc, w, b, groups, eps)
+        ctx.save_for_backward(xc, w, b)
+        ctx.meta = (groups, eps)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        xc, w, b = ctx.saved_tensors
+        groups, eps = ctx.meta
+        g = _lib.f32c(g)
+        M, C = xc.shape
+        dx, dw, db = torch.empty_like(xc), torch.empty_like(w), torch.empty_like(b)
+        stats = torch.empty(2 * M * groups, dtype=torch.float32, device=xc.device)
+        _lib.call("mpx_groupnorm_leaky_grad", _lib.ptr(xc), _lib.ptr(w), _lib.ptr(b), _lib.ptr(g), M, C, groups, float(eps),
+                  _lib.ptr(dx), _lib.ptr(dw), _lib.ptr(db), _lib.ptr(stats))
+        return dx, dw, db, None, None
+
+
+def groupnorm_leaky_train(x: torch.Tensor, norm: nn.GroupNorm) -> torch.Tensor:
+    return _GroupNormLeakyFn.apply(x, norm.weight, norm.bias, norm.num_groups, norm.eps)
+
+
 def linear_train(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], act: int = 0) -> torch.Tensor:
     """Differentiable dense layer on the engine's kernels; ``x`` may have leading batch dimensions."""
     lead = x.shape[:-1]
