@@ -105,3 +105,21 @@ def test_depth_clouds_feed_the_policy():
     with torch.no_grad():
         dq = mdl(prob["xyz"], prob["q_norm"])
     assert dq.shape == (B, 7) and torch.isfinite(dq).all()
+
+
+def test_full_resolution_draw_matches_oracle(oracle):
+    """640 x 480 images, the reference's 4096-point draw (run_inference.py:52-54, 78-85): same subset, same order."""
+    from mpinets_amd.depth import DepthCamera, camera_pose
+
+    B = 2
+    scn, t, cub, cyl, q = problem(B, ("tabletop", "dresser"), 9)
+    cam = DepthCamera()
+    poses = torch.from_numpy(np.stack([camera_pose("tabletop"), camera_pose("dresser")])).to(dev())
+    depth = cam.render(poses, cub, cyl, q=q)
+    pts = cam.sample_cloud(depth, poses, 4096, seed=2024)
+    opts, ocount = oracle.depth_select(depth.reshape(B, -1).cpu().numpy(), poses.cpu().numpy(), cam.intrinsics, 640, 480,
+                                       4096, 2024)
+    np.testing.assert_array_equal(cam.last_counts.cpu().numpy(), ocount)
+    assert ocount.min() >= 4096
+    np.testing.assert_allclose(pts.cpu().numpy(), opts, rtol=0, atol=2e-6)
+    assert torch.minimum(cub.sdf(pts), cyl.sdf(pts)).abs().max().item() < 2e-5

@@ -109,6 +109,22 @@ def test_ball_query_bucketed_path_edge_cases(oracle, N, npoint, stride):
     np.testing.assert_array_equal(idx.cpu().numpy(), ref)
 
 
+def test_ball_query_bucketed_path_smaller_nsample(oracle):
+    """nsample 64 on the bucketed path (rows never exceed one key per lane)."""
+    from mpinets_amd.pointnet2 import ball_query
+
+    rng = np.random.default_rng(5)
+    x = rng.uniform(-0.4, 0.4, (2, 3000, 3)).astype(np.float32)
+    x[:, :200] = rng.normal(scale=0.02, size=(2, 200, 3))  # > 64 hits around the origin
+    centres = np.ascontiguousarray(x[:, ::10][:, :256]).copy()
+    centres[:, 0] = 0.0
+    idx, cnt = ball_query(0.06, 64, T(x), T(centres), return_counts=True)
+    ref, rcnt = oracle.ball_query(centres, x, 0.06, 64, return_counts=True)
+    assert rcnt[:, 0].min() == 64
+    np.testing.assert_array_equal(cnt.cpu().numpy(), rcnt)
+    np.testing.assert_array_equal(idx.cpu().numpy(), ref)
+
+
 def test_group_points_matches_oracle(oracle):
     from mpinets_amd.pointnet2 import ball_query, furthest_point_sample, query_and_group
 
