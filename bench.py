@@ -234,8 +234,39 @@ def main():
             orc.collision_flags(ctr[:, None], r_, (ph["cuboid_centers"], ph["cuboid_dims"], ph["cuboid_quats"]),
                                 (ph["cylinder_centers"], ph["cylinder_radii"], ph["cylinder_heights"], ph["cylinder_quats"]))
             c2_cpu = 1024 / (time.perf_counter() - th)
+        c4_cpu = None
+        if args.cpu_envs > 0:  # config-4 work on the host: 32 trajectories x 50 waypoints, oracle port, single thread
+            th = time.perf_counter()
+            tj = traj[:32].cpu().numpy()
+            ctr4 = orc.transform_table(orc.franka_fk(tj.reshape(-1, 7)), c_, l_).reshape(32, 50, -1, 3)
+            p4 = {k: prob[k][:32].cpu().numpy() for k in prob if k.startswith(("cuboid_", "cylinder_"))}
+            orc.collision_flags(ctr4, r_, (p4["cuboid_centers"], p4["cuboid_dims"], p4["cuboid_quats"]),
+                                (p4["cylinder_centers"], p4["cylinder_radii"], p4["cylinder_heights"], p4["cylinder_quats"]))
+            c4_cpu = 32 * 50 / (time.perf_counter() - th)
+        # configs 1 and 3: the same closed-loop step (static scene) for a single problem and for 256 problems x 50 steps
+        small = {}
+        for nb, nsteps in ((1, 50), (256, 50)):
+            ps = make_problem_batch(nb, seed=7000 + nb, device=dev, kinds=("tabletop",), M1=16, M2=16, scene_pool=64,
+                                    device_clouds=True)
+            es = RolloutEngine(model, ps)
+            es.step()
+            torch.cuda.synchronize()
+            t_s = time.perf_counter()
+            for _ in range(nsteps):
+                es.step()
+            torch.cuda.synchronize()
+            small[nb] = (time.perf_counter() - t_s) * 1e3
+            del es, ps
         extra = {
+            "c1_single_problem": {"envs": 1, "steps": 50, "ms_per_step": small[1] / 50, "rollout_ms": small[1],
+                                  "what": "one tabletop problem, 50 closed-loop steps (the reference's deployed use; it "
+                                          "assumes 80 ms per step, run_inference.py:297)"},
+            "c3_rollout_256": {"envs": 256, "steps": 50, "ms_per_step": small[256] / 50, "rollout_ms": small[256],
+                               "env_steps_per_s": 256 * 50 / small[256] * 1e3, "dtype": "f32",
+                               "what": "256 tabletop problems, 50-step rollout (policy forward + joint update + FK cloud "
+                                       "refresh + collision check per step)"},
             "c4_collision_validation": {"envs": B, "waypoints": 50, "ms": c4_ms, "env_waypoints_per_s": B * 50 / c4_ms * 1e3,
+                                        "cpu_port_env_waypoints_per_s": c4_cpu, "cpu_cores": 1,
                                         "what": "FK + 56-sphere SDF vs 40 cuboids + 16 cylinders (zero-padded), has_collision[B] (model.py:293-314)"},
             "c2_fk_sdf_1024": {"envs": 1024, "ms": c2_ms, "env_steps_per_s": 1024 / c2_ms * 1e3,
                                "cpu_port_env_steps_per_s": c2_cpu, "cpu_cores": 1,
