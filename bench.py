@@ -83,7 +83,7 @@ def stage_table(prof, steps, B, sa1_ms, sa1_exec, sa2_ms, sa2_exec):
     executed FLOPs, FPS / ball query in G point-pair distance evaluations per second (VALU / latency bound: their
     HBM traffic, the 100 KB slab read once, is negligible)."""
     ms = lambda k: float(np.sum(prof[k])) / steps
-    lin_ms = ms("mpx_linear") + ms("mpx_linear_rowmax")
+    lin_ms = ms("mpx_linear") + ms("mpx_linear_ws") + ms("mpx_linear_rowmax")
     lin_flops = 2.0 * B * (512 * 68 * 128 + 128 * 4 * 128            # SA2 first layer, per point / per query
                            + 128 * (260 * 512 + 512 * 512 + 512 * 1024)  # group-all module
                            + 1024 * 4096 + 4096 * 2048 + 2048 * 2048    # fc head
@@ -156,7 +156,7 @@ def main():
         eng.step()
     torch.cuda.synchronize()
     shard.barrier()
-    _lib.profile_start("mpx_sa_mlp", "mpx_sa_mlp_factored", "mpx_fps", "mpx_ball_query", "mpx_linear", "mpx_linear_rowmax",
+    _lib.profile_start("mpx_sa_mlp", "mpx_sa_mlp_factored", "mpx_fps", "mpx_ball_query", "mpx_linear", "mpx_linear_ws", "mpx_linear_rowmax",
                         "mpx_franka_cloud", "mpx_franka_collision", "mpx_joint_step", "mpx_groupnorm_leaky", "mpx_scene_cloud")
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -178,7 +178,7 @@ def main():
         torch.cuda.synchronize()
         shard.barrier()
         _lib.profile_start("mpx_sa_mlp_bf16x3", "mpx_sa_mlp_bf16x3_factored", "mpx_linear_bf16x3", "mpx_linear_rowmax_bf16x3",
-                            "mpx_linear")
+                            "mpx_linear", "mpx_linear_ws")
         tf0 = time.perf_counter()
         for _ in range(args.fast_steps):
             eng.step()
@@ -188,7 +188,7 @@ def main():
         fall = _lib.profile_stop()
         model.set_precision("fp32")
         fdense = float(np.sum(fall["mpx_linear_bf16x3"]) + np.sum(fall["mpx_linear_rowmax_bf16x3"])
-                       + np.sum(fall["mpx_linear"])) / args.fast_steps
+                       + np.sum(fall["mpx_linear"]) + np.sum(fall["mpx_linear_ws"])) / args.fast_steps
         fast = (fel, float(np.mean(fall["mpx_sa_mlp_bf16x3"])), float(np.mean(fall["mpx_sa_mlp_bf16x3_factored"])), fdense)
 
     # final host gather (the only cross-rank data movement): joint angles + collision flags
@@ -283,7 +283,7 @@ def main():
         eng_s.step()
         torch.cuda.synchronize()
         shard.barrier()
-        names_s = ("mpx_sa_mlp", "mpx_sa_mlp_factored", "mpx_fps", "mpx_ball_query", "mpx_linear", "mpx_linear_rowmax")
+        names_s = ("mpx_sa_mlp", "mpx_sa_mlp_factored", "mpx_fps", "mpx_ball_query", "mpx_linear", "mpx_linear_ws", "mpx_linear_rowmax")
         _lib.profile_start(*names_s)
         ts0 = time.perf_counter()
         for _ in range(args.static_steps):
@@ -371,7 +371,7 @@ def main():
                 "sa1_tiles_nominal": B * 512 * 4,
                 "fps": float(np.sum(prof["mpx_fps"])) / args.steps,
                 "ball_query": float(np.sum(prof["mpx_ball_query"])) / args.steps,
-                "linear_all": float(np.sum(prof["mpx_linear"]) + np.sum(prof["mpx_linear_rowmax"])) / args.steps,
+                "linear_all": float(np.sum(prof["mpx_linear"]) + np.sum(prof["mpx_linear_ws"]) + np.sum(prof["mpx_linear_rowmax"])) / args.steps,
             },
             # per-stage achieved / peak with the ALGORITHMIC work of SURVEY.md section 8(d) (per env-step, x B envs)
             "stages": stage_table(prof, args.steps, B, sa1_ms, sa1_exec, sa2_ms, sa2_exec),

@@ -343,6 +343,16 @@ int mpx_sa_pack_bf16x3(const float *w1, const float *b1, const float *w2, const 
 int mpx_linear(const float *x, int ldx, const float *w, const float *bias, int M, int N, int K,
                int act, float *y, int ldy, mpx_stream_t stream);
 
+/* The same layer with a caller-provided workspace that lets skinny problems (few 128x128 output tiles, long K:
+ * the fc / decoder layers of a single-problem or few-hundred-problem rollout) split K over the chip's CUs.
+ * mpx_linear_workspace(M,N,K) = bytes this shape wants (0: it would not split); the partial sums are added in
+ * slice order, so results are deterministic (they differ from mpx_linear's by fp32 summation order only).
+ * workspace == NULL behaves exactly like mpx_linear.                                          */
+int64_t mpx_linear_workspace(int M, int N, int K);
+int mpx_linear_ws(const float *x, int ldx, const float *w, const float *bias, int M, int N, int K,
+                  int act, float *y, int ldy, void *workspace, int64_t workspace_bytes,
+                  mpx_stream_t stream);
+
 /* Last layer of the group-all SA module with its max-pool fused (model.py:383):
  *   y[g, n] = max over the `rows` rows of group g of relu(x[g*rows + r, :] . w[n, :] + bias[n])
  * rows must be 128 (one workgroup tile) and divide M; y [M/rows, N] is written (zeroed first).  */

@@ -33,8 +33,9 @@ __device__ __forceinline__ float act_apply(float v, int act) {
 // because the pooled values are post-ReLU (>= 0) and y is zero-initialised by the launcher.
 template <int BK, bool POOL>
 __global__ void __launch_bounds__(256)
-    linear_kernel(const float *__restrict__ x, int ldx, const float *__restrict__ w,
-                  const float *__restrict__ bias, int M, int N, int K, int act, float *__restrict__ y, int ldy) {
+    linear_kernel(const float *__restrict__ x, int ldx, const float *__restrict__ w, int ldw,
+                  const float *__restrict__ bias, int M, int N, int K, int act, float *__restrict__ y, int ldy,
+                  int kslice, size_t zstride) {
   constexpr int LDT = BK + 4;       // padded row: conflict-free 16-byte fragment reads
   constexpr int HK = BK / 2;        // k-values per lane-half per slab
   constexpr int NLD = BK / 8;       // float4 staged per thread per matrix per slab
@@ -55,6 +56,15 @@ __global__ void __launch_bounds__(256)
     bx = (int)(slot % gridDim.x);
   }
   const int m0 = by * BM, n0 = bx * BN;
+  // split-K launches (gridDim.z > 1): slice z owns k in [z*kslice, (z+1)*kslice) and writes its raw partial
+  // tile to y + z*zstride; the launcher passes bias = nullptr / act = none and reduces the slices afterwards.
+  {
+    const int kz = blockIdx.z * kslice;
+    x += kz;
+    w += kz;
+    y += blockIdx.z * zstride;
+    K = min(kslice, K - kz);
+  }
 
   // staging map: thread -> (row, 4-float column chunk); BK/4 chunks per row, NLD rows per thread
   constexpr int CPR = BK / 4, RPP = 256 / CPR;  // chunks per row, rows per pass
@@ -68,7 +78,7 @@ __global__ void __launch_bounds__(256)
       pa[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       pb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (m0 + r < M && kk < K) pa[i] = *reinterpret_cast<const float4 *>(x + (size_t)(m0 + r) * ldx + kk);
-      if (n0 + r < N && kk < K) pb[i] = *reinterpret_cast<const float4 *>(w + (size_t)(n0 + r) * K + kk);
+      if (n0 + r < N && kk < K) pb[i] = *reinterpret_cast<const float4 *>(w + (size_t)(n0 + r) * ldw + kk);
     }
   };
   auto sstore = [&](int buf) {
@@ -190,11 +200,71 @@ MPX_EXPORT int mpx_linear(const float *x, int ldx, const float *w, const float *
   static const int bk = getenv("MPX_GEMM_BK") ? atoi(getenv("MPX_GEMM_BK")) : 16;  // tuning override
   if (bk == 32 && K >= 64)
     hipLaunchKernelGGL((linear_kernel<32, false>), dim3(cdiv(N, BN), cdiv(M, BM)), dim3(256), 0, mpx_s(stream), x, ldx,
-                       w, bias, M, N, K, act, y, ldy);
+                       w, K, bias, M, N, K, act, y, ldy, K, (size_t)0);
   else
     hipLaunchKernelGGL((linear_kernel<16, false>), dim3(cdiv(N, BN), cdiv(M, BM)), dim3(256), 0, mpx_s(stream), x, ldx,
-                       w, bias, M, N, K, act, y, ldy);
+                       w, K, bias, M, N, K, act, y, ldy, K, (size_t)0);
   MPX_LAUNCH_CHECK("mpx_linear");
+}
+
+// ---- split-K for skinny problems ------------------------------------------------------------------------
+// A rollout of ONE problem (or a few hundred) leaves the fc / decoder layers with 1..32 output tiles: 4096->2048
+// at M <= 128 is 16 workgroups walking K = 4096 alone (310 us on 6 % of the CUs).  With a workspace the K range
+// is cut into S slices (blockIdx.z), each writing a raw partial tile; splitk_reduce_kernel then adds the S
+// partials IN SLICE ORDER (deterministic), the bias and the activation.
+static int splitk_plan(int M, int N, int K, int *kslice) {
+  const int64_t tiles = (int64_t)cdiv(M, BM) * cdiv(N, BN);
+  *kslice = K;
+  if (tiles >= 128 || K < 512) return 1;
+  const int slabs = cdiv(K, 16);
+  int S = (int)((512 + tiles - 1) / tiles);
+  if (S > slabs / 4) S = slabs / 4;  // >= 64 k per slice
+  if (S < 2) return 1;
+  const int per = cdiv(slabs, S);
+  *kslice = per * 16;
+  return cdiv(K, *kslice);
+}
+
+__global__ void __launch_bounds__(256)
+    splitk_reduce_kernel(const float *__restrict__ part, int S, size_t zstride, const float *__restrict__ bias,
+                         int M, int N, int act, float *__restrict__ y, int ldy) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (int64_t)M * N) return;
+  const int row = (int)(e / N), col = (int)(e % N);
+  float acc = part[e];
+  for (int s = 1; s < S; ++s) acc += part[s * zstride + e];
+  if (bias) acc += bias[col];
+  y[(size_t)row * ldy + col] = act_apply(acc, act);
+}
+
+MPX_EXPORT int64_t mpx_linear_workspace(int M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  int kslice;
+  const int S = splitk_plan(M, N, K, &kslice);
+  return S > 1 ? (int64_t)S * M * N * (int64_t)sizeof(float) : 0;
+}
+
+MPX_EXPORT int mpx_linear_ws(const float *x, int ldx, const float *w, const float *bias, int M, int N, int K,
+                             int act, float *y, int ldy, void *workspace, int64_t workspace_bytes,
+                             mpx_stream_t stream) {
+  int kslice = K;
+  const int S = (M > 0 && N > 0 && K > 0) ? splitk_plan(M, N, K, &kslice) : 1;
+  if (S <= 1 || workspace == nullptr) return mpx_linear(x, ldx, w, bias, M, N, K, act, y, ldy, stream);
+  MPX_REQUIRE(K % 4 == 0 && ldx % 4 == 0, "mpx_linear_ws: K and ldx must be multiples of 4 (got %d, %d)", K, ldx);
+  MPX_REQUIRE((((uintptr_t)x | (uintptr_t)w | (uintptr_t)workspace) & 15) == 0,
+              "mpx_linear_ws: x, w and workspace must be 16-byte aligned");
+  MPX_REQUIRE(ldx >= K && ldy >= N, "mpx_linear_ws: leading dimension too small");
+  MPX_REQUIRE(act >= 0 && act <= 2, "mpx_linear_ws: unknown activation %d", act);
+  MPX_REQUIRE(workspace_bytes >= mpx_linear_workspace(M, N, K),
+              "mpx_linear_ws: workspace of %lld bytes, mpx_linear_workspace asks for %lld", (long long)workspace_bytes,
+              (long long)mpx_linear_workspace(M, N, K));
+  float *part = static_cast<float *>(workspace);
+  const size_t zstride = (size_t)M * N;
+  hipLaunchKernelGGL((linear_kernel<16, false>), dim3(cdiv(N, BN), cdiv(M, BM), S), dim3(256), 0, mpx_s(stream), x,
+                     ldx, w, K, static_cast<const float *>(nullptr), M, N, K, MPX_ACT_NONE, part, N, kslice, zstride);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv((int64_t)M * N, 256)), dim3(256), 0, mpx_s(stream), part, S,
+                     zstride, bias, M, N, act, y, ldy);
+  MPX_LAUNCH_CHECK("mpx_linear_ws");
 }
 
 MPX_EXPORT int mpx_linear_rowmax(const float *x, int ldx, const float *w, const float *bias, int M, int N, int K,
@@ -212,10 +282,10 @@ MPX_EXPORT int mpx_linear_rowmax(const float *x, int ldx, const float *w, const 
   static const int bk = getenv("MPX_GEMM_BK") ? atoi(getenv("MPX_GEMM_BK")) : 16;
   if (bk == 32 && K >= 64)
     hipLaunchKernelGGL((linear_kernel<32, true>), dim3(cdiv(N, BN), M / BM), dim3(256), 0, mpx_s(stream), x, ldx, w,
-                       bias, M, N, K, MPX_ACT_RELU, y, ldy);
+                       K, bias, M, N, K, MPX_ACT_RELU, y, ldy, K, (size_t)0);
   else
     hipLaunchKernelGGL((linear_kernel<16, true>), dim3(cdiv(N, BN), M / BM), dim3(256), 0, mpx_s(stream), x, ldx, w,
-                       bias, M, N, K, MPX_ACT_RELU, y, ldy);
+                       K, bias, M, N, K, MPX_ACT_RELU, y, ldy, K, (size_t)0);
   MPX_LAUNCH_CHECK("mpx_linear_rowmax");
 }
 

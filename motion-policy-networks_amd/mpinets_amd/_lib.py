@@ -59,6 +59,8 @@ PROTOTYPES = {
     "mpx_sa_pack_bf16x3_size": [I, I, I, I],
     "mpx_sa_pack_bf16x3": [P, P, P, P, P, P, I, I, I, I, P, P],
     "mpx_linear": [P, I, P, P, I, I, I, I, P, I, P],
+    "mpx_linear_workspace": [I, I, I],
+    "mpx_linear_ws": [P, I, P, P, I, I, I, I, P, I, P, L, P],
     "mpx_linear_rowmax": [P, I, P, P, I, I, I, I, P, I, P],
     "mpx_split_bf16": [P, I, I, P, P, P],
     "mpx_linear_bf16x3": [P, I, P, P, P, I, I, I, I, P, I, P],
@@ -71,7 +73,7 @@ PROTOTYPES = {
     "mpx_rowmax": [P, I, I, I, I, P, I, P],
 }
 RESTYPES = {"mpx_last_error": c_char_p, "mpx_sa_pack_size": c_int64, "mpx_sa_pack_bf16x3_size": c_int64,
-            "mpx_linear_wgrad_scratch": c_int64}
+            "mpx_linear_wgrad_scratch": c_int64, "mpx_linear_workspace": c_int64}
 
 _lib: Optional[ctypes.CDLL] = None
 

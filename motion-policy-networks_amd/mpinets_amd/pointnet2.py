@@ -77,9 +77,21 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], 
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=x.device)
     assert out.shape == (M, N) and out.stride(1) == 1
-    _lib.call("mpx_linear", _lib.ptr(x), x.stride(0), _lib.ptr(weight), _lib.ptr(bias), M, N, K, act,
-              _lib.ptr(out), out.stride(0))
+    need = _lib.load().mpx_linear_workspace(M, N, K)
+    if need == 0:
+        _lib.call("mpx_linear", _lib.ptr(x), x.stride(0), _lib.ptr(weight), _lib.ptr(bias), M, N, K, act,
+                  _lib.ptr(out), out.stride(0))
+    else:  # skinny problem: split K over the CUs through a per-(device, stream) workspace (stream-ordered reuse)
+        key = (x.device, _lib.stream_ptr())
+        ws = _WORKSPACE.get(key)
+        if ws is None or ws.numel() < need:
+            ws = _WORKSPACE[key] = torch.empty(max(need, 16 << 20), dtype=torch.uint8, device=x.device)
+        _lib.call("mpx_linear_ws", _lib.ptr(x), x.stride(0), _lib.ptr(weight), _lib.ptr(bias), M, N, K, act,
+                  _lib.ptr(out), out.stride(0), _lib.ptr(ws), ws.numel())
     return out
+
+
+_WORKSPACE = {}
 
 
 class SplitWeights:

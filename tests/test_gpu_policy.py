@@ -48,6 +48,46 @@ def test_linear_strided_output_and_input():
     assert (out[:, :8] == -5).all() and (out[:, 32:] == -5).all()
 
 
+def test_linear_split_k_for_skinny_problems():
+    """mpx_linear_ws: the K range of a layer with few output tiles is cut over the CUs; slices are added in
+    order (deterministic), so the result matches float64 like the unsplit kernel and repeats bit for bit."""
+    from mpinets_amd import _lib
+    from mpinets_amd.pointnet2 import linear
+
+    lib = _lib.load()
+    assert lib.mpx_linear_workspace(8192, 4096, 1024) == 0  # enough tiles already
+    assert lib.mpx_linear_workspace(1, 64, 128) == 0        # K too short to be worth a second launch
+    rng = np.random.default_rng(5)
+    for (M, N, K) in [(1, 2048, 4096), (1, 512, 2112), (256, 2048, 2048), (50, 7, 512), (130, 300, 1000)]:
+        need = lib.mpx_linear_workspace(M, N, K)
+        assert need > 0 and need % (4 * M * N) == 0, (M, N, K, need)
+        xw = T(rng.normal(size=(M, K + 12)).astype(np.float32))
+        w = T(rng.normal(size=(N, K)).astype(np.float32))
+        b = T(rng.normal(size=N).astype(np.float32))
+        out = torch.full((M, N + 9), -5.0, device=dev())
+        for act in (0, 2):
+            linear(xw[:, :K], w, b, act, out=out[:, 4:4 + N])
+            ref = xw[:, :K].double() @ w.double().T + b.double()
+            if act == 2:
+                ref = torch.where(ref >= 0, ref, 0.01 * ref)
+            assert (out[:, 4:4 + N].double() - ref).abs().max() <= 1e-5 * np.sqrt(K), (M, N, K, act)
+            assert (out[:, :4] == -5).all() and (out[:, 4 + N:] == -5).all()
+            again = torch.empty((M, N), device=dev())
+            linear(xw[:, :K], w, b, act, out=again)
+            assert torch.equal(again, out[:, 4:4 + N])
+        # a NULL workspace is the unsplit kernel
+        y0 = torch.empty((M, N), device=dev())
+        _lib.call("mpx_linear_ws", _lib.ptr(xw), xw.stride(0), _lib.ptr(w), _lib.ptr(b), M, N, K, 0, _lib.ptr(y0), N, None, 0)
+        y1 = torch.empty((M, N), device=dev())
+        _lib.call("mpx_linear", _lib.ptr(xw), xw.stride(0), _lib.ptr(w), _lib.ptr(b), M, N, K, 0, _lib.ptr(y1), N)
+        assert torch.equal(y0, y1)
+        # too small a workspace is refused
+        small = torch.empty(16, dtype=torch.uint8, device=dev())
+        with pytest.raises(_lib.MpxError):
+            _lib.call("mpx_linear_ws", _lib.ptr(xw), xw.stride(0), _lib.ptr(w), _lib.ptr(b), M, N, K, 0, _lib.ptr(y0), N,
+                      _lib.ptr(small), 16)
+
+
 def test_groupnorm_leaky_and_rowmax(oracle):
     from mpinets_amd import _lib
     from mpinets_amd.pointnet2 import groupnorm_leaky
@@ -260,6 +300,24 @@ def test_padding_elision_is_bit_identical(precision):
     assert c1.min() >= 1 and c2.max() <= 128
 
 
+@pytest.mark.parametrize("factored", [True, False])
+def test_small_batch_launch_shape_is_bit_identical(factored):
+    """A single problem runs the grouped-MLP kernels with fewer queries per wave than a large batch (more waves,
+    lower latency): every (query, neighbour) row is still the same arithmetic, so the features agree bit for bit."""
+    from mpinets_amd.model import MotionPolicyNetwork
+    from mpinets_amd.scenes import make_problem_batch
+
+    torch.manual_seed(6)
+    mdl = MotionPolicyNetwork().to(dev()).eval().set_factored(factored)
+    prob = make_problem_batch(80, seed=12, device=dev(), kinds=("tabletop", "cubby", "dresser"), M1=40, device_clouds=True)
+    a, b = {}, {}
+    with torch.no_grad():
+        mdl(prob["xyz"], prob["q_norm"], aux=a)                      # 80 x 512 / 80 x 128 queries: 16 / 8 per wave
+        dq_small = mdl(prob["xyz"][:3].contiguous(), prob["q_norm"][:3].contiguous(), aux=b)  # 4 / 2 per wave
+    assert torch.equal(a["f1"][:3], b["f1"]) and torch.equal(a["sa3_in"][:3], b["sa3_in"])
+    assert torch.isfinite(dq_small).all()
+
+
 def test_factored_first_layer_matches_direct_form(oracle):
     """SA2's first layer per point / per query (mpx_sa_mlp_factored) vs per (query, neighbour) row (mpx_sa_mlp):
     same result up to the rounding of one re-associated sum, both within the north-star 1e-5 of the oracle."""
@@ -303,7 +361,10 @@ def test_linear_rowmax_equals_linear_then_rowmax():
     x = T(rng.normal(size=(5 * 128, 512)).astype(np.float32))
     w = T((rng.normal(size=(1024, 512)) * 0.05).astype(np.float32))
     b = T(rng.normal(size=1024).astype(np.float32))
-    ref = linear(x, w, b, 1).reshape(5, 128, 1024).max(dim=1).values
+    full = torch.empty((640, 1024), device=dev())  # the unsplit kernel: same k order as the pooled one
+    _lib.call("mpx_linear", _lib.ptr(x), 512, _lib.ptr(w), _lib.ptr(b), 640, 1024, 512, 1, _lib.ptr(full), 1024)
+    ref = full.reshape(5, 128, 1024).max(dim=1).values
+    assert (linear(x, w, b, 1) - full).abs().max() < 1e-5  # (linear() splits K at this size)
     out = torch.full((5, 1024), -1.0, device=dev())
     _lib.call("mpx_linear_rowmax", _lib.ptr(x), 512, _lib.ptr(w), _lib.ptr(b), 640, 1024, 512, 128, _lib.ptr(out), 1024)
     assert torch.equal(out, ref)
