@@ -215,7 +215,8 @@ MPX_EXPORT int mpx_linear(const float *x, int ldx, const float *w, const float *
 static int splitk_plan(int M, int N, int K, int *kslice) {
   const int64_t tiles = (int64_t)cdiv(M, BM) * cdiv(N, BN);
   *kslice = K;
-  if (tiles >= 128 || K < 512) return 1;
+  // (M > 1024: the partial tiles would cost more HBM traffic than the idle CUs are worth)
+  if (tiles >= 128 || K < 256 || M > 1024) return 1;
   const int slabs = cdiv(K, 16);
   int S = (int)((512 + tiles - 1) / tiles);
   if (S > slabs / 4) S = slabs / 4;  // >= 64 k per slice

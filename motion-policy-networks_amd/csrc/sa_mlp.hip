@@ -657,7 +657,7 @@ MPX_EXPORT int mpx_sa_mlp_factored(const float *pre, const float *ctr, const int
   if (B == 0 || npoint == 0) return 0;
   const int64_t nq = (int64_t)B * npoint;
   MPX_REQUIRE(nq / 4 + 1 < ((int64_t)1 << 31), "mpx_sa_mlp_factored: too many query points");
-  auto go = [&](auto qtag) {  // queries per wave: 8, or 2 for small batches (see launch_sa)
+  auto go = [&](auto qtag) {  // queries per wave: 8, or 2 / 1 for small batches (see launch_sa)
     constexpr int Q = decltype(qtag)::value;
     const int64_t nw = (nq + Q - 1) / Q;
     const int bpe = (npoint % Q == 0 && B % 8 == 0) ? npoint / Q : 0;
@@ -666,7 +666,8 @@ MPX_EXPORT int mpx_sa_mlp_factored(const float *pre, const float *ctr, const int
                        out_stride, bpe, pre, ctr);
   };
   if (nq >= 1024 * 8) go(std::integral_constant<int, 8>{});
-  else go(std::integral_constant<int, 2>{});
+  else if (nq >= 1024) go(std::integral_constant<int, 2>{});
+  else go(std::integral_constant<int, 1>{});  // a handful of problems: one query (1-2 tiles) per wave
   MPX_LAUNCH_CHECK("mpx_sa_mlp_factored");
 }
 

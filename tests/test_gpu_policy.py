@@ -58,7 +58,7 @@ def test_linear_split_k_for_skinny_problems():
     assert lib.mpx_linear_workspace(8192, 4096, 1024) == 0  # enough tiles already
     assert lib.mpx_linear_workspace(1, 64, 128) == 0        # K too short to be worth a second launch
     rng = np.random.default_rng(5)
-    for (M, N, K) in [(1, 2048, 4096), (1, 512, 2112), (256, 2048, 2048), (50, 7, 512), (130, 300, 1000)]:
+    for (M, N, K) in [(1, 2048, 4096), (1, 512, 2112), (256, 2048, 2048), (50, 7, 256), (130, 300, 1000)]:
         need = lib.mpx_linear_workspace(M, N, K)
         assert need > 0 and need % (4 * M * N) == 0, (M, N, K, need)
         xw = T(rng.normal(size=(M, K + 12)).astype(np.float32))
