@@ -245,9 +245,10 @@ def main():
             c4_cpu = 32 * 50 / (time.perf_counter() - th)
         # configs 1 and 3: the same closed-loop step (static scene) for a single problem and for 256 problems x 50 steps
         small = {}
-        for nb, nsteps in ((1, 50), (256, 50)):
+        for nb, nsteps, prec in ((1, 50, "fp32"), (256, 50, "fp32"), (256, 50, "bf16x3")):
             ps = make_problem_batch(nb, seed=7000 + nb, device=dev, kinds=("tabletop",), M1=16, M2=16, scene_pool=64,
                                     device_clouds=True)
+            model.set_precision(prec)
             es = RolloutEngine(model, ps)
             es.step()
             torch.cuda.synchronize()
@@ -255,14 +256,16 @@ def main():
             for _ in range(nsteps):
                 es.step()
             torch.cuda.synchronize()
-            small[nb] = (time.perf_counter() - t_s) * 1e3
+            small[nb if prec == "fp32" else "256x3"] = (time.perf_counter() - t_s) * 1e3
             del es, ps
+        model.set_precision("fp32")
         extra = {
             "c1_single_problem": {"envs": 1, "steps": 50, "ms_per_step": small[1] / 50, "rollout_ms": small[1],
                                   "what": "one tabletop problem, 50 closed-loop steps (the reference's deployed use; it "
                                           "assumes 80 ms per step, run_inference.py:297)"},
             "c3_rollout_256": {"envs": 256, "steps": 50, "ms_per_step": small[256] / 50, "rollout_ms": small[256],
                                "env_steps_per_s": 256 * 50 / small[256] * 1e3, "dtype": "f32",
+                               "bf16x3_rollout_ms": small["256x3"], "bf16x3_env_steps_per_s": 256 * 50 / small["256x3"] * 1e3,
                                "what": "256 tabletop problems, 50-step rollout (policy forward + joint update + FK cloud "
                                        "refresh + collision check per step)"},
             "c4_collision_validation": {"envs": B, "waypoints": 50, "ms": c4_ms, "env_waypoints_per_s": B * 50 / c4_ms * 1e3,

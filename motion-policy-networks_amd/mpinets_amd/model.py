@@ -13,6 +13,8 @@ GroupNorm all run in ``libmpinets_hip.so`` (fp32 end to end, fp32 MFMA for every
 """
 from __future__ import annotations
 
+import os
+
 from typing import Callable, Dict, List, Optional, Sequence
 
 import torch
@@ -24,6 +26,21 @@ from .pointnet2 import (FACTORED_SHAPE, PRECISIONS, groupnorm_leaky_train, linea
 from .utils import unnormalize_franka_joints
 
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
+
+
+# A handful of problems cannot fill the chip with any single kernel (FPS is ONE workgroup per problem), so below
+# this batch size independent branches of the forward are issued on a second HIP stream: the joint-angle encoder
+# next to the point-cloud encoder, SA2's sampling + ball query next to SA1's ball query + grouped MLP.
+OVERLAP_MAX_BATCH = int(os.environ.get("MPX_OVERLAP_MAX_BATCH", "512"))
+_SIDE_STREAMS = {}
+
+
+def side_stream(device) -> "torch.cuda.Stream":
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    st = _SIDE_STREAMS.get(key)
+    if st is None:
+        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return st
 
 
 class MPiNetsPointNet(nn.Module):
@@ -156,28 +173,43 @@ class MPiNetsPointNet(nn.Module):
         lib.call("mpx_fps", lib.ptr(pc), B, N, 4, sa1.npoint, lib.ptr(idx1), lib.ptr(xyz1), 3)
         nbr1 = torch.empty((B, sa1.npoint, sa1.nsample), dtype=torch.int32, device=dev)
         cnt1 = torch.empty((B, sa1.npoint), dtype=torch.int32, device=dev)
-        lib.call("mpx_ball_query", lib.ptr(xyz1), 3, lib.ptr(pc), 4, B, N, sa1.npoint, float(sa1.radius),
-                 sa1.nsample, lib.ptr(nbr1), lib.ptr(cnt1))
         c1 = sa1.convs()
         w1 = sa1._packed.get(c1, 1, sa1.precision)
         # SA1 output rows carry [f1 (64) | xyz1 (3) | 0]: the operand of SA2's per-point first-layer GEMM
         C1o = c1[-1].out_channels
         f1buf = torch.empty((B, sa1.npoint, C1o + 4), dtype=torch.float32, device=dev)
         f1 = f1buf[:, :, :C1o]
-        launch_sa(sa1.precision, lib.ptr(pc), 4, lib.ptr(xyz1), 3, lib.ptr(pc) + 12, 4, 1, nbr1,
-                  cnt1 if sa1.elide_padding else None, B, N, sa1.npoint, sa1.nsample, w1,
-                  tuple(c.out_channels for c in c1), lib.ptr(f1), f1.stride(1))
-        # ---- SA2 (writes into the group-all input rows [xyz2 | f2 | 0]) ----------------------------
+        # SA2's inputs (the group-all rows [xyz2 | f2 | 0] it will write into, its samples and neighbours)
         c2 = sa2.convs()
         C2o = c2[-1].out_channels
         K3 = (3 + C2o + 3) // 4 * 4
         sa3_in = torch.zeros((B, sa2.npoint, K3), dtype=torch.float32, device=dev)
         idx2 = torch.empty((B, sa2.npoint), dtype=torch.int32, device=dev)
-        lib.call("mpx_fps", lib.ptr(xyz1), B, sa1.npoint, 3, sa2.npoint, lib.ptr(idx2), lib.ptr(sa3_in), K3)
         nbr2 = torch.empty((B, sa2.npoint, sa2.nsample), dtype=torch.int32, device=dev)
         cnt2 = torch.empty((B, sa2.npoint), dtype=torch.int32, device=dev)
-        lib.call("mpx_ball_query", lib.ptr(sa3_in), K3, lib.ptr(xyz1), 3, B, sa1.npoint, sa2.npoint,
-                 float(sa2.radius), sa2.nsample, lib.ptr(nbr2), lib.ptr(cnt2))
+
+        def sample_sa2():  # needs only xyz1
+            lib.call("mpx_fps", lib.ptr(xyz1), B, sa1.npoint, 3, sa2.npoint, lib.ptr(idx2), lib.ptr(sa3_in), K3)
+            lib.call("mpx_ball_query", lib.ptr(sa3_in), K3, lib.ptr(xyz1), 3, B, sa1.npoint, sa2.npoint,
+                     float(sa2.radius), sa2.nsample, lib.ptr(nbr2), lib.ptr(cnt2))
+
+        def module_sa1():
+            lib.call("mpx_ball_query", lib.ptr(xyz1), 3, lib.ptr(pc), 4, B, N, sa1.npoint, float(sa1.radius),
+                     sa1.nsample, lib.ptr(nbr1), lib.ptr(cnt1))
+            launch_sa(sa1.precision, lib.ptr(pc), 4, lib.ptr(xyz1), 3, lib.ptr(pc) + 12, 4, 1, nbr1,
+                      cnt1 if sa1.elide_padding else None, B, N, sa1.npoint, sa1.nsample, w1,
+                      tuple(c.out_channels for c in c1), lib.ptr(f1), f1.stride(1))
+
+        if B <= OVERLAP_MAX_BATCH:  # two independent chains, two streams (buffers were allocated above, on `main`)
+            main, side = torch.cuda.current_stream(), side_stream(dev)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                sample_sa2()
+            module_sa1()
+            main.wait_stream(side)
+        else:
+            module_sa1()
+            sample_sa2()
         if sa2.factored and (C1o,) + tuple(c.out_channels for c in c2) == FACTORED_SHAPE:
             f1buf[:, :, C1o:C1o + 3] = xyz1
             f1buf[:, :, C1o + 3] = 0
@@ -304,15 +336,29 @@ class MotionPolicyNetwork(nn.Module):
 
             return mlp(self.decoder, torch.cat((pc_encoding, mlp(self.feature_encoder, _lib.f32c(q))), dim=1))
         cat = torch.empty((B, 2048 + 64), dtype=torch.float32, device=dev)
-        self.point_cloud_encoder(xyz, out=cat[:, :2048], aux=aux)
         fe = self.feature_encoder
         q8 = torch.zeros((B, 8), dtype=torch.float32, device=dev)
         q8[:, :7] = q
-        h = linear(q8, self._q_first_weight(), fe[0].bias, ACT_LEAKY)
-        h = linear(h, fe[2].weight, fe[2].bias, ACT_LEAKY)
-        h = linear(h, fe[4].weight, fe[4].bias, ACT_LEAKY)
-        h = linear(h, fe[6].weight, fe[6].bias, ACT_LEAKY)
-        linear(h, fe[8].weight, fe[8].bias, ACT_NONE, out=cat[:, 2048:])
+
+        def encode_q():
+            h1 = linear(q8, self._q_first_weight(), fe[0].bias, ACT_LEAKY)
+            h2 = linear(h1, fe[2].weight, fe[2].bias, ACT_LEAKY)
+            h3 = linear(h2, fe[4].weight, fe[4].bias, ACT_LEAKY)
+            h4 = linear(h3, fe[6].weight, fe[6].bias, ACT_LEAKY)
+            linear(h4, fe[8].weight, fe[8].bias, ACT_NONE, out=cat[:, 2048:])
+            return h1, h2, h3, h4
+
+        if B <= OVERLAP_MAX_BATCH:  # the joint-angle encoder beside the point-cloud encoder (see OVERLAP_MAX_BATCH)
+            main, side = torch.cuda.current_stream(), side_stream(dev)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                keep = encode_q()  # (side-stream temporaries stay referenced until `main` has waited for `side`)
+            self.point_cloud_encoder(xyz, out=cat[:, :2048], aux=aux)
+            main.wait_stream(side)
+            del keep
+        else:
+            self.point_cloud_encoder(xyz, out=cat[:, :2048], aux=aux)
+            encode_q()
         de = self.decoder
         h = self.point_cloud_encoder._lin(cat, de[0].weight, de[0].bias, ACT_LEAKY)
         h = linear(h, de[2].weight, de[2].bias, ACT_LEAKY)

@@ -1,0 +1,56 @@
+"""Does running two half-batches on two HIP streams (one a stage ahead of the other) beat one full batch?
+(development aid; result recorded in profiles/r01_other_measurements.md)  usage: two_stream_timing.py [B] [steps]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "motion-policy-networks_amd")]
+import torch
+
+from mpinets_amd.model import MotionPolicyNetwork
+from mpinets_amd.rollout import RolloutEngine
+from mpinets_amd.scenes import make_problem_batch
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+mdl = MotionPolicyNetwork().to(dev).eval()
+kinds = ("tabletop", "cubby", "dresser")
+
+
+def run(engines, streams, stagger_ms):
+    for e, s in zip(engines, streams):
+        with torch.cuda.stream(s):
+            e.step()
+    torch.cuda.synchronize()
+    if stagger_ms and len(streams) > 1:
+        with torch.cuda.stream(streams[1]):
+            torch.cuda._sleep(int(stagger_ms * 2.0e6))  # ~2 GHz spin
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        for e, s in zip(engines, streams):
+            with torch.cuda.stream(s):
+                e.step()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
+full = RolloutEngine(mdl, make_problem_batch(B, seed=0, device=dev, kinds=kinds, M1=40, scene_pool=64, device_clouds=True),
+                     rerender_scene=True)
+ms = run([full], [torch.cuda.current_stream()], 0)
+print(f"one stream, {B} envs: {ms:.2f} ms/step")
+del full
+halves = [RolloutEngine(mdl, make_problem_batch(B // 2, seed=10 + i, device=dev, kinds=kinds, M1=40, scene_pool=64,
+                                                device_clouds=True), rerender_scene=True) for i in range(2)]
+streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+for stagger in (0, 25, 50):
+    ms = run(halves, streams, stagger)
+    print(f"two streams x {B // 2} envs, stagger {stagger} ms: {ms:.2f} ms/step (incl. the stagger once: {stagger / steps:.2f} ms/step)")
+del halves
+quarters = [RolloutEngine(mdl, make_problem_batch(B // 4, seed=20 + i, device=dev, kinds=kinds, M1=40, scene_pool=64,
+                                                  device_clouds=True), rerender_scene=True) for i in range(4)]
+streams = [torch.cuda.Stream() for _ in range(4)]
+ms = run(quarters, streams, 0)
+print(f"four streams x {B // 4} envs: {ms:.2f} ms/step")
