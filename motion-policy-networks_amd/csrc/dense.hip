@@ -188,6 +188,81 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// ---- a few rows (M <= 8: the head of a single-problem rollout) ---------------------------------------------
+// No tile of the matrix pipe is worth filling: the layer is a stream of N*K weights (67 MB for the three fc layers)
+// against 1-8 activation rows.  The rows sit in LDS; a wave owns R = 2 output columns and walks their weight rows
+// 1 KB at a time (16 bytes per lane, coalesced), one fmaf chain per (row, column) and lane, then a butterfly sum
+// over the lanes -- a fixed order, so the result is deterministic (it differs from the MFMA kernel's by fp32
+// summation order only).
+constexpr int GEMV_R = 2;
+template <int MT>
+__global__ void __launch_bounds__(256)
+    gemv_kernel(const float *__restrict__ x, int ldx, const float *__restrict__ w, const float *__restrict__ bias,
+                int M, int N, int K, int act, float *__restrict__ y, int ldy) {
+  extern __shared__ __attribute__((aligned(16))) float xs[];  // [MT][K]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid * 4; i < MT * K; i += 1024) {  // K % 4 == 0: a float4 never straddles two rows
+    const int m = i / K, k = i - m * K;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (m < M) v = *reinterpret_cast<const float4 *>(x + (size_t)m * ldx + k);
+    *reinterpret_cast<float4 *>(xs + i) = v;
+  }
+  __syncthreads();
+  const int n0 = (blockIdx.x * 4 + wave) * GEMV_R;
+  if (n0 >= N) return;
+  float acc[MT][GEMV_R];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int r = 0; r < GEMV_R; ++r) acc[m][r] = 0.0f;
+  const float *wr[GEMV_R];
+#pragma unroll
+  for (int r = 0; r < GEMV_R; ++r) wr[r] = w + (size_t)min(n0 + r, N - 1) * K;  // (a column past N repeats the last: not stored)
+#pragma unroll 4
+  for (int k = lane * 4; k < K; k += 256) {
+    float4 wv[GEMV_R];
+#pragma unroll
+    for (int r = 0; r < GEMV_R; ++r) wv[r] = *reinterpret_cast<const float4 *>(wr[r] + k);
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const float4 xv = *reinterpret_cast<const float4 *>(xs + m * K + k);
+#pragma unroll
+      for (int r = 0; r < GEMV_R; ++r) {
+        float a = acc[m][r];
+        a = mpx_fma(xv.x, wv[r].x, a);
+        a = mpx_fma(xv.y, wv[r].y, a);
+        a = mpx_fma(xv.z, wv[r].z, a);
+        a = mpx_fma(xv.w, wv[r].w, a);
+        acc[m][r] = a;
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int r = 0; r < GEMV_R; ++r) {
+      float v = acc[m][r];
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+      if (lane == 0 && m < M && n0 + r < N)
+        y[(size_t)m * ldy + n0 + r] = act_apply(v + (bias ? bias[n0 + r] : 0.0f), act);
+    }
+}
+
+static bool gemv_fits(int M, int K) { return M <= 8 && (int64_t)(M <= 1 ? 1 : M <= 2 ? 2 : M <= 4 ? 4 : 8) * K * 4 <= 64 * 1024; }
+
+static void gemv_launch(const float *x, int ldx, const float *w, const float *bias, int M, int N, int K, int act,
+                        float *y, int ldy, mpx_stream_t stream) {
+  const dim3 g(cdiv(N, 4 * GEMV_R)), t(256);
+#define GEMV_GO(MT) \
+  hipLaunchKernelGGL(gemv_kernel<MT>, g, t, (size_t)MT * K * sizeof(float), mpx_s(stream), x, ldx, w, bias, M, N, K, act, y, ldy)
+  if (M <= 1) GEMV_GO(1);
+  else if (M <= 2) GEMV_GO(2);
+  else if (M <= 4) GEMV_GO(4);
+  else GEMV_GO(8);
+#undef GEMV_GO
+}
+
 MPX_EXPORT int mpx_linear(const float *x, int ldx, const float *w, const float *bias, int M, int N, int K,
                           int act, float *y, int ldy, mpx_stream_t stream) {
   MPX_REQUIRE(M >= 0 && N >= 1 && K >= 1, "mpx_linear: bad size");
@@ -196,6 +271,10 @@ MPX_EXPORT int mpx_linear(const float *x, int ldx, const float *w, const float *
   MPX_REQUIRE(ldx >= K && ldy >= N, "mpx_linear: leading dimension too small");
   MPX_REQUIRE(act >= 0 && act <= 2, "mpx_linear: unknown activation %d", act);
   if (M == 0) return 0;
+  if (gemv_fits(M, K)) {
+    gemv_launch(x, ldx, w, bias, M, N, K, act, y, ldy, stream);
+    MPX_LAUNCH_CHECK("mpx_linear");
+  }
   MPX_REQUIRE(cdiv(M, BM) <= 65535, "mpx_linear: M too large");
   static const int bk = getenv("MPX_GEMM_BK") ? atoi(getenv("MPX_GEMM_BK")) : 16;  // tuning override
   if (bk == 32 && K >= 64)
@@ -216,7 +295,7 @@ static int splitk_plan(int M, int N, int K, int *kslice) {
   const int64_t tiles = (int64_t)cdiv(M, BM) * cdiv(N, BN);
   *kslice = K;
   // (M > 1024: the partial tiles would cost more HBM traffic than the idle CUs are worth)
-  if (tiles >= 128 || K < 256 || M > 1024) return 1;
+  if (tiles >= 128 || K < 256 || M > 1024 || gemv_fits(M, K)) return 1;
   const int slabs = cdiv(K, 16);
   int S = (int)((512 + tiles - 1) / tiles);
   if (S > slabs / 4) S = slabs / 4;  // >= 64 k per slice

@@ -56,9 +56,10 @@ def test_linear_split_k_for_skinny_problems():
 
     lib = _lib.load()
     assert lib.mpx_linear_workspace(8192, 4096, 1024) == 0  # enough tiles already
-    assert lib.mpx_linear_workspace(1, 64, 128) == 0        # K too short to be worth a second launch
+    assert lib.mpx_linear_workspace(9, 64, 128) == 0        # K too short to be worth a second launch
+    assert lib.mpx_linear_workspace(1, 2048, 4096) == 0     # a few rows: the weight-streaming kernel, no split
     rng = np.random.default_rng(5)
-    for (M, N, K) in [(1, 2048, 4096), (1, 512, 2112), (256, 2048, 2048), (50, 7, 256), (130, 300, 1000)]:
+    for (M, N, K) in [(9, 2048, 4096), (12, 512, 2112), (256, 2048, 2048), (50, 7, 256), (130, 300, 1000)]:
         need = lib.mpx_linear_workspace(M, N, K)
         assert need > 0 and need % (4 * M * N) == 0, (M, N, K, need)
         xw = T(rng.normal(size=(M, K + 12)).astype(np.float32))
@@ -86,6 +87,28 @@ def test_linear_split_k_for_skinny_problems():
         with pytest.raises(_lib.MpxError):
             _lib.call("mpx_linear_ws", _lib.ptr(xw), xw.stride(0), _lib.ptr(w), _lib.ptr(b), M, N, K, 0, _lib.ptr(y0), N,
                       _lib.ptr(small), 16)
+
+
+def test_linear_few_rows_streams_the_weights():
+    """M <= 8 (the head of a single-problem rollout): rows in LDS, one wave per two output columns."""
+    from mpinets_amd.pointnet2 import linear
+
+    rng = np.random.default_rng(6)
+    for (M, N, K) in [(1, 4096, 1024), (1, 2048, 4096), (1, 7, 128), (2, 513, 2112), (3, 64, 8), (4, 2048, 4096),
+                      (5, 300, 2048), (8, 129, 260), (8, 33, 2048)]:
+        xw = T(rng.normal(size=(M, K + 4)).astype(np.float32))
+        w = T(rng.normal(size=(N, K)).astype(np.float32))
+        b = T(rng.normal(size=N).astype(np.float32))
+        out = torch.full((M, N + 5), -5.0, device=dev())
+        for act, bias in ((0, b), (1, b), (2, None)):
+            linear(xw[:, :K], w, bias, act, out=out[:, 2:2 + N])
+            ref = xw[:, :K].double() @ w.double().T + (b.double() if bias is not None else 0)
+            if act == 1:
+                ref = ref.clamp(min=0)
+            if act == 2:
+                ref = torch.where(ref >= 0, ref, 0.01 * ref)
+            assert (out[:, 2:2 + N].double() - ref).abs().max() <= 1e-5 * np.sqrt(K), (M, N, K, act)
+            assert (out[:, :2] == -5).all() and (out[:, 2 + N:] == -5).all()
 
 
 def test_groupnorm_leaky_and_rowmax(oracle):
