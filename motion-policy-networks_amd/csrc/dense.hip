@@ -430,15 +430,22 @@ MPX_EXPORT int mpx_groupnorm_leaky(const float *x, const float *gamma, const flo
 }
 
 // ---- max over groups of consecutive rows -------------------------------------------------------------
+// workgroup = 64 columns x 4 row groups (each thread walks every 4th row, coalesced 256-byte reads per row),
+// then the four partial maxima meet in LDS
 __global__ void __launch_bounds__(256)
     rowmax_kernel(const float *__restrict__ x, int ldx, int rows, int C, float *__restrict__ y, int ldy) {
-  const int g = blockIdx.y;
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  const float *p = x + (size_t)g * rows * ldx + c;
+  __shared__ float part[4][64];
+  const int g = blockIdx.y, lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
   float m = -__builtin_inff();
-  for (int r = 0; r < rows; ++r) m = fmaxf(m, p[(size_t)r * ldx]);
-  y[(size_t)g * ldy + c] = m;
+  if (c < C) {
+    const float *p = x + (size_t)g * rows * ldx + c;
+    for (int r = rg; r < rows; r += 4) m = fmaxf(m, p[(size_t)r * ldx]);
+  }
+  part[rg][lane] = m;
+  __syncthreads();
+  if (rg == 0 && c < C)
+    y[(size_t)g * ldy + c] = fmaxf(fmaxf(part[0][lane], part[1][lane]), fmaxf(part[2][lane], part[3][lane]));
 }
 
 MPX_EXPORT int mpx_rowmax(const float *x, int ldx, int G, int rows, int C, float *y, int ldy,
@@ -446,6 +453,6 @@ MPX_EXPORT int mpx_rowmax(const float *x, int ldx, int G, int rows, int C, float
   MPX_REQUIRE(G >= 0 && rows >= 1 && C >= 1 && ldx >= C && ldy >= C, "mpx_rowmax: bad size");
   MPX_REQUIRE(G <= 65535, "mpx_rowmax: G > 65535 (slab the batch)");
   if (G == 0) return 0;
-  hipLaunchKernelGGL(rowmax_kernel, dim3(cdiv(C, 256), G), dim3(256), 0, mpx_s(stream), x, ldx, rows, C, y, ldy);
+  hipLaunchKernelGGL(rowmax_kernel, dim3(cdiv(C, 64), G), dim3(256), 0, mpx_s(stream), x, ldx, rows, C, y, ldy);
   MPX_LAUNCH_CHECK("mpx_rowmax");
 }

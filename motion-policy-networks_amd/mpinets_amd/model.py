@@ -147,8 +147,10 @@ class MPiNetsPointNet(nn.Module):
         return self._sa3_w0[1]
 
     def forward(self, point_cloud: torch.Tensor, out: Optional[torch.Tensor] = None,
-                aux: Optional[dict] = None) -> torch.Tensor:
-        """point_cloud [B,N,4] (x,y,z,label) on the GPU -> [B,2048].
+                aux: Optional[dict] = None, side_work: Optional[Callable[[], object]] = None) -> torch.Tensor:
+        """point_cloud [B,N,4] (x,y,z,label) on the GPU -> [B,2048].  ``side_work``: launches of an independent
+        branch (the policy's joint-angle encoder) that small batches issue on the second stream, AFTER the first
+        sampling kernel is in flight so the host never delays it; large batches simply run it first.
 
         Engine path: the slab is read in place (stride-4 rows, label column = SA1's feature),
         features stay point-major between modules, SA2 writes straight into the group-all
@@ -200,16 +202,22 @@ class MPiNetsPointNet(nn.Module):
                       cnt1 if sa1.elide_padding else None, B, N, sa1.npoint, sa1.nsample, w1,
                       tuple(c.out_channels for c in c1), lib.ptr(f1), f1.stride(1))
 
+        keep = None
         if B <= OVERLAP_MAX_BATCH:  # two independent chains, two streams (buffers were allocated above, on `main`)
             main, side = torch.cuda.current_stream(), side_stream(dev)
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 sample_sa2()
+                if side_work is not None:
+                    keep = side_work()  # (its temporaries stay referenced until `main` has waited for `side`)
             module_sa1()
             main.wait_stream(side)
         else:
+            if side_work is not None:
+                side_work()
             module_sa1()
             sample_sa2()
+        del keep
         if sa2.factored and (C1o,) + tuple(c.out_channels for c in c2) == FACTORED_SHAPE:
             f1buf[:, :, C1o:C1o + 3] = xyz1
             f1buf[:, :, C1o + 3] = 0
@@ -337,28 +345,19 @@ class MotionPolicyNetwork(nn.Module):
             return mlp(self.decoder, torch.cat((pc_encoding, mlp(self.feature_encoder, _lib.f32c(q))), dim=1))
         cat = torch.empty((B, 2048 + 64), dtype=torch.float32, device=dev)
         fe = self.feature_encoder
-        q8 = torch.zeros((B, 8), dtype=torch.float32, device=dev)
-        q8[:, :7] = q
 
         def encode_q():
+            q8 = torch.zeros((B, 8), dtype=torch.float32, device=dev)
+            q8[:, :7] = q
             h1 = linear(q8, self._q_first_weight(), fe[0].bias, ACT_LEAKY)
             h2 = linear(h1, fe[2].weight, fe[2].bias, ACT_LEAKY)
             h3 = linear(h2, fe[4].weight, fe[4].bias, ACT_LEAKY)
             h4 = linear(h3, fe[6].weight, fe[6].bias, ACT_LEAKY)
             linear(h4, fe[8].weight, fe[8].bias, ACT_NONE, out=cat[:, 2048:])
-            return h1, h2, h3, h4
+            return q8, h1, h2, h3, h4
 
-        if B <= OVERLAP_MAX_BATCH:  # the joint-angle encoder beside the point-cloud encoder (see OVERLAP_MAX_BATCH)
-            main, side = torch.cuda.current_stream(), side_stream(dev)
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                keep = encode_q()  # (side-stream temporaries stay referenced until `main` has waited for `side`)
-            self.point_cloud_encoder(xyz, out=cat[:, :2048], aux=aux)
-            main.wait_stream(side)
-            del keep
-        else:
-            self.point_cloud_encoder(xyz, out=cat[:, :2048], aux=aux)
-            encode_q()
+        # (small batches: beside the point-cloud encoder, on its second stream -- see OVERLAP_MAX_BATCH)
+        self.point_cloud_encoder(xyz, out=cat[:, :2048], aux=aux, side_work=encode_q)
         de = self.decoder
         h = self.point_cloud_encoder._lin(cat, de[0].weight, de[0].bias, ACT_LEAKY)
         h = linear(h, de[2].weight, de[2].bias, ACT_LEAKY)
