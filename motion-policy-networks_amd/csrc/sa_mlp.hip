@@ -290,6 +290,10 @@ __global__ void __launch_bounds__(256, 2)
 // once per QUERY (`ctr` [B*npoint, C1]); the kernel then starts at relu(pre[j] - ctr[i]) -- a gather, a
 // subtraction -- and skips the layer-1 MFMAs of every (query, neighbour) row (15 % of SA2's matrix work).
 // Same arithmetic up to the order of that one sum (tolerance-level, not bit-level, vs the direct form).
+// A VALU read of a 16-pass MFMA result needs 19 wait states.  The compiler inserts them in front of its own
+// instructions but not in front of inline asm (mpx_max), so an accumulator passes through this point first.
+__device__ __forceinline__ void settle(f32x16 &acc) { asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc)); }
+
 template <int CF, int C1, int C2, int C3, int Q, bool FACT>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CF == 1 ? 4 : 2, CF == 1 ? 4 : 2)))
     sa_mlp_packed_kernel(const float *__restrict__ xyz, int stride, const float *__restrict__ new_xyz,
@@ -339,6 +343,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CF == 1
     if (lane >= o) pre += t;
   }
   const int total = __builtin_amdgcn_readlane(pre, Q - 1);
+  // environment of this wave's query `lane` (the 64-bit division happens once, here, not per tile)
+  const int my_env = (int)((q0 + (lane < Q ? lane : 0)) / npoint);
   pre -= my_rows;  // exclusive
   int s_pre[Q], s_cnt[Q];
 #pragma unroll
@@ -370,12 +376,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CF == 1
 
   const int qbase = (int)q0;  // query ids fit 31 bits (checked by the launcher)
   float run[Cfg::OT3];  // running max of the query being merged, per output tile (this lane's half of the rows)
-  int cur[Cfg::OT3];    // ... and which of this wave's queries that is (wave-uniform)
+  int cur = 0;          // ... and which of this wave's queries that is (wave-uniform; the same for every output tile
+                        // between two row tiles, so it advances once per row tile)
 #pragma unroll
-  for (int ot = 0; ot < Cfg::OT3; ++ot) {
-    run[ot] = -__builtin_inff();
-    cur[ot] = 0;
-  }
+  for (int ot = 0; ot < Cfg::OT3; ++ot) run[ot] = -__builtin_inff();
   auto flush = [&](int ot, int qi) __attribute__((always_inline)) {
     float v = run[ot];
     v = mpx_max_across_halves(v);
@@ -404,7 +408,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CF == 1
   float raw_dx, raw_dy, raw_dz, raw_f[NF];
   auto gather = [&](int qi, int k) __attribute__((always_inline)) {
     const int64_t qg = q0 + qi;
-    const int64_t b = qg / npoint;
+    const int64_t b = __shfl(my_env, qi);
     if constexpr (FACT) {  // this lane-half's 4-channel groups of the point's pre-activation row
       const float *pa = pre_rows + (b * N + k) * (int64_t)C1 + 4 * half;
 #pragma unroll
@@ -497,6 +501,19 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CF == 1
       }
     }
     const int q_tile = q_cur;  // which query this lane's row of the current tile belongs to
+    // ... per 4-row group, wave-uniform (non-decreasing).  Read once per tile when 8 output tiles share them; the
+    // narrow module (2 output tiles, 16 queries' offsets already in SGPRs) reads them where they are used.
+    constexpr bool HOIST = Cfg::OT3 > 2;
+    int gq_s[HOIST ? 8 : 1];
+    if constexpr (HOIST) {
+#pragma unroll
+      for (int grp = 0; grp < 8; ++grp) gq_s[grp] = __builtin_amdgcn_readlane(q_tile, 4 * grp);
+    }
+    auto gq = [&](int grp) __attribute__((always_inline)) {
+      if constexpr (HOIST) return gq_s[grp];
+      else return __builtin_amdgcn_readlane(q_tile, 4 * grp);
+    };
+    const int cur0 = cur;
     const int q_gather = q_next, k_gather = k_next;
     q_cur = q_next;
     if (rt + 64 < total) {
@@ -560,17 +577,25 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CF == 1
         }
         if (gg == GPT - 1) {
           float gm[4];
+          settle(a3);
 #pragma unroll
           for (int j = 0; j < 4; ++j)
-            gm[j] = fmaxf(fmaxf(a3[4 * j], a3[4 * j + 1]), fmaxf(a3[4 * j + 2], a3[4 * j + 3]));
+            gm[j] = mpx_max(mpx_max(a3[4 * j], a3[4 * j + 1]), mpx_max(a3[4 * j + 2], a3[4 * j + 3]));
+          if (gq(7) == cur0) {  // the whole tile belongs to the query being merged (the common case): no flush
+            run[ot] = fmaxf(run[ot], mpx_max(mpx_max(gm[0], gm[1]), mpx_max(gm[2], gm[3])));
+          } else {
+            int c = cur0;
 #pragma unroll
-          for (int grp = 0; grp < 8; ++grp) {
-            const int gq = __builtin_amdgcn_readlane(q_tile, 4 * grp);
-            if (gq != cur[ot]) {
-              flush(ot, cur[ot]);
-              cur[ot] = gq;
+            for (int grp = 0; grp < 8; ++grp) {
+              const int g_q = gq(grp);
+              if (g_q != c) {
+                flush(ot, c);
+                c = g_q;
+              }
+              // (a select, not a branch; fmaxf, not mpx_max: flush() reads run[] with v_permlane32_swap, and the
+              // compiler only inserts that instruction's wait states after VALU writes it can see)
+              run[ot] = fmaxf(run[ot], ((grp & 1) == half) ? gm[grp >> 1] : -__builtin_inff());
             }
-            if ((grp & 1) == half) run[ot] = fmaxf(run[ot], gm[grp >> 1]);
           }
         }
       }
@@ -583,9 +608,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CF == 1
       for (int u = 0; u < CH; ++u)
         if (c * CH + u < GT) step(c * CH + u, ring[c & 1][u]);
     }
+    cur = gq(7);
   }
 #pragma unroll
-  for (int ot = 0; ot < Cfg::OT3; ++ot) flush(ot, cur[ot]);
+  for (int ot = 0; ot < Cfg::OT3; ++ot) flush(ot, cur);
 }
 
 // ---- host entry points -----------------------------------------------------------------------------------

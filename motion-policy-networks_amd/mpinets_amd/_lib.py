@@ -14,7 +14,7 @@ from typing import Optional
 import torch  # noqa: F401  (must be imported first: it loads the HIP runtime the library binds to)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmpinets_hip.so")
+LIB_PATH = os.environ.get("MPX_LIB_PATH") or os.path.join(_HERE, "libmpinets_hip.so")  # (override: A/B builds)
 
 P, I, F, L = c_void_p, c_int, c_float, c_int64
 
