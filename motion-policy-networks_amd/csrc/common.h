@@ -71,17 +71,6 @@ __device__ __forceinline__ float mpx_max_across_halves(float v) {
   return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 
-// max(a, b) as ONE v_max_f32: fmaxf() first canonicalises an operand that comes straight out of the matrix pipe (an
-// extra v_max v, v, v per value).  Same result for non-NaN inputs.  The compiler does not treat inline asm as a VALU
-// write when it places hazard wait states, so the RESULT must only feed plain VALU instructions (hardware
-// interlocked) -- never an MFMA operand, v_readlane, v_permlane* or DPP (measured: a ReLU written this way in
-// front of the next layer's MFMAs read stale registers) -- and an MFMA result must pass a settle point first.
-__device__ __forceinline__ float mpx_max(float a, float b) {
-  float r;
-  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-
 // 3x4 rigid transform: r[9] row-major rotation, t[3]
 struct Rigid {
   float r[9];

@@ -290,10 +290,6 @@ __global__ void __launch_bounds__(256, 2)
 // once per QUERY (`ctr` [B*npoint, C1]); the kernel then starts at relu(pre[j] - ctr[i]) -- a gather, a
 // subtraction -- and skips the layer-1 MFMAs of every (query, neighbour) row (15 % of SA2's matrix work).
 // Same arithmetic up to the order of that one sum (tolerance-level, not bit-level, vs the direct form).
-// A VALU read of a 16-pass MFMA result needs 19 wait states.  The compiler inserts them in front of its own
-// instructions but not in front of inline asm (mpx_max), so an accumulator passes through this point first.
-__device__ __forceinline__ void settle(f32x16 &acc) { asm volatile("s_nop 15\n\ts_nop 3" : "+v"(acc)); }
-
 template <int CF, int C1, int C2, int C3, int Q, bool FACT>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CF == 1 ? 4 : 2, CF == 1 ? 4 : 2)))
     sa_mlp_packed_kernel(const float *__restrict__ xyz, int stride, const float *__restrict__ new_xyz,
@@ -577,12 +573,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CF == 1
         }
         if (gg == GPT - 1) {
           float gm[4];
-          settle(a3);
 #pragma unroll
           for (int j = 0; j < 4; ++j)
-            gm[j] = mpx_max(mpx_max(a3[4 * j], a3[4 * j + 1]), mpx_max(a3[4 * j + 2], a3[4 * j + 3]));
+            gm[j] = fmaxf(fmaxf(a3[4 * j], a3[4 * j + 1]), fmaxf(a3[4 * j + 2], a3[4 * j + 3]));
           if (gq(7) == cur0) {  // the whole tile belongs to the query being merged (the common case): no flush
-            run[ot] = fmaxf(run[ot], mpx_max(mpx_max(gm[0], gm[1]), mpx_max(gm[2], gm[3])));
+            run[ot] = fmaxf(run[ot], fmaxf(fmaxf(gm[0], gm[1]), fmaxf(gm[2], gm[3])));
           } else {
             int c = cur0;
 #pragma unroll
@@ -592,8 +587,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CF == 1
                 flush(ot, c);
                 c = g_q;
               }
-              // (a select, not a branch; fmaxf, not mpx_max: flush() reads run[] with v_permlane32_swap, and the
-              // compiler only inserts that instruction's wait states after VALU writes it can see)
+              // (a select, not a branch)
               run[ot] = fmaxf(run[ot], ((grp & 1) == half) ? gm[grp >> 1] : -__builtin_inff());
             }
           }
