@@ -105,9 +105,9 @@ __global__ void __launch_bounds__(256)
     if (kb + 1 < nk) gload((kb + 1) * BK);
     float4 a[2][HK / 4], b[2][HK / 4];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int v = 0; v < HK / 4; ++v)
 #pragma unroll
-      for (int v = 0; v < HK / 4; ++v) {
+      for (int t = 0; t < 2; ++t) {
         a[t][v] = *reinterpret_cast<const float4 *>(&As[buf][(wm * 64 + t * 32 + l31) * LDT + HK * half + 4 * v]);
         b[t][v] = *reinterpret_cast<const float4 *>(&Bs[buf][(wn * 64 + t * 32 + l31) * LDT + HK * half + 4 * v]);
       }
@@ -123,6 +123,16 @@ __global__ void __launch_bounds__(256)
             const float bv = u == 0 ? b[j][v].x : (u == 1 ? b[j][v].y : (u == 2 ? b[j][v].z : b[j][v].w));
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
           }
+    // Issue order of the slab.  Left alone the scheduler clusters the eight fragment reads and the first MFMA waits
+    // for the last of them; this pipeline starts the matrix pipe after the first half of the reads and feeds the
+    // rest in between MFMAs (measured at the model's shapes, 8192 envs: 20.3 -> 19.4 ms per step of dense layers;
+    // 1, 3 or 4 MFMAs per read instead of 2: the same within 1 %; reads pinned after the 4th MFMA: 19.9 ms).
+    __builtin_amdgcn_sched_group_barrier(0x100, NLD * 2, 0);  // DS reads
+#pragma unroll
+    for (int i = 0; i < NLD * 2; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);  // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // one more DS read
+    }
     if (kb + 1 < nk) sstore(buf ^ 1);
     __syncthreads();
   }
