@@ -106,7 +106,7 @@ def stage_table(prof, steps, B, sa1_ms, sa1_exec, sa2_ms, sa2_exec):
         "sa1_grouped_mlp": mf(sa1_exec, sa1_ms), "sa2_grouped_mlp": mf(sa2_exec, sa2_ms),
         "dense_layers": dict(mf(lin_flops, lin_ms), note="SA2 layer 1 (factored) + group-all module + heads"),
         "scene_cloud_rerender": dict(hbm(B * 4096 * 12.0, ms("mpx_scene_cloud")),
-                                     note="49,152 B written per env; the per-env urn (one lane) is the long pole, not HBM"),
+                                     note="49,152 B written per env; selection (Philox keys + radix select + counting sort in LDS, one workgroup per env) is the long pole, not HBM"),
         "groupnorm_leaky": {"bound": "hbm", "ms": ms("mpx_groupnorm_leaky")},
         "joint_step": {"bound": "latency", "ms": ms("mpx_joint_step")},
     }

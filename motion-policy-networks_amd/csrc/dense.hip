@@ -16,8 +16,6 @@
 // an fmaf chain in this k order): bound by the 157 TFLOP/s fp32 MFMA pipe.
 #include "common.h"
 
-#include <stdlib.h>
-
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BM = 128, BN = 128;
@@ -286,13 +284,9 @@ MPX_EXPORT int mpx_linear(const float *x, int ldx, const float *w, const float *
     MPX_LAUNCH_CHECK("mpx_linear");
   }
   MPX_REQUIRE(cdiv(M, BM) <= 65535, "mpx_linear: M too large");
-  static const int bk = getenv("MPX_GEMM_BK") ? atoi(getenv("MPX_GEMM_BK")) : 16;  // tuning override
-  if (bk == 32 && K >= 64)
-    hipLaunchKernelGGL((linear_kernel<32, false>), dim3(cdiv(N, BN), cdiv(M, BM)), dim3(256), 0, mpx_s(stream), x, ldx,
-                       w, K, bias, M, N, K, act, y, ldy, K, (size_t)0);
-  else
-    hipLaunchKernelGGL((linear_kernel<16, false>), dim3(cdiv(N, BN), cdiv(M, BM)), dim3(256), 0, mpx_s(stream), x, ldx,
-                       w, K, bias, M, N, K, act, y, ldy, K, (size_t)0);
+  // (BK = 32 slabs were measured: no gain, twice the LDS)
+  hipLaunchKernelGGL((linear_kernel<16, false>), dim3(cdiv(N, BN), cdiv(M, BM)), dim3(256), 0, mpx_s(stream), x, ldx,
+                     w, K, bias, M, N, K, act, y, ldy, K, (size_t)0);
   MPX_LAUNCH_CHECK("mpx_linear");
 }
 
@@ -369,13 +363,8 @@ MPX_EXPORT int mpx_linear_rowmax(const float *x, int ldx, const float *w, const 
   hipError_t e = hipMemset2DAsync(y, (size_t)ldy * sizeof(float), 0, (size_t)N * sizeof(float), (size_t)(M / BM),
                                   mpx_s(stream));
   MPX_REQUIRE(e == hipSuccess, "mpx_linear_rowmax: memset failed: %s", hipGetErrorString(e));
-  static const int bk = getenv("MPX_GEMM_BK") ? atoi(getenv("MPX_GEMM_BK")) : 16;
-  if (bk == 32 && K >= 64)
-    hipLaunchKernelGGL((linear_kernel<32, true>), dim3(cdiv(N, BN), M / BM), dim3(256), 0, mpx_s(stream), x, ldx, w,
-                       K, bias, M, N, K, MPX_ACT_RELU, y, ldy, K, (size_t)0);
-  else
-    hipLaunchKernelGGL((linear_kernel<16, true>), dim3(cdiv(N, BN), M / BM), dim3(256), 0, mpx_s(stream), x, ldx, w,
-                       K, bias, M, N, K, MPX_ACT_RELU, y, ldy, K, (size_t)0);
+  hipLaunchKernelGGL((linear_kernel<16, true>), dim3(cdiv(N, BN), M / BM), dim3(256), 0, mpx_s(stream), x, ldx, w,
+                     K, bias, M, N, K, MPX_ACT_RELU, y, ldy, K, (size_t)0);
   MPX_LAUNCH_CHECK("mpx_linear_rowmax");
 }
 

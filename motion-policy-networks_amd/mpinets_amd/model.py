@@ -284,10 +284,10 @@ class MotionPolicyNetwork(nn.Module):
         return next(self.parameters()).device
 
     def set_precision(self, precision: str) -> "MotionPolicyNetwork":
-        """Arithmetic of the two grouped MLPs (96 % of the FLOPs): ``"fp32"`` = exact fp32 MFMA (default,
-        the parity path) or ``"bf16x3"`` = split-bf16 on the bf16 matrix cores (each product as
-        hi*hi + hi*lo + lo*hi, fp32 accumulate; policy output within ~3e-7 of fp32).  Everything else
-        (FPS, ball query, dense layers, FK, SDF) is fp32 in both modes."""
+        """Arithmetic of the matrix work (the two grouped MLPs and the large dense layers): ``"fp32"`` = exact
+        fp32 MFMA (default, the parity path) or ``"bf16x3"`` = split-bf16 on the bf16 matrix cores (each product
+        as hi*hi + hi*lo + lo*hi, fp32 accumulate; policy output within ~3e-7 of fp32).  Everything else (FPS,
+        ball query, GroupNorm, the small joint-encoder / decoder layers, FK, SDF) is fp32 in both modes."""
         assert precision in PRECISIONS, precision
         for sa in self.point_cloud_encoder.SA_modules:
             sa.precision = precision
