@@ -15,14 +15,14 @@ from __future__ import annotations
 
 import os
 
-from typing import Callable, Dict, List, Optional, Sequence
+from typing import Callable, Dict, List, Optional
 
 import torch
 from torch import nn
 
 from . import _lib
-from .pointnet2 import (FACTORED_SHAPE, PRECISIONS, groupnorm_leaky_train, linear_train, PointnetSAModule, SAWeights, SplitWeights, groupnorm_leaky, launch_sa,
-                        linear, linear_x3, sa_mlp_factored, sa_mlp_fused)
+from .pointnet2 import (FACTORED_SHAPE, PRECISIONS, PointnetSAModule, SplitWeights, groupnorm_leaky, groupnorm_leaky_train,
+                        launch_sa, linear, linear_train, linear_x3, sa_mlp_factored)
 from .utils import unnormalize_franka_joints
 
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2

@@ -9,7 +9,7 @@ sync every step (run_inference.py:171-189), which this engine does not need.
 """
 from __future__ import annotations
 
-from typing import Dict, List, Optional
+from typing import Dict, Optional
 
 import numpy as np
 import torch

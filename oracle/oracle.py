@@ -17,7 +17,7 @@ from __future__ import annotations
 import ctypes
 import os
 import subprocess
-from typing import Dict, List, Optional, Sequence, Tuple
+from typing import Dict, Optional, Sequence, Tuple
 
 import numpy as np
 

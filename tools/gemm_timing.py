@@ -3,7 +3,6 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "motion-policy-networks_amd")]
 import torch
-from mpinets_amd import _lib
 from mpinets_amd.pointnet2 import linear
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 dev = torch.device("cuda:0")

@@ -5,7 +5,6 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "motion-policy-networks_amd")]
-import numpy as np
 import torch
 
 from mpinets_amd.model import TrainingMotionPolicyNetwork
