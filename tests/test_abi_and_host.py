@@ -70,6 +70,34 @@ def test_library_loads_and_reports_errors_without_gpu():
     assert b"8192" in lib.mpx_last_error()
 
 
+def test_header_is_plain_c_and_a_c_client_links(tmp_path):
+    """The boundary is a C ABI: include/mpinets_hip.h compiles as C99 (no C++, no torch types) and a C program
+    linked against the library can call it -- here the calls that need no GPU (version, argument checking)."""
+    import shutil
+    import subprocess
+
+    from mpinets_amd import _lib
+
+    if shutil.which("gcc") is None or not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("needs gcc and the built library")
+    src = tmp_path / "client.c"
+    src.write_text(
+        '#include <stdio.h>\n#include <string.h>\n#include "mpinets_hip.h"\n'
+        "int main(void) {\n"
+        "  if (mpx_version() <= 0) return 1;\n"
+        "  /* K = 6 is not a multiple of 4: refused before any launch, with a message */\n"
+        "  if (mpx_linear(NULL, 8, NULL, NULL, 4, 4, 6, MPX_ACT_NONE, NULL, 4, NULL) == 0) return 2;\n"
+        '  if (strstr(mpx_last_error(), "mpx_linear") == NULL) return 3;\n'
+        "  if (mpx_linear_workspace(1, 2048, 4096) != 0 || mpx_linear_workspace(256, 2048, 4096) <= 0) return 4;\n"
+        '  printf("ok %d\\n", mpx_version());\n  return 0;\n}\n')
+    exe = tmp_path / "client"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src),
+                           "-o", str(exe), "-L", libdir, "-lmpinets_hip", "-Wl,-rpath," + libdir])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.startswith("ok"), (out.returncode, out.stdout, out.stderr)
+
+
 def test_cpu_tensors_are_rejected_not_silently_computed():
     from mpinets_amd import _lib
     from mpinets_amd.model import MotionPolicyNetwork
