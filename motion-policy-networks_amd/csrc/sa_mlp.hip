@@ -402,11 +402,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CF == 1
   // array inside a struct that is passed around by reference is not promoted to registers)
   constexpr int NF = FACT ? C1 / 2 : (CF == 1 ? 1 : CF / 2);
   float raw_dx, raw_dy, raw_dz, raw_f[NF];
-  // FACT: raw_f holds the layer-1 activations themselves (channel 32*(t>>4) + 8*((t&15)>>2) + 4*half + (t&3) at
-  // index t -- the order layer 2 walks).  The gather of the NEXT tile's pre-activation rows lands in these registers
-  // once layer 2 has consumed them, and `form` turns them into relu(pre - ctr) in place, a 4-channel group at a
-  // time, in the shadow of layer 3's MFMAs: a tile then starts on the matrix pipe with no preamble.
-  f32x16 a1[FACT ? 1 : Cfg::OT1];  // (direct form: layer-1 accumulators)
   auto gather = [&](int qi, int k) __attribute__((always_inline)) {
     const int64_t qg = q0 + qi;
     const int64_t b = __shfl(my_env, qi);
@@ -443,24 +438,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CF == 1
     }
   };
 
-  auto form = [&](int i, int qi) __attribute__((always_inline)) {  // FACT: group i of the row of query qi
-    const float4 c = *reinterpret_cast<const float4 *>(ctr_s + qi * C1 + 4 * half + 8 * i);
-    raw_f[4 * i + 0] = fmaxf(raw_f[4 * i + 0] - c.x, 0.0f);
-    raw_f[4 * i + 1] = fmaxf(raw_f[4 * i + 1] - c.y, 0.0f);
-    raw_f[4 * i + 2] = fmaxf(raw_f[4 * i + 2] - c.z, 0.0f);
-    raw_f[4 * i + 3] = fmaxf(raw_f[4 * i + 3] - c.w, 0.0f);
-  };
-
   // gather pipeline: the neighbour index of the next tile is fetched at tile start, its data during layer 3
   int q_cur, q_next = 0, k_next = 0;
   {
     int off;
     map_row(col, q_cur, off);
     gather(q_cur, idx[(q0 + q_cur) * nsample + off]);
-    if constexpr (FACT) {
-#pragma unroll
-      for (int i = 0; i < C1 / 8; ++i) form(i, q_cur);
-    }
     if (total > 32) {
       map_row(32 + col, q_next, off);
       k_next = idx[(q0 + q_next) * nsample + off];
@@ -491,8 +474,18 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CF == 1
     asm volatile("" : "+s"(wb));
 
     float x0[Cfg::KS0];
+    f32x16 a1[Cfg::OT1];
     if constexpr (FACT) {
-      // (a1 was formed during the previous tile's layer 3 -- or in the prologue)
+      // register r of tile ot = channel 32*ot + 8*(r>>2) + 4*half + (r&3) = group i = 4*ot + (r>>2) of raw_f
+      const float *cq = ctr_s + q_cur * C1 + 4 * half;
+#pragma unroll
+      for (int i = 0; i < C1 / 8; ++i) {
+        const float4 c = *reinterpret_cast<const float4 *>(cq + 8 * i);
+        a1[i >> 2][4 * (i & 3) + 0] = fmaxf(raw_f[4 * i + 0] - c.x, 0.0f);
+        a1[i >> 2][4 * (i & 3) + 1] = fmaxf(raw_f[4 * i + 1] - c.y, 0.0f);
+        a1[i >> 2][4 * (i & 3) + 2] = fmaxf(raw_f[4 * i + 2] - c.z, 0.0f);
+        a1[i >> 2][4 * (i & 3) + 3] = fmaxf(raw_f[4 * i + 3] - c.w, 0.0f);
+      }
     } else {
       x0[0] = half ? raw_dy : raw_dx;
       if (CF == 1) {
@@ -555,7 +548,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CF == 1
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int s = 4 * gg + u, t = s / Cfg::OT2, ot = s % Cfg::OT2;
-          a2[ot] = mfma32(comp(w, u), FACT ? raw_f[FACT ? t : 0] : a1[FACT ? 0 : t >> 4][t & 15], a2[ot]);
+          a2[ot] = mfma32(comp(w, u), a1[t >> 4][t & 15], a2[ot]);
         }
         if (gg == G2 - 1) {
 #pragma unroll
@@ -577,15 +570,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CF == 1
         for (int u = 0; u < 4; ++u) {
           const int t = 4 * gg + u;
           a3 = mfma32(a2[t >> 4][t & 15], comp(w, u), a3);
-        }
-        if constexpr (FACT) {
-          // next tile's layer-1 activations, one group per weight group of the second output tile (the gather was
-          // issued a full output tile earlier; without a next tile this touches dead registers)
-          if (g3 >= GPT && g3 < GPT + C1 / 8) {
-            __builtin_amdgcn_sched_barrier(0);  // (keeps the 16 LDS reads from being hoisted together: 64 VGPRs)
-            form(g3 - GPT, q_gather);
-            __builtin_amdgcn_sched_barrier(0);
-          }
         }
         if (gg == GPT - 1) {
           float gm[4];
