@@ -369,6 +369,37 @@ int mpx_groupnorm_leaky(const float *x, const float *gamma, const float *beta, i
 int mpx_rowmax(const float *x, int ldx, int G, int rows, int C, float *y, int ldy,
                mpx_stream_t stream);
 
+/* ---- the whole policy forward in one call: MotionPolicyNetwork.forward, model.py:75-91 ------------------------
+ * For callers without Python (a native planning node): slab + joint configuration in, displacement out.  Host-side
+ * orchestration of the kernels above in the order and shapes of mpinets_amd/model.py, whose fp32 output it
+ * reproduces bit for bit; the caller's stream (for B <= 512 also an internal second stream, forked and joined with
+ * events -- hipGraph-capturable), no allocation, no synchronisation.
+ *
+ * Weights: device pointers, fp32, [out, in] row-major like nn.Linear / 1x1 Conv2d, prepared once:
+ *   sa1_pack, sa2_pack   mpx_sa_pack_weights of SA_modules.{0,1} (C = 1 and 64)
+ *   sa2_wpoint [128,68]  SA2's first layer over rows [f1 (64) | xyz (3) | 0]   (W1[:,3:] | W1[:,:3] | 0)
+ *   sa2_wcentre [128,4]  ... over rows [xyz (3) | *]                             (W1[:,:3] | 0)
+ *   sa2_nb1 [128]        minus its bias
+ *   sa3_w[0] [512,260]   group-all first layer, K padded 259 -> 260 with a zero column; sa3_w[1] [512,512];
+ *                        sa3_w[2] [1024,512]; sa3_b[i] the biases
+ *   fc_w / fc_b          1024 -> 4096 -> 2048 -> 2048; gn_g / gn_b: the two GroupNorm(16) affine vectors
+ *   qe_w[0] [32,8]       joint encoder, first layer K padded 7 -> 8; then 32 -> 64 -> 128 -> 128 -> 64
+ *   de_w / de_b          decoder 2112 -> 512 -> 256 -> 128 -> 7                                                  */
+typedef struct mpx_policy_weights {
+  const float *sa1_pack, *sa2_pack, *sa2_wpoint, *sa2_wcentre, *sa2_nb1;
+  const float *sa3_w[3], *sa3_b[3];
+  const float *fc_w[3], *fc_b[3], *gn_g[2], *gn_b[2];
+  const float *qe_w[5], *qe_b[5];
+  const float *de_w[4], *de_b[4];
+} mpx_policy_weights;
+
+/* bytes of 256-byte aligned device workspace a batch of B problems with N-point slabs needs */
+int64_t mpx_policy_workspace(int B, int N);
+/* xyz [B,N,4] (x, y, z, label; N in [512, 8192]), q [B,7] normalised to [-1,1] -> dq [B,7] (normalised space).
+ * B <= 65535.                                                                                                    */
+int mpx_policy_forward(const mpx_policy_weights *w, const float *xyz, int N, const float *q, int B,
+                       float *dq, void *workspace, int64_t workspace_bytes, mpx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,225 @@
+// policy.hip -- the whole policy forward behind ONE C-ABI call (MotionPolicyNetwork.forward, model.py:75-91):
+// a C / C++ caller (a native planning node) hands over the slab, the joint configuration and a workspace and gets
+// the displacement back.  Host-side orchestration only: every stage is one of this library's kernels, launched in
+// the order and with the shapes of mpinets_amd/model.py (whose output it reproduces bit for bit), on the caller's
+// stream (plus an internal second one for small batches), with no allocation and no synchronisation.
+//
+// Reference: MPiNetsPointNet (model.py:360-426: SA(512, r 0.05, 128, [1,64,64,64]) -> SA(128, r 0.3, 128,
+// [64,128,128,256]) -> group-all [256,512,512,1024] -> 1024-4096-GN-2048-GN-2048), feature_encoder
+// (model.py:47-57), decoder (model.py:58-66).
+#include "common.h"
+
+#include <mutex>
+
+namespace {
+
+constexpr int NP1 = 512, NP2 = 128, NS = 128;     // samples per module, neighbours per ball
+constexpr float R1 = 0.05f, R2 = 0.3f;            // ball radii (model.py:366-381)
+constexpr int C1 = 64, F1 = C1 + 4;               // SA1 output channels; its row [f1 | xyz1 | 0]
+constexpr int C2 = 256, K3 = 3 + C2 + 1;          // SA2 output channels; group-all input row [xyz2 | f2 | 0]
+constexpr int H3 = 512, C3 = 1024;                // group-all hidden / output width
+constexpr int ENC = 2048, QF = 64, CAT = ENC + QF;
+
+// xyz1 -> columns [C1, C1+3) of the SA1 rows, 0 -> column C1+3 (the operand of SA2's per-point first layer)
+__global__ void __launch_bounds__(256) tail_columns_kernel(const float *__restrict__ xyz1, int64_t n, float *__restrict__ rows) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float *r = rows + i * F1 + C1;
+  r[0] = xyz1[3 * i + 0];
+  r[1] = xyz1[3 * i + 1];
+  r[2] = xyz1[3 * i + 2];
+  r[3] = 0.0f;
+}
+
+// q [B,7] -> [B,8] (K of the first joint-encoder layer padded to a multiple of 4)
+__global__ void __launch_bounds__(256) pad_q_kernel(const float *__restrict__ q, int B, float *__restrict__ q8) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= B * 8) return;
+  const int b = i >> 3, j = i & 7;
+  q8[i] = j < 7 ? q[b * 7 + j] : 0.0f;
+}
+
+struct Carver {  // hands out 256-byte aligned pieces of the workspace (or only counts, when base == nullptr)
+  char *base;
+  int64_t used = 0;
+  template <class T>
+  T *take(int64_t n) {
+    T *p = base ? reinterpret_cast<T *>(base + used) : nullptr;
+    used += (n * (int64_t)sizeof(T) + 255) / 256 * 256;
+    return p;
+  }
+};
+
+struct Buffers {
+  int32_t *idx1, *nbr1, *cnt1, *idx2, *nbr2, *cnt2;
+  float *xyz1, *f1, *sa3_in, *pre, *ctr, *h_a, *h_b, *pooled, *fc_a, *fc_b, *cat, *q8, *s_a, *s_b, *q_a, *q_b;
+  void *splitk;
+  int64_t splitk_bytes;
+};
+
+int64_t max_i64(int64_t a, int64_t b) { return a > b ? a : b; }
+
+int64_t carve(char *base, int B, int N, Buffers &bu) {
+  Carver c{base};
+  const int64_t b = B;
+  bu.idx1 = c.take<int32_t>(b * NP1);
+  bu.xyz1 = c.take<float>(b * NP1 * 3);
+  bu.nbr1 = c.take<int32_t>(b * NP1 * NS);
+  bu.cnt1 = c.take<int32_t>(b * NP1);
+  bu.f1 = c.take<float>(b * NP1 * F1);
+  bu.sa3_in = c.take<float>(b * NP2 * K3);
+  bu.idx2 = c.take<int32_t>(b * NP2);
+  bu.nbr2 = c.take<int32_t>(b * NP2 * NS);
+  bu.cnt2 = c.take<int32_t>(b * NP2);
+  bu.pre = c.take<float>(b * NP1 * 128);
+  bu.ctr = c.take<float>(b * NP2 * 128);
+  bu.h_a = c.take<float>(b * NP2 * (B <= 8 ? C3 : H3));  // (a handful of problems: also the unpooled last layer)
+  bu.h_b = c.take<float>(b * NP2 * H3);
+  bu.pooled = c.take<float>(b * C3);
+  bu.fc_a = c.take<float>(b * 4096);
+  bu.fc_b = c.take<float>(b * 2048);
+  bu.cat = c.take<float>(b * CAT);
+  bu.q8 = c.take<float>(b * 8);
+  bu.s_a = c.take<float>(b * 512);
+  bu.s_b = c.take<float>(b * 512);
+  bu.q_a = c.take<float>(b * 128);  // (the joint encoder may run beside the point-cloud chain: its own buffers)
+  bu.q_b = c.take<float>(b * 128);
+  // one split-K area, sized for the hungriest layer of this batch size
+  const int shapes[][3] = {{B * NP2, H3, K3}, {B * NP2, H3, H3}, {B * NP2, C3, H3}, {B, 4096, C3}, {B, 2048, 4096},
+                           {B, 2048, 2048}, {B, 512, CAT}, {B, 256, 512}, {B, 128, 256}};
+  int64_t need = 0;
+  for (const auto &s : shapes) need = max_i64(need, mpx_linear_workspace(s[0], s[1], s[2]));
+  bu.splitk_bytes = need;
+  bu.splitk = need ? c.take<char>(need) : nullptr;
+  (void)N;
+  return c.used;
+}
+
+// Small batches cannot fill the chip with any single kernel (FPS is one workgroup per problem), so two independent
+// branches -- SA2's sampling + ball query and the joint-angle encoder -- are issued on a second stream beside SA1's
+// ball query + grouped MLP, forked and joined with events (the same split as model.py's; a fork / join like this is
+// hipGraph-capturable).  One stream + two events per device, created on first use.
+constexpr int OVERLAP_MAX_BATCH = 512;
+struct Side {
+  hipStream_t stream = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+};
+Side *side_of_current_device() {
+  static std::mutex mu;
+  static Side per_device[64];
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  Side &s = per_device[d];
+  if (!s.stream) {
+    hipStream_t st;
+    hipEvent_t f, j;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&f, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&j, hipEventDisableTiming) != hipSuccess)
+      return nullptr;
+    s.stream = st, s.fork = f, s.join = j;
+  }
+  return &s;
+}
+
+}  // namespace
+
+#define MPX_TRY(call)     \
+  do {                    \
+    const int rc_ = (call); \
+    if (rc_ != 0) return rc_; \
+  } while (0)
+
+MPX_EXPORT int64_t mpx_policy_workspace(int B, int N) {
+  if (B <= 0 || N <= 0) return 0;
+  Buffers bu;
+  return carve(nullptr, B, N, bu);
+}
+
+MPX_EXPORT int mpx_policy_forward(const mpx_policy_weights *w, const float *xyz, int N, const float *q, int B, float *dq,
+                                  void *workspace, int64_t workspace_bytes, mpx_stream_t stream) {
+  MPX_REQUIRE(w && xyz && q && dq, "mpx_policy_forward: NULL operand");
+  MPX_REQUIRE(B >= 0 && B <= 65535, "mpx_policy_forward: B = %d outside [0, 65535] (slab the batch)", B);
+  MPX_REQUIRE(N >= NP1 && N <= 8192, "mpx_policy_forward: N = %d outside [%d, 8192]", N, NP1);
+  if (B == 0) return 0;
+  MPX_REQUIRE(workspace && (((uintptr_t)workspace) & 255) == 0, "mpx_policy_forward: workspace must be 256-byte aligned");
+  Buffers bu;
+  const int64_t need = carve(static_cast<char *>(workspace), B, N, bu);
+  MPX_REQUIRE(workspace_bytes >= need, "mpx_policy_forward: workspace of %lld bytes, mpx_policy_workspace asks for %lld",
+              (long long)workspace_bytes, (long long)need);
+  hipStream_t st = mpx_s(stream);
+  auto lin = [&](const float *x, int ldx, const float *wt, const float *b, int M, int Nn, int K, int act, float *y, int ldy) {
+    return mpx_linear_ws(x, ldx, wt, b, M, Nn, K, act, y, ldy, bu.splitk, bu.splitk_bytes, stream);
+  };
+
+  // the two branches that need only xyz1 / q (second stream for small batches, in line otherwise)
+  auto sample_sa2_and_encode_q = [&](mpx_stream_t s2) -> int {
+    hipError_t e = hipMemsetAsync(bu.sa3_in, 0, (size_t)B * NP2 * K3 * sizeof(float), mpx_s(s2));
+    MPX_REQUIRE(e == hipSuccess, "mpx_policy_forward: memset failed: %s", hipGetErrorString(e));
+    MPX_TRY(mpx_fps(bu.xyz1, B, NP1, 3, NP2, bu.idx2, bu.sa3_in, K3, s2));
+    MPX_TRY(mpx_ball_query(bu.sa3_in, K3, bu.xyz1, 3, B, NP1, NP2, R2, NS, bu.nbr2, bu.cnt2, s2));
+    // joint encoder 7 -> 32 -> 64 -> 128 -> 128 -> 64, into the right part of the decoder's input rows
+    // (no layer here has K >= 256: none of them touches the split-K area the other stream may be using)
+    hipLaunchKernelGGL(pad_q_kernel, dim3(cdiv((int64_t)B * 8, 256)), dim3(256), 0, mpx_s(s2), q, B, bu.q8);
+    MPX_TRY(mpx_linear(bu.q8, 8, w->qe_w[0], w->qe_b[0], B, 32, 8, MPX_ACT_LEAKY, bu.q_a, 32, s2));
+    MPX_TRY(mpx_linear(bu.q_a, 32, w->qe_w[1], w->qe_b[1], B, 64, 32, MPX_ACT_LEAKY, bu.q_b, 64, s2));
+    MPX_TRY(mpx_linear(bu.q_b, 64, w->qe_w[2], w->qe_b[2], B, 128, 64, MPX_ACT_LEAKY, bu.q_a, 128, s2));
+    MPX_TRY(mpx_linear(bu.q_a, 128, w->qe_w[3], w->qe_b[3], B, 128, 128, MPX_ACT_LEAKY, bu.q_b, 128, s2));
+    MPX_TRY(mpx_linear(bu.q_b, 128, w->qe_w[4], w->qe_b[4], B, QF, 128, MPX_ACT_NONE, bu.cat + ENC, CAT, s2));
+    return 0;
+  };
+  auto module_sa1 = [&]() -> int {  // neighbours within 5 cm, grouped MLP over [p - c ; label] rows
+    MPX_TRY(mpx_ball_query(bu.xyz1, 3, xyz, 4, B, N, NP1, R1, NS, bu.nbr1, bu.cnt1, stream));
+    MPX_TRY(mpx_sa_mlp(xyz, 4, bu.xyz1, 3, xyz + 3, 4, 1, bu.nbr1, bu.cnt1, B, N, NP1, NS, w->sa1_pack, 64, 64, C1, bu.f1,
+                       F1, stream));
+    return 0;
+  };
+
+  // ---- SA1 (sample 512) and, beside it, SA2's sampling (128 of the 512, neighbours within 30 cm) ---------------
+  MPX_TRY(mpx_fps(xyz, B, N, 4, NP1, bu.idx1, bu.xyz1, 3, stream));
+  Side *side = B <= OVERLAP_MAX_BATCH ? side_of_current_device() : nullptr;
+  if (side) {
+    hipError_t e = hipEventRecord(side->fork, st);
+    if (e == hipSuccess) e = hipStreamWaitEvent(side->stream, side->fork, 0);
+    MPX_REQUIRE(e == hipSuccess, "mpx_policy_forward: stream fork failed: %s", hipGetErrorString(e));
+    const int rc_side = sample_sa2_and_encode_q(reinterpret_cast<mpx_stream_t>(side->stream));
+    const int rc_main = rc_side == 0 ? module_sa1() : 0;
+    e = hipEventRecord(side->join, side->stream);  // (always joined, also on an error path)
+    if (e == hipSuccess) e = hipStreamWaitEvent(st, side->join, 0);
+    if (rc_side != 0) return rc_side;
+    if (rc_main != 0) return rc_main;
+    MPX_REQUIRE(e == hipSuccess, "mpx_policy_forward: stream join failed: %s", hipGetErrorString(e));
+  } else {
+    MPX_TRY(module_sa1());
+    MPX_TRY(sample_sa2_and_encode_q(stream));
+  }
+  // ---- SA2: first layer per point / per query, layers 2-3 + max-pool fused ------------------------------------
+  hipLaunchKernelGGL(tail_columns_kernel, dim3(cdiv((int64_t)B * NP1, 256)), dim3(256), 0, st, bu.xyz1, (int64_t)B * NP1,
+                     bu.f1);
+  MPX_TRY(lin(bu.f1, F1, w->sa2_wpoint, nullptr, B * NP1, 128, F1, MPX_ACT_NONE, bu.pre, 128));
+  MPX_TRY(lin(bu.sa3_in, K3, w->sa2_wcentre, w->sa2_nb1, B * NP2, 128, 4, MPX_ACT_NONE, bu.ctr, 128));
+  MPX_TRY(mpx_sa_mlp_factored(bu.pre, bu.ctr, bu.nbr2, bu.cnt2, B, NP1, NP2, NS, w->sa2_pack, C1, 128, 128, C2,
+                              bu.sa3_in + 3, K3, stream));
+  // ---- group-all module: three dense layers over the B*128 rows, max over each environment's rows --------------
+  MPX_TRY(lin(bu.sa3_in, K3, w->sa3_w[0], w->sa3_b[0], B * NP2, H3, K3, MPX_ACT_RELU, bu.h_a, H3));
+  MPX_TRY(lin(bu.h_a, H3, w->sa3_w[1], w->sa3_b[1], B * NP2, H3, H3, MPX_ACT_RELU, bu.h_b, H3));
+  if (B > 8) {
+    MPX_TRY(mpx_linear_rowmax(bu.h_b, H3, w->sa3_w[2], w->sa3_b[2], B * NP2, C3, H3, NP2, bu.pooled, C3, stream));
+  } else {  // a handful of problems: split-K layer + row-max (see model.py)
+    MPX_TRY(lin(bu.h_b, H3, w->sa3_w[2], w->sa3_b[2], B * NP2, C3, H3, MPX_ACT_RELU, bu.h_a, C3));
+    MPX_TRY(mpx_rowmax(bu.h_a, C3, B, NP2, C3, bu.pooled, C3, stream));
+  }
+  // ---- fc head: 1024 -> 4096 -> GN -> 2048 -> GN -> 2048 (into the left part of the decoder's input rows) ------
+  MPX_TRY(lin(bu.pooled, C3, w->fc_w[0], w->fc_b[0], B, 4096, C3, MPX_ACT_NONE, bu.fc_a, 4096));
+  MPX_TRY(mpx_groupnorm_leaky(bu.fc_a, w->gn_g[0], w->gn_b[0], B, 4096, 16, 1e-5f, bu.fc_a, stream));
+  MPX_TRY(lin(bu.fc_a, 4096, w->fc_w[1], w->fc_b[1], B, 2048, 4096, MPX_ACT_NONE, bu.fc_b, 2048));
+  MPX_TRY(mpx_groupnorm_leaky(bu.fc_b, w->gn_g[1], w->gn_b[1], B, 2048, 16, 1e-5f, bu.fc_b, stream));
+  MPX_TRY(lin(bu.fc_b, 2048, w->fc_w[2], w->fc_b[2], B, ENC, 2048, MPX_ACT_NONE, bu.cat, CAT));
+  // ---- decoder 2112 -> 512 -> 256 -> 128 -> 7 ------------------------------------------------------------------
+  MPX_TRY(lin(bu.cat, CAT, w->de_w[0], w->de_b[0], B, 512, CAT, MPX_ACT_LEAKY, bu.s_a, 512));
+  MPX_TRY(lin(bu.s_a, 512, w->de_w[1], w->de_b[1], B, 256, 512, MPX_ACT_LEAKY, bu.s_b, 256));
+  MPX_TRY(lin(bu.s_b, 256, w->de_w[2], w->de_b[2], B, 128, 256, MPX_ACT_LEAKY, bu.s_a, 128));
+  MPX_TRY(lin(bu.s_a, 128, w->de_w[3], w->de_b[3], B, 7, 128, MPX_ACT_NONE, dq, 7));
+  MPX_LAUNCH_CHECK("mpx_policy_forward");
+}

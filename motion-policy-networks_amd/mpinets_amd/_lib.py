@@ -71,9 +71,11 @@ PROTOTYPES = {
     "mpx_linear_wgrad": [P, I, P, I, I, I, I, P, P, P, P],
     "mpx_groupnorm_leaky": [P, P, P, I, I, I, F, P, P],
     "mpx_rowmax": [P, I, I, I, I, P, I, P],
+    "mpx_policy_workspace": [I, I],
+    "mpx_policy_forward": [P, P, I, P, I, P, P, L, P],
 }
 RESTYPES = {"mpx_last_error": c_char_p, "mpx_sa_pack_size": c_int64, "mpx_sa_pack_bf16x3_size": c_int64,
-            "mpx_linear_wgrad_scratch": c_int64, "mpx_linear_workspace": c_int64}
+            "mpx_linear_wgrad_scratch": c_int64, "mpx_linear_workspace": c_int64, "mpx_policy_workspace": c_int64}
 
 _lib: Optional[ctypes.CDLL] = None
 

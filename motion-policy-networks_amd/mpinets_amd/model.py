@@ -13,6 +13,7 @@ GroupNorm all run in ``libmpinets_hip.so`` (fp32 end to end, fp32 MFMA for every
 """
 from __future__ import annotations
 
+import ctypes
 import os
 
 from typing import Callable, Dict, List, Optional
@@ -326,6 +327,51 @@ class MotionPolicyNetwork(nn.Module):
         if self._q_w0 is None or self._q_w0[0] != key:
             self._q_w0 = (key, torch.nn.functional.pad(lin.weight.detach(), (0, 1)).contiguous())
         return self._q_w0[1]
+
+    # ---- the single-call C entry point (mpx_policy_forward): what a caller without Python would use ----------
+    class _NativeWeights(ctypes.Structure):  # field order = struct mpx_policy_weights (include/mpinets_hip.h)
+        _fields_ = [(n, ctypes.c_void_p) for n in ("sa1_pack", "sa2_pack", "sa2_wpoint", "sa2_wcentre", "sa2_nb1")] + \
+                   [(n, ctypes.c_void_p * k) for n, k in (("sa3_w", 3), ("sa3_b", 3), ("fc_w", 3), ("fc_b", 3), ("gn_g", 2),
+                                                          ("gn_b", 2), ("qe_w", 5), ("qe_b", 5), ("de_w", 4), ("de_b", 4))]
+
+    def native_weights(self):
+        """-> (struct mpx_policy_weights, tensors it points to).  Valid until a parameter changes."""
+        enc = self.point_cloud_encoder
+        sa1, sa2, sa3 = enc.SA_modules
+        c1, c2, c3 = sa1.convs(), sa2.convs(), sa3.convs()
+        f = lambda t: _lib.f32c(t.detach())
+        wp, wc, nb1 = sa2._packed.factored(c2, c1[-1].out_channels)
+        lins = lambda seq: [m for m in seq if isinstance(m, nn.Linear)]
+        fc, fe, de = lins(enc.fc_layer), lins(self.feature_encoder), lins(self.decoder)
+        gns = [m for m in enc.fc_layer if isinstance(m, nn.GroupNorm)]
+        groups = {
+            "sa3_w": [enc._sa3_first_weight()] + [f(c.weight.view(c.out_channels, -1)) for c in c3[1:]],
+            "sa3_b": [f(c.bias) for c in c3],
+            "fc_w": [f(m.weight) for m in fc], "fc_b": [f(m.bias) for m in fc],
+            "gn_g": [f(m.weight) for m in gns], "gn_b": [f(m.bias) for m in gns],
+            "qe_w": [self._q_first_weight()] + [f(m.weight) for m in fe[1:]], "qe_b": [f(m.bias) for m in fe],
+            "de_w": [f(m.weight) for m in de], "de_b": [f(m.bias) for m in de],
+        }
+        single = {"sa1_pack": sa1._packed.get(c1, 1, "fp32"), "sa2_pack": sa2._packed.get(c2, c1[-1].out_channels, "fp32"),
+                  "sa2_wpoint": wp, "sa2_wcentre": wc, "sa2_nb1": nb1}
+        w = self._NativeWeights()
+        for k, t in single.items():
+            setattr(w, k, t.data_ptr())
+        for k, ts in groups.items():
+            setattr(w, k, (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts]))
+        return w, (single, groups)
+
+    def forward_native(self, xyz: torch.Tensor, q: torch.Tensor) -> torch.Tensor:
+        """The same forward through ``mpx_policy_forward`` (fp32): one C call, caller-provided workspace."""
+        B, N, _ = xyz.shape
+        w, keep = self.native_weights()
+        need = _lib.load().mpx_policy_workspace(B, N)
+        ws = torch.empty(need, dtype=torch.uint8, device=xyz.device)
+        dq = torch.empty((B, 7), dtype=torch.float32, device=xyz.device)
+        _lib.call("mpx_policy_forward", ctypes.addressof(w), _lib.ptr(_lib.f32c(xyz)), N, _lib.ptr(_lib.f32c(q)), B,
+                  _lib.ptr(dq), _lib.ptr(ws), need)
+        del keep
+        return dq
 
     def forward(self, xyz: torch.Tensor, q: torch.Tensor, aux: Optional[dict] = None) -> torch.Tensor:
         """xyz [B,N,4], q [B,7] normalised to [-1,1] -> displacement [B,7] (normalised space)."""

@@ -89,6 +89,10 @@ def test_header_is_plain_c_and_a_c_client_links(tmp_path):
         "  if (mpx_linear(NULL, 8, NULL, NULL, 4, 4, 6, MPX_ACT_NONE, NULL, 4, NULL) == 0) return 2;\n"
         '  if (strstr(mpx_last_error(), "mpx_linear") == NULL) return 3;\n'
         "  if (mpx_linear_workspace(1, 2048, 4096) != 0 || mpx_linear_workspace(256, 2048, 4096) <= 0) return 4;\n"
+        "  /* the single-call policy forward: workspace query, and a NULL weight struct is refused */\n"
+        "  if (mpx_policy_workspace(1, 6272) <= 0 || mpx_policy_workspace(1, 6272) % 256 != 0) return 5;\n"
+        "  { mpx_policy_weights w; memset(&w, 0, sizeof w); (void)w;\n"
+        "    if (mpx_policy_forward(NULL, NULL, 6272, NULL, 1, NULL, NULL, 0, NULL) == 0) return 6; }\n"
         '  printf("ok %d\\n", mpx_version());\n  return 0;\n}\n')
     exe = tmp_path / "client"
     libdir = os.path.dirname(_lib.LIB_PATH)

@@ -427,3 +427,35 @@ def test_linear_bf16x3_matches_fp32_layer():
     w.mul_(2.0)
     y2 = linear_x3(x, w, b, 0, split)
     np.testing.assert_allclose(y2.cpu().numpy(), (x.double() @ w.double().T + b.double()).cpu().numpy(), atol=3e-4)
+
+
+@pytest.mark.parametrize("B", [1, 5, 9, 40])
+def test_single_call_c_forward_reproduces_the_python_path(oracle, B):
+    """mpx_policy_forward (one C call, caller workspace, no Python orchestration) == MotionPolicyNetwork.forward
+    bit for bit -- across the batch sizes where the launch shapes change (weight-streaming layers, split-K,
+    queries per wave, fused / unfused pooling) -- and, like it, within 1e-5 of the oracle."""
+    from mpinets_amd import _lib
+    from mpinets_amd.model import MotionPolicyNetwork
+    from mpinets_amd.scenes import make_problem_batch
+
+    torch.manual_seed(11)
+    mdl = MotionPolicyNetwork().to(dev()).eval()
+    prob = make_problem_batch(B, seed=21, device=dev(), kinds=("tabletop", "cubby", "dresser"), M1=40, device_clouds=True)
+    with torch.no_grad():
+        ref = mdl(prob["xyz"], prob["q_norm"])
+        got = mdl.forward_native(prob["xyz"], prob["q_norm"])
+        again = mdl.forward_native(prob["xyz"], prob["q_norm"])
+    assert torch.equal(got, ref) and torch.equal(again, got)
+    if B <= 5:
+        sd = {k: v.detach().cpu().numpy() for k, v in mdl.state_dict().items()}
+        want, _ = oracle.policy_forward(sd, prob["xyz"].cpu().numpy(), prob["q_norm"].cpu().numpy())
+        assert np.abs(got.cpu().numpy() - want).max() < TOL
+    # argument checking: a workspace that is too small is refused with a message, nothing is launched
+    w, keep = mdl.native_weights()
+    need = _lib.load().mpx_policy_workspace(B, prob["xyz"].size(1))
+    small = torch.empty(need - 256, dtype=torch.uint8, device=dev())
+    dq = torch.empty((B, 7), device=dev())
+    import ctypes
+    with pytest.raises(_lib.MpxError, match="workspace"):
+        _lib.call("mpx_policy_forward", ctypes.addressof(w), _lib.ptr(prob["xyz"]), prob["xyz"].size(1), _lib.ptr(prob["q_norm"]),
+                  B, _lib.ptr(dq), _lib.ptr(small), need - 256)
