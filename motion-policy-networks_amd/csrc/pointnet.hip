@@ -370,12 +370,18 @@ __global__ void __launch_bounds__(BQG_THREADS)
   const float *ctr = new_xyz + (size_t)b * npoint * new_stride;
   int32_t *rows = idx + (size_t)b * npoint * nsample;
 
-  // ---- cloud -> LDS, lower corner of its (x, y) bounding box
+  // ---- cloud -> registers, lower corner of its (x, y) bounding box
+  constexpr int PT = 8192 / BQG_THREADS;  // points per thread (N <= 8192)
+  float px[PT], py[PT], pz[PT];
   float mnx = __builtin_inff(), mny = __builtin_inff();
-  for (int k = tid; k < N; k += BQG_THREADS) {
-    const float px = pts[(size_t)k * stride], py = pts[(size_t)k * stride + 1], pz = pts[(size_t)k * stride + 2];
-    sx[k] = px, sy[k] = py, sz[k] = pz;
-    mnx = fminf(mnx, px), mny = fminf(mny, py);
+#pragma unroll
+  for (int i = 0; i < PT; ++i) {
+    const int k = tid + i * BQG_THREADS;
+    px[i] = py[i] = pz[i] = 0.0f;
+    if (k < N) {
+      px[i] = pts[(size_t)k * stride], py[i] = pts[(size_t)k * stride + 1], pz[i] = pts[(size_t)k * stride + 2];
+      mnx = fminf(mnx, px[i]), mny = fminf(mny, py[i]);
+    }
   }
   for (int i = tid; i < BQG * BQG; i += BQG_THREADS) ccount[i] = 0;
   if (tid == 0) n_ovf = 0;
@@ -387,9 +393,15 @@ __global__ void __launch_bounds__(BQG_THREADS)
 #pragma unroll
   for (int w = 1; w < BQG_THREADS / 64; ++w) ox = fminf(ox, red[2 * w]), oy = fminf(oy, red[2 * w + 1]);
 
-  // ---- counting sort of the point ids by column
-  for (int k = tid; k < N; k += BQG_THREADS)
-    atomicAdd(&ccount[bq_cell(sx[k], ox, inv_h) * BQG + bq_cell(sy[k], oy, inv_h)], 1);
+  // ---- counting sort by column: LDS receives the coordinates IN BUCKET ORDER (sx/sy/sz[e]) next to the point ids
+  // (order[e]), so a candidate costs three independent LDS reads instead of an id read followed by three
+  // dependent ones
+  int cell[PT];
+#pragma unroll
+  for (int i = 0; i < PT; ++i) {
+    cell[i] = bq_cell(px[i], ox, inv_h) * BQG + bq_cell(py[i], oy, inv_h);
+    if (tid + i * BQG_THREADS < N) atomicAdd(&ccount[cell[i]], 1);
+  }
   __syncthreads();
   {
     constexpr int PER = (BQG * BQG + BQG_THREADS - 1) / BQG_THREADS;
@@ -422,9 +434,14 @@ __global__ void __launch_bounds__(BQG_THREADS)
     if (tid == BQG_THREADS - 1) cstart[BQG * BQG] = (unsigned short)N;
   }
   __syncthreads();
-  for (int k = tid; k < N; k += BQG_THREADS) {
-    const int at = atomicAdd(&ccount[bq_cell(sx[k], ox, inv_h) * BQG + bq_cell(sy[k], oy, inv_h)], 1);
-    order[at] = (unsigned short)k;
+#pragma unroll
+  for (int i = 0; i < PT; ++i) {
+    const int k = tid + i * BQG_THREADS;
+    if (k < N) {
+      const int at = atomicAdd(&ccount[cell[i]], 1);
+      order[at] = (unsigned short)k;
+      sx[at] = px[i], sy[at] = py[i], sz[at] = pz[i];
+    }
   }
   __syncthreads();
 
@@ -452,24 +469,20 @@ __global__ void __launch_bounds__(BQG_THREADS)
       // columns y0..y1 of one x are adjacent in the sorted order: one contiguous range
       const int e0 = cstart[gx * BQG + y0], e1 = cstart[gx * BQG + y1 + 1];
       int e = e0;
-      for (; e + 4 <= e1; e += 4) {  // four candidates in flight: the id -> coordinate LDS reads are dependent
-        int k[4];
+      for (; e + 4 <= e1; e += 4) {  // four candidates in flight
         float d2[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) k[u] = order[e + u];
-#pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const float dx = cx - sx[k[u]], dy = cy - sy[k[u]], dz = cz - sz[k[u]];
+          const float dx = cx - sx[e + u], dy = cy - sy[e + u], dz = cz - sz[e + u];
           d2[u] = mpx_fma(dz, dz, mpx_fma(dy, dy, dx * dx));
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-          if (d2[u] < radius2) hit(k[u]);
+          if (d2[u] < radius2) hit(order[e + u]);
       }
       for (; e < e1; ++e) {
-        const int k = order[e];
-        const float dx = cx - sx[k], dy = cy - sy[k], dz = cz - sz[k];
-        if (mpx_fma(dz, dz, mpx_fma(dy, dy, dx * dx)) < radius2) hit(k);
+        const float dx = cx - sx[e], dy = cy - sy[e], dz = cz - sz[e];
+        if (mpx_fma(dz, dz, mpx_fma(dy, dy, dx * dx)) < radius2) hit(order[e]);
       }
     }
     if (over) ovf[atomicAdd(&n_ovf, 1)] = (unsigned short)j;
@@ -488,8 +501,8 @@ __global__ void __launch_bounds__(BQG_THREADS)
     for (int k0 = 0; k0 < N && have < nsample; k0 += 64) {
       const int k = k0 + lane;
       bool hit = false;
-      if (k < N) {
-        const float dx = cx - sx[k], dy = cy - sy[k], dz = cz - sz[k];
+      if (k < N) {  // (index order: from global memory -- LDS holds the cloud in bucket order)
+        const float dx = cx - pts[(size_t)k * stride], dy = cy - pts[(size_t)k * stride + 1], dz = cz - pts[(size_t)k * stride + 2];
         hit = mpx_fma(dz, dz, mpx_fma(dy, dy, dx * dx)) < radius2;
       }
       const unsigned long long m = __ballot(hit);
