@@ -19,4 +19,4 @@ e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=Tr
 e0.record()
 for _ in range(5): run()
 e1.record(); torch.cuda.synchronize()
-print(f"MPX_FPS_BLOCK={os.environ.get('MPX_FPS_BLOCK','1024')}: fps 6272->512, B={B}: {e0.elapsed_time(e1)/5:.3f} ms  checksum {int(idx.sum())}")
+print(f"MPX_FPS_BLOCK={os.environ.get('MPX_FPS_BLOCK','512')}: fps 6272->512, B={B}: {e0.elapsed_time(e1)/5:.3f} ms  checksum {int(idx.sum())}")
