@@ -29,8 +29,9 @@ __device__ __forceinline__ float act_apply(float v, int act) {
 // POOL: instead of storing the [M,N] result, max-pool it over each workgroup's BM = 128 rows (one
 // environment of the group-all module) into y[blockIdx.y][n] with atomicMax on the float bits -- valid
 // because the pooled values are post-ReLU (>= 0) and y is zero-initialised by the launcher.
+// (four waves per SIMD: 128 VGPRs with the accumulators in them, four 40 KB workgroups per CU)
 template <int BK, bool POOL>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
     linear_kernel(const float *__restrict__ x, int ldx, const float *__restrict__ w, int ldw,
                   const float *__restrict__ bias, int M, int N, int K, int act, float *__restrict__ y, int ldy,
                   int kslice, size_t zstride) {
