@@ -29,16 +29,26 @@ __device__ __forceinline__ float act_apply(float v, int act) {
 // POOL: instead of storing the [M,N] result, max-pool it over each workgroup's BM = 128 rows (one
 // environment of the group-all module) into y[blockIdx.y][n] with atomicMax on the float bits -- valid
 // because the pooled values are post-ReLU (>= 0) and y is zero-initialised by the launcher.
-// (four waves per SIMD: 128 VGPRs with the accumulators in them, four 40 KB workgroups per CU)
-template <int BK, bool POOL>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
+// (DMA: four waves per SIMD, 108 VGPRs with the accumulators in them, four 34 KB workgroups per CU; the
+// register-staged form needs 140 registers: three)
+//
+// DMA (K a multiple of the slab, operands under 4 GB, no split): the next slab goes global -> LDS directly
+// (`buffer_load_dwordx4 ... lds`: no staging registers, no ds_write; the staging instructions were measured to cost
+// 11 % of the matrix pipe).  A wave's DMA load writes 1 KB of consecutive LDS -- 16 rows x 64 B, no padding possible
+// -- so the 16-byte k-chunk c of row r is kept at physical chunk c ^ ((r >> 2) & 3): the lane picks WHICH global chunk
+// it fetches, the fragment reads apply the same xor, and every quarter-wave ds_read_b128 still touches all 64 banks
+// once.  Rows past M / N come back as zeros through the buffer descriptor's range check.
+template <int BK, bool POOL, bool DMA>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DMA ? 4 : 3, DMA ? 4 : 3)))
     linear_kernel(const float *__restrict__ x, int ldx, const float *__restrict__ w, int ldw,
                   const float *__restrict__ bias, int M, int N, int K, int act, float *__restrict__ y, int ldy,
                   int kslice, size_t zstride) {
-  constexpr int LDT = BK + 4;       // padded row: conflict-free 16-byte fragment reads
+  static_assert(!DMA || BK == 16, "the DMA layout is written for 16-float slabs");
+  constexpr int LDT = DMA ? BK : BK + 4;  // padded row (or xor-swizzled chunks): conflict-free 16-byte fragment reads
   constexpr int HK = BK / 2;        // k-values per lane-half per slab
   constexpr int NLD = BK / 8;       // float4 staged per thread per matrix per slab
-  __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LDT];  // [As0 | As1 | Bs0 | Bs1]
+  constexpr int SMEM_OPERANDS = 2 * (BM + BN) * LDT, SMEM_EPILOGUE = POOL ? 0 : 4 * 32 * (64 + 4);
+  __shared__ __attribute__((aligned(1024))) float smem[SMEM_OPERANDS > SMEM_EPILOGUE ? SMEM_OPERANDS : SMEM_EPILOGUE];  // [As0 | As1 | Bs0 | Bs1]
   float(*As)[BM * LDT] = reinterpret_cast<float(*)[BM * LDT]>(smem);
   float(*Bs)[BN * LDT] = reinterpret_cast<float(*)[BN * LDT]>(smem + 2 * BM * LDT);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -89,6 +99,34 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
     }
   };
 
+  // DMA staging: wave `wave` brings rows [32*wave, 32*wave + 32) of both operand tiles, 16 rows (1 KB) per load;
+  // lane -> (row = lane / 4 of the 16, physical chunk = lane % 4), fetching logical chunk (lane % 4) ^ (lane / 16)
+  typedef __attribute__((address_space(3))) void lds_void;
+  __amdgpu_buffer_rsrc_t xrsrc, wrsrc;
+  int xvoff[2], wvoff[2];
+  if constexpr (DMA) {
+    xrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x), 0, (int)(uint32_t)((int64_t)M * ldx * 4), 0x00020000);
+    wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(w), 0, (int)(uint32_t)((int64_t)N * ldw * 4), 0x00020000);
+    const int c4 = (((lane & 3) ^ (lane >> 4)) & 3) * 16;  // byte offset of the logical chunk inside the slab row
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = 32 * wave + 16 * i + (lane >> 2);
+      // (a row past the end gets an offset past num_records: the load returns zeros)
+      xvoff[i] = m0 + r < M ? (int)((uint32_t)(m0 + r) * (uint32_t)ldx * 4u + (uint32_t)c4) : (int)0xFFFFFFF0u;
+      wvoff[i] = n0 + r < N ? (int)((uint32_t)(n0 + r) * (uint32_t)ldw * 4u + (uint32_t)c4) : (int)0xFFFFFFF0u;
+    }
+  }
+  auto dma = [&](int k0, int buf) __attribute__((always_inline)) {
+    if constexpr (!DMA) return;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, (lds_void *)&As[buf][(32 * wave + 16 * i) * LDT], 16, xvoff[i], k0 * 4, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, (lds_void *)&Bs[buf][(32 * wave + 16 * i) * LDT], 16, wvoff[i], k0 * 4, 0, 0);
+    }
+  };
+  // fragment address: row r, 16-byte chunk c of the slab row
+  auto frag = [&](int r, int c) __attribute__((always_inline)) { return r * LDT + (DMA ? ((c ^ (r >> 2)) & 3) * 4 : c * 4); };
+
   f32x16 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -96,19 +134,28 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
     for (int j = 0; j < 2; ++j) acc[i][j] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
   const int nk = (K + BK - 1) / BK;  // the k-guards zero-fill a partial last slab
-  gload(0);
-  sstore(0);
+  if constexpr (DMA) {
+    dma(0, 0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the compiler does not know these loads write LDS
+  } else {
+    gload(0);
+    sstore(0);
+  }
   __syncthreads();
   for (int kb = 0; kb < nk; ++kb) {
     const int buf = kb & 1;
-    if (kb + 1 < nk) gload((kb + 1) * BK);
+    if constexpr (DMA) {
+      if (kb + 1 < nk) dma((kb + 1) * BK, buf ^ 1);
+    } else {
+      if (kb + 1 < nk) gload((kb + 1) * BK);
+    }
     float4 a[2][HK / 4], b[2][HK / 4];
 #pragma unroll
     for (int v = 0; v < HK / 4; ++v)
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        a[t][v] = *reinterpret_cast<const float4 *>(&As[buf][(wm * 64 + t * 32 + l31) * LDT + HK * half + 4 * v]);
-        b[t][v] = *reinterpret_cast<const float4 *>(&Bs[buf][(wn * 64 + t * 32 + l31) * LDT + HK * half + 4 * v]);
+        a[t][v] = *reinterpret_cast<const float4 *>(&As[buf][frag(wm * 64 + t * 32 + l31, (HK / 4) * half + v)]);
+        b[t][v] = *reinterpret_cast<const float4 *>(&Bs[buf][frag(wn * 64 + t * 32 + l31, (HK / 4) * half + v)]);
       }
 #pragma unroll
     for (int v = 0; v < HK / 4; ++v)
@@ -132,7 +179,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
       __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);  // MFMA
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // one more DS read
     }
-    if (kb + 1 < nk) sstore(buf ^ 1);
+    if constexpr (DMA) {
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // the next slab has landed in LDS (vmcnt(0))
+    } else {
+      if (kb + 1 < nk) sstore(buf ^ 1);
+    }
     __syncthreads();
   }
 
@@ -161,7 +212,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
     // Per wave and per 32-row half: acc -> lds[32][64+4] (ds_write_b32), back as float4 along the row.
     constexpr int LDC = 64 + 4;
     float *stage = smem + wave * (32 * LDC);  // 4 waves x 8.5 KB inside the 40 KB of operand buffers
-    static_assert(4 * 32 * LDC <= 2 * (BM + BN) * LDT, "staging must fit the operand buffers");
+    static_assert(POOL || 4 * 32 * LDC <= (int)(sizeof(smem) / sizeof(float)), "staging must fit the shared array");
     const bool vec_ok = (ldy % 4 == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -195,6 +246,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
       }
     }
   }
+}
+
+// the direct-to-LDS variant wants whole slabs and operands a 32-bit buffer offset can span
+static bool dma_ok(int M, int N, int K, int ldx, int ldw) {
+  const int64_t lim = ((int64_t)1 << 32) - 4096;  // (offsets and num_records are unsigned 32-bit)
+  return K % 16 == 0 && (int64_t)M * ldx * 4 < lim && (int64_t)N * ldw * 4 < lim;
 }
 
 // ---- a few rows (M <= 8: the head of a single-problem rollout) ---------------------------------------------
@@ -286,8 +343,12 @@ MPX_EXPORT int mpx_linear(const float *x, int ldx, const float *w, const float *
   }
   MPX_REQUIRE(cdiv(M, BM) <= 65535, "mpx_linear: M too large");
   // (BK = 32 slabs were measured: no gain, twice the LDS)
-  hipLaunchKernelGGL((linear_kernel<16, false>), dim3(cdiv(N, BN), cdiv(M, BM)), dim3(256), 0, mpx_s(stream), x, ldx,
-                     w, K, bias, M, N, K, act, y, ldy, K, (size_t)0);
+  if (dma_ok(M, N, K, ldx, K))
+    hipLaunchKernelGGL((linear_kernel<16, false, true>), dim3(cdiv(N, BN), cdiv(M, BM)), dim3(256), 0, mpx_s(stream), x,
+                       ldx, w, K, bias, M, N, K, act, y, ldy, K, (size_t)0);
+  else
+    hipLaunchKernelGGL((linear_kernel<16, false, false>), dim3(cdiv(N, BN), cdiv(M, BM)), dim3(256), 0, mpx_s(stream), x,
+                       ldx, w, K, bias, M, N, K, act, y, ldy, K, (size_t)0);
   MPX_LAUNCH_CHECK("mpx_linear");
 }
 
@@ -345,7 +406,7 @@ MPX_EXPORT int mpx_linear_ws(const float *x, int ldx, const float *w, const floa
               (long long)mpx_linear_workspace(M, N, K));
   float *part = static_cast<float *>(workspace);
   const size_t zstride = (size_t)M * N;
-  hipLaunchKernelGGL((linear_kernel<16, false>), dim3(cdiv(N, BN), cdiv(M, BM), S), dim3(256), 0, mpx_s(stream), x,
+  hipLaunchKernelGGL((linear_kernel<16, false, false>), dim3(cdiv(N, BN), cdiv(M, BM), S), dim3(256), 0, mpx_s(stream), x,
                      ldx, w, K, static_cast<const float *>(nullptr), M, N, K, MPX_ACT_NONE, part, N, kslice, zstride);
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv((int64_t)M * N, 256)), dim3(256), 0, mpx_s(stream), part, S,
                      zstride, bias, M, N, act, y, ldy);
@@ -364,8 +425,12 @@ MPX_EXPORT int mpx_linear_rowmax(const float *x, int ldx, const float *w, const 
   hipError_t e = hipMemset2DAsync(y, (size_t)ldy * sizeof(float), 0, (size_t)N * sizeof(float), (size_t)(M / BM),
                                   mpx_s(stream));
   MPX_REQUIRE(e == hipSuccess, "mpx_linear_rowmax: memset failed: %s", hipGetErrorString(e));
-  hipLaunchKernelGGL((linear_kernel<16, true>), dim3(cdiv(N, BN), M / BM), dim3(256), 0, mpx_s(stream), x, ldx, w,
-                     K, bias, M, N, K, MPX_ACT_RELU, y, ldy, K, (size_t)0);
+  if (dma_ok(M, N, K, ldx, K))
+    hipLaunchKernelGGL((linear_kernel<16, true, true>), dim3(cdiv(N, BN), M / BM), dim3(256), 0, mpx_s(stream), x, ldx, w,
+                       K, bias, M, N, K, MPX_ACT_RELU, y, ldy, K, (size_t)0);
+  else
+    hipLaunchKernelGGL((linear_kernel<16, true, false>), dim3(cdiv(N, BN), M / BM), dim3(256), 0, mpx_s(stream), x, ldx, w,
+                       K, bias, M, N, K, MPX_ACT_RELU, y, ldy, K, (size_t)0);
   MPX_LAUNCH_CHECK("mpx_linear_rowmax");
 }
 
