@@ -197,7 +197,7 @@ def main():
 
     # ---- extra: BASELINE configs 2 and 4 (FK + swept-sphere SDF collision validation only) on this rank's envs
     extra = None
-    if rank == 0 and args.extra:
+    if rank == 0 and ws == 1 and args.extra:  # (single-GPU runs only: the other ranks would wait at the next barrier)
         from mpinets_amd.scenes import linear_trajectories, random_configurations
 
         def timed(fn, n=20):
@@ -303,7 +303,8 @@ def main():
                   "what": "tabletop scenes (16 cuboids + 16 cylinders, zero-padded), static scene cloud; every step: policy "
                           "forward + joint update + FK cloud refresh + collision check"}
         del eng_s, prob_s
-        if extra is not None:
+        if rank == 0:
+            extra = extra if extra is not None else {}
             extra["tabletop_static_scene"] = static
 
     if rank == 0:
@@ -395,7 +396,7 @@ def main():
                 "sa2_executed_tflops": tiles_lockstep(cnt2, 4) * 32 * SA2_ROW_MACS * 2 / (f2_ms * 1e-3) / 1e12,
                 "sa2_frac_of_bf16_peak_2500": tiles_lockstep(cnt2, 4) * 32 * SA2_ROW_MACS * 2 / (f2_ms * 1e-3) / 1e12 / 2500.0,
             }
-        if args.cpu_envs > 0:
+        if args.cpu_envs > 0 and ws == 1:  # rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(prob, model, args.cpu_envs)
         print(json.dumps(out))
     shard.barrier()
