@@ -21,7 +21,7 @@ for arg in "$@"; do
       timeout 1200 python bench.py $val > gpurun_out/bench.log 2> gpurun_out/bench.err
       echo "bench exit: $?" >> gpurun_out/bench.err; tail -3 gpurun_out/bench.err; cat gpurun_out/bench.log ;;
     prof)
-      ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof && timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o run -- python $REPO/bench.py ${val:---steps 3 --warmup 1 --cpu-envs 0} > $REPO/gpurun_out/prof_bench.log 2> $REPO/gpurun_out/prof.err
+      ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof && timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o run -- python $REPO/bench.py ${val:---steps 3 --warmup 1 --cpu-envs 0 --extra 0 --fast-steps 0} > $REPO/gpurun_out/prof_bench.log 2> $REPO/gpurun_out/prof.err
         echo "prof exit: $?" >> $REPO/gpurun_out/prof.err
         mkdir -p $REPO/gpurun_out/prof; find /tmp/prof -name "*stats*" -exec cp {} $REPO/gpurun_out/prof/ \; ; ls -la /tmp/prof/* | head -20 >> $REPO/gpurun_out/prof.err )
       tail -3 gpurun_out/prof.err; cat gpurun_out/prof_bench.log | tail -1 | cut -c1-200; head -12 gpurun_out/prof/*kernel_stats.csv ;;
