@@ -95,6 +95,14 @@ def test_policy_step_is_deterministic_and_finite(problem, forward):
     assert torch.isfinite(aux["sa3_in"]).all() and (aux["f1"] >= 0).all()  # pooled ReLU outputs
 
 
+def test_single_call_forward_matches_at_full_size(problem, forward):
+    """mpx_policy_forward (one C call, 11.5 GB workspace at this size) == the Python-orchestrated forward, bit for bit."""
+    mdl, dq, _ = forward
+    with torch.no_grad():
+        dq_c = mdl.forward_native(problem["xyz"], problem["q_norm"])
+    assert torch.equal(dq_c, dq)
+
+
 def test_collision_sweep_fused_equals_unfused_at_config4_size(problem):
     """BASELINE config 4: 8192 trajectories x 50 waypoints; fused kernel vs sphere centres + SDF classes + threshold."""
     from mpinets_amd.geometry import TorchCuboids, TorchCylinders
