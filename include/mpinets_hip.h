@@ -400,6 +400,35 @@ int64_t mpx_policy_workspace(int B, int N);
 int mpx_policy_forward(const mpx_policy_weights *w, const float *xyz, int N, const float *q, int B,
                        float *dq, void *workspace, int64_t workspace_bytes, mpx_stream_t stream);
 
+/* ---- one closed-loop step in one call: TrainingMotionPolicyNetwork.rollout's loop body (model.py:160-181) plus the
+ * collision check of validation_step (model.py:293-314), i.e. what mpinets_amd.rollout.RolloutEngine.step() does
+ * with a static scene:  dq = policy(xyz, q_norm);  q_norm = clamp(q_norm + dq, -1, 1);  q = unnormalise(q_norm);
+ * robot rows of the slab <- FK cloud of q;  flags = any collision sphere of q inside a primitive.
+ * Everything besides the policy weights that the step reads (device pointers, shared by the batch unless noted): */
+typedef struct mpx_rollout_scene {
+  const float *limits;           /* [7,2] joint limits (lower, upper)                                            */
+  float finger;                  /* prismatic finger opening used for FK                                        */
+  const float *table_pts;        /* FrankaSampler point table [P,3] in link frames ...                         */
+  const int32_t *table_link;     /* ... and the link of each point [P]                                         */
+  const int32_t *subset;         /* the n_robot table rows written to the slab (NULL: the first n_robot)       */
+  int n_robot;                   /* robot rows at the head of every slab (2048)                                */
+  const float *sph_centers, *sph_radii; /* collision spheres [S,3], [S] in link frames ...                     */
+  const int32_t *sph_link;       /* ... and their links [S]                                                    */
+  int n_spheres;
+  const float *cub_frames, *cub_dims;   /* per environment: [B,M1,4,4] inverse frames (mpx_prim_frames), [B,M1,3] */
+  int M1;
+  const float *cyl_frames, *cyl_radii, *cyl_heights;   /* [B,M2,4,4], [B,M2], [B,M2]                           */
+  int M2;
+} mpx_rollout_scene;
+
+/* workspace bytes (256-byte aligned) of mpx_rollout_step */
+int64_t mpx_rollout_workspace(int B, int N);
+/* xyz [B,N,4] slab (robot rows rewritten in place), q_norm [B,7] in/out, q [B,7] out (radians), flags int32 [B] out
+ * (non-zero: in collision), min_sdf [B, n_spheres] out or NULL.                                                   */
+int mpx_rollout_step(const mpx_policy_weights *w, const mpx_rollout_scene *scene, float *xyz, int N,
+                     float *q_norm, float *q, int B, int32_t *flags, float *min_sdf, void *workspace,
+                     int64_t workspace_bytes, mpx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

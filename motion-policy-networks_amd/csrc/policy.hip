@@ -223,3 +223,29 @@ MPX_EXPORT int mpx_policy_forward(const mpx_policy_weights *w, const float *xyz,
   MPX_TRY(lin(bu.s_a, 128, w->de_w[3], w->de_b[3], B, 7, 128, MPX_ACT_NONE, dq, 7));
   MPX_LAUNCH_CHECK("mpx_policy_forward");
 }
+
+// ---- one closed-loop step (RolloutEngine.step with a static scene) ---------------------------------------------
+MPX_EXPORT int64_t mpx_rollout_workspace(int B, int N) {
+  if (B <= 0 || N <= 0) return 0;
+  return mpx_policy_workspace(B, N) + ((int64_t)B * 7 * (int64_t)sizeof(float) + 255) / 256 * 256;
+}
+
+MPX_EXPORT int mpx_rollout_step(const mpx_policy_weights *w, const mpx_rollout_scene *sc, float *xyz, int N, float *q_norm,
+                                float *q, int B, int32_t *flags, float *min_sdf, void *workspace, int64_t workspace_bytes,
+                                mpx_stream_t stream) {
+  MPX_REQUIRE(w && sc && xyz && q_norm && q && flags, "mpx_rollout_step: NULL operand");
+  MPX_REQUIRE(sc->n_robot >= 1 && sc->n_robot <= N, "mpx_rollout_step: n_robot = %d outside [1, N]", sc->n_robot);
+  if (B == 0) return 0;
+  const int64_t need = mpx_rollout_workspace(B, N);
+  MPX_REQUIRE(workspace && workspace_bytes >= need, "mpx_rollout_step: workspace of %lld bytes, mpx_rollout_workspace asks for %lld",
+              (long long)workspace_bytes, (long long)need);
+  const int64_t policy_bytes = mpx_policy_workspace(B, N);
+  float *dq = reinterpret_cast<float *>(static_cast<char *>(workspace) + policy_bytes);
+  MPX_TRY(mpx_policy_forward(w, xyz, N, q_norm, B, dq, workspace, policy_bytes, stream));
+  MPX_TRY(mpx_joint_step(q_norm, dq, sc->limits, B, q_norm, q, nullptr, stream));
+  MPX_TRY(mpx_franka_cloud(q, B, sc->finger, sc->table_pts, sc->table_link, sc->subset, sc->n_robot, xyz, (int64_t)N * 4, 4,
+                           stream));
+  return mpx_franka_collision(q, B, 1, sc->finger, sc->sph_centers, sc->sph_radii, sc->sph_link, sc->n_spheres, sc->cub_frames,
+                              sc->cub_dims, sc->M1, sc->cyl_frames, sc->cyl_radii, sc->cyl_heights, sc->M2, flags, min_sdf,
+                              stream);
+}

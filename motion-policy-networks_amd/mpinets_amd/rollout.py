@@ -9,6 +9,7 @@ sync every step (run_inference.py:171-189), which this engine does not need.
 """
 from __future__ import annotations
 
+import ctypes
 from typing import Dict, Optional
 
 import numpy as np
@@ -101,6 +102,38 @@ class RolloutEngine:
                  lib.ptr(c.radii), lib.ptr(c.links), c.num_spheres, lib.ptr(self.cuboids.inv_frames),
                  lib.ptr(self._cd), self.cuboids.centers.size(1), lib.ptr(self.cylinders.inv_frames),
                  lib.ptr(self._yr), lib.ptr(self._yh), self.cylinders.centers.size(1), lib.ptr(self.flags), None)
+        self.steps_done += 1
+        return self.q
+
+    # ---- the same step through the single C entry point (mpx_rollout_step): what a caller without Python uses ----
+    class _NativeScene(ctypes.Structure):  # field order = struct mpx_rollout_scene (include/mpinets_hip.h)
+        _fields_ = [("limits", ctypes.c_void_p), ("finger", ctypes.c_float), ("table_pts", ctypes.c_void_p),
+                    ("table_link", ctypes.c_void_p), ("subset", ctypes.c_void_p), ("n_robot", ctypes.c_int),
+                    ("sph_centers", ctypes.c_void_p), ("sph_radii", ctypes.c_void_p), ("sph_link", ctypes.c_void_p),
+                    ("n_spheres", ctypes.c_int), ("cub_frames", ctypes.c_void_p), ("cub_dims", ctypes.c_void_p),
+                    ("M1", ctypes.c_int), ("cyl_frames", ctypes.c_void_p), ("cyl_radii", ctypes.c_void_p),
+                    ("cyl_heights", ctypes.c_void_p), ("M2", ctypes.c_int)]
+
+    @torch.no_grad()
+    def step_native(self) -> torch.Tensor:
+        """``step()`` as ONE call of ``mpx_rollout_step`` (static scene, fp32, no success tracking): same kernels,
+        same order, bit-identical state."""
+        assert not self.rerender_scene and self.done is None
+        if getattr(self, "_native", None) is None:
+            c, sc = self.collision, self._NativeScene()
+            sc.limits, sc.finger = self.limits.data_ptr(), float(self.sampler.finger)
+            sc.table_pts, sc.table_link = self.sampler.table_pts.data_ptr(), self.sampler.table_link.data_ptr()
+            sc.subset, sc.n_robot = self.subset.data_ptr(), int(self.subset.numel())
+            sc.sph_centers, sc.sph_radii, sc.sph_link, sc.n_spheres = c.centers.data_ptr(), c.radii.data_ptr(), c.links.data_ptr(), c.num_spheres
+            sc.cub_frames, sc.cub_dims, sc.M1 = self.cuboids.inv_frames.data_ptr(), self._cd.data_ptr(), self.cuboids.centers.size(1)
+            sc.cyl_frames, sc.cyl_radii, sc.cyl_heights = self.cylinders.inv_frames.data_ptr(), self._yr.data_ptr(), self._yh.data_ptr()
+            sc.M2 = self.cylinders.centers.size(1)
+            w, keep = self.model.native_weights()
+            need = _lib.load().mpx_rollout_workspace(self.B, self.xyz.size(1))
+            self._native = (sc, w, keep, torch.empty(need, dtype=torch.uint8, device=self.device), need)
+        sc, w, _, ws, need = self._native
+        _lib.call("mpx_rollout_step", ctypes.addressof(w), ctypes.addressof(sc), _lib.ptr(self.xyz), self.xyz.size(1),
+                  _lib.ptr(self.q_norm), _lib.ptr(self.q), self.B, _lib.ptr(self.flags), None, _lib.ptr(ws), need)
         self.steps_done += 1
         return self.q
 

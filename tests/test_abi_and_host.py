@@ -93,6 +93,9 @@ def test_header_is_plain_c_and_a_c_client_links(tmp_path):
         "  if (mpx_policy_workspace(1, 6272) <= 0 || mpx_policy_workspace(1, 6272) % 256 != 0) return 5;\n"
         "  { mpx_policy_weights w; memset(&w, 0, sizeof w); (void)w;\n"
         "    if (mpx_policy_forward(NULL, NULL, 6272, NULL, 1, NULL, NULL, 0, NULL) == 0) return 6; }\n"
+        "  { mpx_rollout_scene sc; memset(&sc, 0, sizeof sc); sc.n_robot = 2048;\n"
+        "    if (mpx_rollout_workspace(1, 6272) <= mpx_policy_workspace(1, 6272)) return 7;\n"
+        "    if (mpx_rollout_step(NULL, &sc, NULL, 6272, NULL, NULL, 1, NULL, NULL, NULL, 0, NULL) == 0) return 8; }\n"
         '  printf("ok %d\\n", mpx_version());\n  return 0;\n}\n')
     exe = tmp_path / "client"
     libdir = os.path.dirname(_lib.LIB_PATH)

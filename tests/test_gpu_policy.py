@@ -459,3 +459,26 @@ def test_single_call_c_forward_reproduces_the_python_path(oracle, B):
     with pytest.raises(_lib.MpxError, match="workspace"):
         _lib.call("mpx_policy_forward", ctypes.addressof(w), _lib.ptr(prob["xyz"]), prob["xyz"].size(1), _lib.ptr(prob["q_norm"]),
                   B, _lib.ptr(dq), _lib.ptr(small), need - 256)
+
+
+@pytest.mark.parametrize("B", [1, 24])
+def test_single_call_rollout_step_reproduces_the_engine(B):
+    """mpx_rollout_step (policy forward + joint update + FK cloud refresh + collision check in one C call) leaves
+    exactly the state RolloutEngine.step() leaves: joint angles, normalised angles, slab and collision flags."""
+    from mpinets_amd.model import MotionPolicyNetwork
+    from mpinets_amd.rollout import RolloutEngine
+    from mpinets_amd.scenes import make_problem_batch
+
+    torch.manual_seed(12)
+    mdl = MotionPolicyNetwork().to(dev()).eval()
+    engines = []
+    for _ in range(2):
+        prob = make_problem_batch(B, seed=31, device=dev(), kinds=("tabletop", "cubby"), M1=24, device_clouds=True)
+        engines.append(RolloutEngine(mdl, prob))
+    a, b = engines
+    assert torch.equal(a.xyz, b.xyz)
+    for _ in range(3):
+        qa, qb = a.step(), b.step_native()
+        assert torch.equal(qa, qb) and torch.equal(a.q_norm, b.q_norm)
+        assert torch.equal(a.xyz, b.xyz) and torch.equal(a.flags, b.flags)
+    assert (a.q_norm.abs() <= 1).all()

@@ -24,3 +24,12 @@ for B in [int(a) for a in sys.argv[1:]] or [1, 256]:
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / 50 * 1e3
     print(f"B={B}: {ms:.3f} ms/step ({1e3/ms:.0f} Hz), 50-step rollout {50*ms:.1f} ms, {B*1e3/ms:.0f} env-steps/s")
+    eng.step_native()  # the same step as one C call (mpx_rollout_step)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(50):
+        eng.step_native()
+    t_host = (time.perf_counter() - t0) / 50 * 1e3
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / 50 * 1e3
+    print(f"B={B}: {ms:.3f} ms/step through mpx_rollout_step (host time {t_host:.3f} ms)")
