@@ -380,7 +380,7 @@ int mpx_rowmax(const float *x, int ldx, int G, int rows, int C, float *y, int ld
  *   sa2_wpoint [128,68]  SA2's first layer over rows [f1 (64) | xyz (3) | 0]   (W1[:,3:] | W1[:,:3] | 0)
  *   sa2_wcentre [128,4]  ... over rows [xyz (3) | *]                             (W1[:,:3] | 0)
  *   sa2_nb1 [128]        minus its bias
- *   sa3_w[0] [512,260]   group-all first layer, K padded 259 -> 260 with a zero column; sa3_w[1] [512,512];
+ *   sa3_w[0] [512,272]   group-all first layer, K padded 259 -> 272 with zero columns; sa3_w[1] [512,512];
  *                        sa3_w[2] [1024,512]; sa3_b[i] the biases
  *   fc_w / fc_b          1024 -> 4096 -> 2048 -> 2048; gn_g / gn_b: the two GroupNorm(16) affine vectors
  *   qe_w[0] [32,8]       joint encoder, first layer K padded 7 -> 8; then 32 -> 64 -> 128 -> 128 -> 64

@@ -16,7 +16,7 @@ namespace {
 constexpr int NP1 = 512, NP2 = 128, NS = 128;     // samples per module, neighbours per ball
 constexpr float R1 = 0.05f, R2 = 0.3f;            // ball radii (model.py:366-381)
 constexpr int C1 = 64, F1 = C1 + 4;               // SA1 output channels; its row [f1 | xyz1 | 0]
-constexpr int C2 = 256, K3 = 3 + C2 + 1;          // SA2 output channels; group-all input row [xyz2 | f2 | 0]
+constexpr int C2 = 256, K3 = 272;                 // SA2 output channels; group-all input row [xyz2 | f2 | 0 x 13]
 constexpr int H3 = 512, C3 = 1024;                // group-all hidden / output width
 constexpr int ENC = 2048, QF = 64, CAT = ENC + QF;
 

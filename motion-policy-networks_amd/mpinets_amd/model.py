@@ -65,7 +65,7 @@ class MPiNetsPointNet(nn.Module):
             nn.LeakyReLU(inplace=True),
             nn.Linear(2048, 2048),
         )
-        self._sa3_w0 = None  # first group-all layer with K padded 259 -> 260
+        self._sa3_w0 = None  # first group-all layer with K padded 259 -> 272 (whole 16-float slabs: direct-to-LDS GEMM)
         self.dense_precision = "fp32"  # "bf16x3": the large dense layers on the bf16 matrix cores (set_precision)
         self._split = SplitWeights()
 
@@ -144,7 +144,7 @@ class MPiNetsPointNet(nn.Module):
         key = (conv.weight._version, conv.weight.data_ptr())
         if self._sa3_w0 is None or self._sa3_w0[0] != key:
             w = conv.weight.detach().reshape(conv.out_channels, -1)
-            self._sa3_w0 = (key, torch.nn.functional.pad(w, (0, (-w.size(1)) % 4)).contiguous())
+            self._sa3_w0 = (key, torch.nn.functional.pad(w, (0, (-w.size(1)) % 16)).contiguous())
         return self._sa3_w0[1]
 
     def forward(self, point_cloud: torch.Tensor, out: Optional[torch.Tensor] = None,
@@ -185,7 +185,7 @@ class MPiNetsPointNet(nn.Module):
         # SA2's inputs (the group-all rows [xyz2 | f2 | 0] it will write into, its samples and neighbours)
         c2 = sa2.convs()
         C2o = c2[-1].out_channels
-        K3 = (3 + C2o + 3) // 4 * 4
+        K3 = (3 + C2o + 15) // 16 * 16  # [xyz2 | f2 | 0...]: whole 16-float GEMM slabs
         sa3_in = torch.zeros((B, sa2.npoint, K3), dtype=torch.float32, device=dev)
         idx2 = torch.empty((B, sa2.npoint), dtype=torch.int32, device=dev)
         nbr2 = torch.empty((B, sa2.npoint, sa2.nsample), dtype=torch.int32, device=dev)

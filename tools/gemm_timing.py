@@ -14,7 +14,7 @@ def t(fn, n=5):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
-shapes = [("sa2_pre", B*512, 128, 68), ("sa3_l1", B*128, 512, 260), ("sa3_l2", B*128, 512, 512), ("sa3_l3", B*128, 1024, 512), ("fc1", B, 4096, 1024),
+shapes = [("sa2_pre", B*512, 128, 68), ("sa3_l1", B*128, 512, 272), ("sa3_l2", B*128, 512, 512), ("sa3_l3", B*128, 1024, 512), ("fc1", B, 4096, 1024),
           ("fc2", B, 2048, 4096), ("fc3", B, 2048, 2048), ("dec1", B, 512, 2112), ("dec2", B, 256, 512), ("qenc", B, 128, 128)]
 tot = 0
 for name, M, N, K in shapes:
