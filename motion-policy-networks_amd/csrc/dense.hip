@@ -406,8 +406,12 @@ MPX_EXPORT int mpx_linear_ws(const float *x, int ldx, const float *w, const floa
               (long long)mpx_linear_workspace(M, N, K));
   float *part = static_cast<float *>(workspace);
   const size_t zstride = (size_t)M * N;
-  hipLaunchKernelGGL((linear_kernel<16, false, false>), dim3(cdiv(N, BN), cdiv(M, BM), S), dim3(256), 0, mpx_s(stream), x,
-                     ldx, w, K, static_cast<const float *>(nullptr), M, N, K, MPX_ACT_NONE, part, N, kslice, zstride);
+  if (dma_ok(M, N, K, ldx, K))  // (slices are multiples of the slab, so every slice keeps whole slabs too)
+    hipLaunchKernelGGL((linear_kernel<16, false, true>), dim3(cdiv(N, BN), cdiv(M, BM), S), dim3(256), 0, mpx_s(stream), x,
+                       ldx, w, K, static_cast<const float *>(nullptr), M, N, K, MPX_ACT_NONE, part, N, kslice, zstride);
+  else
+    hipLaunchKernelGGL((linear_kernel<16, false, false>), dim3(cdiv(N, BN), cdiv(M, BM), S), dim3(256), 0, mpx_s(stream), x,
+                       ldx, w, K, static_cast<const float *>(nullptr), M, N, K, MPX_ACT_NONE, part, N, kslice, zstride);
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv((int64_t)M * N, 256)), dim3(256), 0, mpx_s(stream), part, S,
                      zstride, bias, M, N, act, y, ldy);
   MPX_LAUNCH_CHECK("mpx_linear_ws");
