@@ -31,6 +31,16 @@ __global__ void __launch_bounds__(256) tail_columns_kernel(const float *__restri
   r[3] = 0.0f;
 }
 
+// zero columns [3 + C2, K3) of the group-all input rows (the sampling kernel writes xyz2, SA2 writes f2) and column
+// 3, which the per-query first-layer GEMM reads -- times a zero weight -- before SA2 has written it
+__global__ void __launch_bounds__(256) zero_tail_kernel(float *__restrict__ rows, int64_t n) {
+  constexpr int TAIL = K3 - 3 - C2 + 1;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n * TAIL) return;
+  const int j = (int)(i % TAIL);
+  rows[(i / TAIL) * K3 + (j == 0 ? 3 : 3 + C2 + j - 1)] = 0.0f;
+}
+
 // q [B,7] -> [B,8] (K of the first joint-encoder layer padded to a multiple of 4)
 __global__ void __launch_bounds__(256) pad_q_kernel(const float *__restrict__ q, int B, float *__restrict__ q8) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -155,8 +165,8 @@ MPX_EXPORT int mpx_policy_forward(const mpx_policy_weights *w, const float *xyz,
 
   // the two branches that need only xyz1 / q (second stream for small batches, in line otherwise)
   auto sample_sa2_and_encode_q = [&](mpx_stream_t s2) -> int {
-    hipError_t e = hipMemsetAsync(bu.sa3_in, 0, (size_t)B * NP2 * K3 * sizeof(float), mpx_s(s2));
-    MPX_REQUIRE(e == hipSuccess, "mpx_policy_forward: memset failed: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(zero_tail_kernel, dim3(cdiv((int64_t)B * NP2 * (K3 - 3 - C2 + 1), 256)), dim3(256), 0, mpx_s(s2), bu.sa3_in,
+                       (int64_t)B * NP2);
     MPX_TRY(mpx_fps(bu.xyz1, B, NP1, 3, NP2, bu.idx2, bu.sa3_in, K3, s2));
     MPX_TRY(mpx_ball_query(bu.sa3_in, K3, bu.xyz1, 3, B, NP1, NP2, R2, NS, bu.nbr2, bu.cnt2, s2));
     // joint encoder 7 -> 32 -> 64 -> 128 -> 128 -> 64, into the right part of the decoder's input rows

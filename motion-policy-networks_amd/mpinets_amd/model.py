@@ -186,7 +186,11 @@ class MPiNetsPointNet(nn.Module):
         c2 = sa2.convs()
         C2o = c2[-1].out_channels
         K3 = (3 + C2o + 15) // 16 * 16  # [xyz2 | f2 | 0...]: whole 16-float GEMM slabs
-        sa3_in = torch.zeros((B, sa2.npoint, K3), dtype=torch.float32, device=dev)
+        sa3_in = torch.empty((B, sa2.npoint, K3), dtype=torch.float32, device=dev)
+        # xyz2 and f2 are written by the sampling and SA2 kernels: only the padding needs zeros -- and column 3, which
+        # the per-query first-layer GEMM reads (times a zero weight) before SA2 has written it
+        sa3_in[:, :, 3 + C2o:] = 0
+        sa3_in[:, :, 3] = 0
         idx2 = torch.empty((B, sa2.npoint), dtype=torch.int32, device=dev)
         nbr2 = torch.empty((B, sa2.npoint, sa2.nsample), dtype=torch.int32, device=dev)
         cnt2 = torch.empty((B, sa2.npoint), dtype=torch.int32, device=dev)
