@@ -369,6 +369,12 @@ int mpx_groupnorm_leaky(const float *x, const float *gamma, const float *beta, i
 int mpx_rowmax(const float *x, int ldx, int G, int rows, int C, float *y, int ldy,
                mpx_stream_t stream);
 
+/* rows[i, col0 : col0+ncols] = src[i, :ncols] and rows[i, col0+ncols : col0+ncols+nzero] = 0 for i < n (strides in
+ * floats).  Builds SA2's per-point operand rows [f1 | xyz1 | 0] next to the features SA1 wrote (model.py:404-407's
+ * torch.cat of xyz and features, without the copy of the features).                                              */
+int mpx_append_columns(const float *src, int src_stride, int ncols, int nzero, int64_t n, float *rows,
+                       int row_stride, int col0, mpx_stream_t stream);
+
 /* ---- the whole policy forward in one call: MotionPolicyNetwork.forward, model.py:75-91 ------------------------
  * For callers without Python (a native planning node): slab + joint configuration in, displacement out.  Host-side
  * orchestration of the kernels above in the order and shapes of mpinets_amd/model.py, whose fp32 output it

@@ -20,15 +20,16 @@ constexpr int C2 = 256, K3 = 272;                 // SA2 output channels; group-
 constexpr int H3 = 512, C3 = 1024;                // group-all hidden / output width
 constexpr int ENC = 2048, QF = 64, CAT = ENC + QF;
 
-// xyz1 -> columns [C1, C1+3) of the SA1 rows, 0 -> column C1+3 (the operand of SA2's per-point first layer)
-__global__ void __launch_bounds__(256) tail_columns_kernel(const float *__restrict__ xyz1, int64_t n, float *__restrict__ rows) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  float *r = rows + i * F1 + C1;
-  r[0] = xyz1[3 * i + 0];
-  r[1] = xyz1[3 * i + 1];
-  r[2] = xyz1[3 * i + 2];
-  r[3] = 0.0f;
+// rows[i, col0 : col0 + ncols] = src[i, :ncols], rows[i, col0 + ncols : col0 + ncols + nzero] = 0
+__global__ void __launch_bounds__(256)
+    append_columns_kernel(const float *__restrict__ src, int src_stride, int ncols, int nzero, int64_t n, float *__restrict__ rows,
+                          int row_stride, int col0) {
+  const int w = ncols + nzero;
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n * w) return;
+  const int64_t i = e / w;
+  const int j = (int)(e - i * w);
+  rows[i * row_stride + col0 + j] = j < ncols ? src[i * src_stride + j] : 0.0f;
 }
 
 // zero columns [3 + C2, K3) of the group-all input rows (the sampling kernel writes xyz2, SA2 writes f2) and column
@@ -141,6 +142,16 @@ Side *side_of_current_device() {
     if (rc_ != 0) return rc_; \
   } while (0)
 
+MPX_EXPORT int mpx_append_columns(const float *src, int src_stride, int ncols, int nzero, int64_t n, float *rows, int row_stride,
+                                  int col0, mpx_stream_t stream) {
+  MPX_REQUIRE(ncols >= 0 && nzero >= 0 && ncols + nzero >= 1 && n >= 0, "mpx_append_columns: bad size");
+  MPX_REQUIRE(src_stride >= ncols && col0 >= 0 && row_stride >= col0 + ncols + nzero, "mpx_append_columns: bad stride");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(append_columns_kernel, dim3(cdiv(n * (ncols + nzero), 256)), dim3(256), 0, mpx_s(stream), src, src_stride,
+                     ncols, nzero, n, rows, row_stride, col0);
+  MPX_LAUNCH_CHECK("mpx_append_columns");
+}
+
 MPX_EXPORT int64_t mpx_policy_workspace(int B, int N) {
   if (B <= 0 || N <= 0) return 0;
   Buffers bu;
@@ -205,8 +216,7 @@ MPX_EXPORT int mpx_policy_forward(const mpx_policy_weights *w, const float *xyz,
     MPX_TRY(sample_sa2_and_encode_q(stream));
   }
   // ---- SA2: first layer per point / per query, layers 2-3 + max-pool fused ------------------------------------
-  hipLaunchKernelGGL(tail_columns_kernel, dim3(cdiv((int64_t)B * NP1, 256)), dim3(256), 0, st, bu.xyz1, (int64_t)B * NP1,
-                     bu.f1);
+  MPX_TRY(mpx_append_columns(bu.xyz1, 3, 3, 1, (int64_t)B * NP1, bu.f1, F1, C1, stream));  // rows [f1 | xyz1 | 0]
   MPX_TRY(lin(bu.f1, F1, w->sa2_wpoint, nullptr, B * NP1, 128, F1, MPX_ACT_NONE, bu.pre, 128));
   MPX_TRY(lin(bu.sa3_in, K3, w->sa2_wcentre, w->sa2_nb1, B * NP2, 128, 4, MPX_ACT_NONE, bu.ctr, 128));
   MPX_TRY(mpx_sa_mlp_factored(bu.pre, bu.ctr, bu.nbr2, bu.cnt2, B, NP1, NP2, NS, w->sa2_pack, C1, 128, 128, C2,

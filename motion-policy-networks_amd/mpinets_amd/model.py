@@ -224,8 +224,7 @@ class MPiNetsPointNet(nn.Module):
             sample_sa2()
         del keep
         if sa2.factored and (C1o,) + tuple(c.out_channels for c in c2) == FACTORED_SHAPE:
-            f1buf[:, :, C1o:C1o + 3] = xyz1
-            f1buf[:, :, C1o + 3] = 0
+            lib.call("mpx_append_columns", lib.ptr(xyz1), 3, 3, 1, B * sa1.npoint, lib.ptr(f1buf), C1o + 4, C1o)
             sa_mlp_factored(f1buf.view(B * sa1.npoint, C1o + 4), sa3_in.view(B * sa2.npoint, K3)[:, :4], nbr2,
                             cnt2 if sa2.elide_padding else torch.full_like(cnt2, sa2.nsample), sa2._packed, c2, C1o,
                             sa1.npoint, lib.ptr(sa3_in) + 12, K3, precision=sa2.precision, split=self._split)
