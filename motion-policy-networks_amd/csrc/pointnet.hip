@@ -108,7 +108,9 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PTS <
       sy[k] = y[i];
       sz[k] = z[i];
       const float mag = mpx_fma(z[i], z[i], mpx_fma(y[i], y[i], x[i] * x[i]));
-      if (!(mag <= 1e-3f)) {
+      // upstream compares the float magnitude with the DOUBLE literal 1e-3 (`if (mag <= 1e-3) continue;`): a point with
+      // mag == 1e-3f (= 0.0010000000475 > 1e-3) is kept
+      if (!((double)mag <= 1e-3)) {
         // tie order of the reference: smaller (bitrev(k mod bs), k / bs) wins -> larger key wins.
         // brev of a < 2^9 value lands in the top 9 bits: keeping the top 16 preserves the order.
         const unsigned rank = (__brev((unsigned)k & bsmask) & 0xFFFF0000u) | ((unsigned)k >> log2bs);

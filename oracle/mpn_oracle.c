@@ -362,7 +362,7 @@ ORC_API void orc_fps(const float *xyz, int B, int N, int stride, int npoint, int
         for (int k = t; k < N; k += bs) {
           const float *p2 = pts + (size_t)k * stride;
           float mag = fmaf(p2[2], p2[2], fmaf(p2[1], p2[1], p2[0] * p2[0]));
-          if (mag <= 1e-3f) continue;
+          if ((double)mag <= 1e-3) continue; /* upstream: float mag vs the double literal 1e-3 */
           float d = sqdist(p2, p1);
           float d2 = fminf(d, temp[k]);
           temp[k] = d2;

@@ -150,3 +150,20 @@ def test_sort_queries_by_tiles():
     assert sorted(o.tolist()) == list(range(5000))  # a permutation
     rows = (np.clip(cnt, 1, 128) + 3) // 4 * 4
     assert (np.diff(rows[o]) <= 0).all()  # non-increasing packed row count
+
+
+def _threshold_cloud():
+    """Points whose squared norm is exactly 1e-3f (kept upstream: the float is compared with the DOUBLE literal
+    1e-3 < 1e-3f) and one float below it (skipped)."""
+    from test_oracle_pointnet import threshold_points
+
+    return threshold_points()
+
+
+def test_fps_skip_threshold_is_the_double_comparison(oracle):
+    from mpinets_amd.pointnet2 import furthest_point_sample
+
+    x, expect = _threshold_cloud()
+    ref = oracle.fps(x, expect.shape[1])
+    np.testing.assert_array_equal(ref, expect)
+    np.testing.assert_array_equal(furthest_point_sample(T(x), expect.shape[1]).cpu().numpy(), ref)
