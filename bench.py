@@ -1,9 +1,13 @@
 #!/usr/bin/env python
 """bench.py -- env-steps/s of the closed-loop policy step (FK + SDF collision + PointNet++).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W        (N > 1: starts its own N ranks, one per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+
+Launched plainly with --gpus N > 1 it re-executes itself under torch.distributed.run (like the reference's launcher
+starts its own ranks, run_training.py:71-77,106-115) and fails loudly when fewer than N GPUs are visible
+(development only: MPX_SHARE_GPU=1 lets the ranks share the visible GPUs over gloo; the JSON then says so).
 
 Workload (BASELINE.json metric "at 8192 envs" = the per-GPU share of its largest configuration, configs[4]:
 "mixed tabletop/cubby/dresser 65536 envs, closed-loop point-cloud re-render + policy step, 8 GPUs"): every
@@ -76,6 +80,17 @@ def cpu_baseline(prob, model, n_env: int):
 
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+TRAFFIC_RECORD = "r02_traffic.json"  # written by tools/pmc_traffic.py from the PMC passes of this round
+
+
+def kernel_source_hash() -> str:
+    """SHA-256 over the sources of the dominant kernel (csrc/sa_mlp.hip + common.h): stamps the PMC traffic record."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in ("sa_mlp.hip", "common.h"):
+        h.update(open(os.path.join(ROOT, "motion-policy-networks_amd", "csrc", f), "rb").read())
+    return h.hexdigest()
 
 
 def stage_table(prof, steps, B, sa1_ms, sa1_exec, sa2_ms, sa2_exec):
@@ -117,6 +132,32 @@ def stage_table(prof, steps, B, sa1_ms, sa1_exec, sa2_ms, sa2_exec):
 SA2_ROW_MACS = 128 * 128 + 128 * 256
 
 
+def spawn_ranks_if_needed(args) -> bool:
+    """`python bench.py --gpus N` (N > 1) outside a torchrun job: start the N ranks ourselves and exit with their
+    status.  Returns True when the ranks of THIS job share GPUs (development mode, MPX_SHARE_GPU=1)."""
+    shared = os.environ.get("MPX_SHARED_DEVICES") == "1"
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return shared
+    import socket
+    import subprocess
+
+    ndev = torch.cuda.device_count()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this driver (RCCL needs it)
+    if ndev < args.gpus:
+        if os.environ.get("MPX_SHARE_GPU") != "1" or ndev == 0:
+            sys.exit(f"bench.py: --gpus {args.gpus} but only {ndev} GPU(s) visible -- refusing to report a "
+                     f"{args.gpus}-GPU number from fewer devices (development: MPX_SHARE_GPU=1 shares them over gloo)")
+        env["MPX_SHARED_DEVICES"] = "1"
+        env["MPX_DIST_BACKEND"] = "gloo"  # RCCL refuses two ranks on one device
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -129,28 +170,37 @@ def main():
     ap.add_argument("--cpu-envs", type=int, default=64, help="env-steps in the CPU baseline sample (0 = skip)")
     ap.add_argument("--scene-pool", type=int, default=1024, help="distinct host-generated primitive sets tiled over the batch (clouds are drawn per env on the device)")
     args = ap.parse_args()
+    shared_devices = spawn_ranks_if_needed(args)
 
     from mpinets_amd import _lib, shard
     from mpinets_amd.model import MotionPolicyNetwork
     from mpinets_amd.rollout import RolloutEngine
     from mpinets_amd.scenes import make_problem_batch
 
-    rank, ws, local = shard.init()
-    assert ws == args.gpus or ws == 1, f"WORLD_SIZE={ws} but --gpus {args.gpus}"
-    n_gpus = ws
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
-    # MPX_DEVICE_OVERRIDE: development only (several ranks sharing one GPU to exercise the N > 1 path)
-    dev = torch.device("cuda", int(os.environ.get("MPX_DEVICE_OVERRIDE", local)))
-    torch.cuda.set_device(dev)
+    ndev = torch.cuda.device_count()
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    # (shared_devices: development only -- several ranks on one GPU to exercise the N > 1 path)
+    dev = torch.device("cuda", local % ndev if shared_devices else local)
+    rank, ws, local = shard.init(device=dev)
+    if ws != args.gpus:
+        sys.exit(f"bench.py: WORLD_SIZE={ws} but --gpus {args.gpus} (launch with --nproc-per-node {args.gpus}, or run "
+                 f"`python bench.py --gpus {args.gpus}` and let it start its own ranks)")
+    n_gpus = ws
     _lib.load()
 
     B = args.envs
     torch.manual_seed(0)  # identical random-init weights on every rank (replicated, like a checkpoint)
     model = MotionPolicyNetwork().to(dev).eval()
     envs = shard.env_range(rank, n_gpus, B)
-    prob = make_problem_batch(B, seed=1000 + rank, device=dev, kinds=("tabletop", "cubby", "dresser"), M1=40, M2=16,
-                              scene_pool=args.scene_pool, device_clouds=True)
-    eng = RolloutEngine(model, prob, rerender_scene=True, scene_seed=17 + rank)
+    # ONE global batch of n_gpus * B problems that depends on the seed only; this rank owns rows `envs` of it and every
+    # random draw (scene clouds at set-up and at every re-render) is keyed by the GLOBAL environment id, so the
+    # gathered result of an N-rank run equals a single-rank run over the same environments bit for bit
+    # (tests/test_gpu_shard.py)
+    prob = make_problem_batch(B, seed=1000, device=dev, kinds=("tabletop", "cubby", "dresser"), M1=40, M2=16,
+                              scene_pool=args.scene_pool, device_clouds=True, env_offset=envs.start,
+                              total_envs=B * n_gpus)
+    eng = RolloutEngine(model, prob, rerender_scene=True, scene_seed=17)
 
     for _ in range(args.warmup):
         eng.step()
@@ -197,7 +247,7 @@ def main():
 
     # ---- extra: BASELINE configs 2 and 4 (FK + swept-sphere SDF collision validation only) on this rank's envs
     extra = None
-    if rank == 0 and ws == 1 and args.extra:  # (single-GPU runs only: the other ranks would wait at the next barrier)
+    if rank == 0 and args.extra and not shared_devices:  # rank 0's GPU only; the other ranks idle at the next barrier
         from mpinets_amd.scenes import linear_trajectories, random_configurations
 
         def timed(fn, n=20):
@@ -267,7 +317,12 @@ def main():
                                "env_steps_per_s": 256 * 50 / small[256] * 1e3, "dtype": "f32",
                                "bf16x3_rollout_ms": small["256x3"], "bf16x3_env_steps_per_s": 256 * 50 / small["256x3"] * 1e3,
                                "what": "256 tabletop problems, 50-step rollout (policy forward + joint update + FK cloud "
-                                       "refresh + collision check per step)"},
+                                       "refresh + collision check per step)",
+                               "precision_note": "BASELINE configs[2] names bf16 for the policy forward; plain bf16 products "
+                                                 "miss the north star's 1e-5 bar on the policy deltas (2.6e-4 simulated), so the "
+                                                 "bf16 matrix cores are offered only as 'bf16x3' (3 split products per fp32 "
+                                                 "product, fp32 accumulate; 2.6e-7 measured) -- the bf16x3_* fields are that mode, "
+                                                 "the headline fields exact fp32"},
             "c4_collision_validation": {"envs": B, "waypoints": 50, "ms": c4_ms, "env_waypoints_per_s": B * 50 / c4_ms * 1e3,
                                         "cpu_port_env_waypoints_per_s": c4_cpu, "cpu_cores": 1,
                                         "what": "FK + 56-sphere SDF vs 40 cuboids + 16 cylinders (zero-padded), has_collision[B] (model.py:293-314)"},
@@ -280,8 +335,9 @@ def main():
     # cylinders): the reference's rollout re-samples only the robot points (model.py:180-181); all ranks, weak scaling
     static = None
     if args.extra and args.static_steps > 0:
-        prob_s = make_problem_batch(B, seed=5000 + rank, device=dev, kinds=("tabletop",), M1=16, M2=16,
-                                    scene_pool=args.scene_pool, device_clouds=True)
+        prob_s = make_problem_batch(B, seed=5000, device=dev, kinds=("tabletop",), M1=16, M2=16,
+                                    scene_pool=args.scene_pool, device_clouds=True, env_offset=envs.start,
+                                    total_envs=B * n_gpus)
         eng_s = RolloutEngine(model, prob_s)
         eng_s.step()
         torch.cuda.synchronize()
@@ -329,14 +385,17 @@ def main():
         sa1_exec, sa2_exec = t1 * 32 * 8448 * 2, t2 * 32 * SA2_ROW_MACS * 2
         achieved = sa2_exec / (sa2_ms * 1e-3) / 1e12
         total_envsteps = B * n_gpus * args.steps
-        # HBM traffic of the dominant kernel comes from committed PMC passes (it cannot be read live)
+        # HBM traffic of the dominant kernel comes from committed PMC passes (it cannot be read live).  The record
+        # carries the SHA-256 of the kernel source it was measured on: a changed kernel file -> traffic null
         traffic, traffic_note = None, None
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-            if tj["envs_per_gpu"] == B and "8, true>" in tj["kernel"]:  # same kernel build, same size
+            tj = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_RECORD)))
+            if tj["envs_per_gpu"] == B and tj["kernel_source_sha256"] == kernel_source_hash():
                 traffic, traffic_note = tj["hbm_bytes_per_launch"], tj["source"] + "; " + tj["correction"]
-        except Exception:
-            pass
+            else:
+                traffic_note = f"profiles/{TRAFFIC_RECORD} is stale (kernel source or batch size changed since the PMC passes)"
+        except Exception as e:
+            traffic_note = f"no PMC record: {e}"
         out = {
             "metric": "env-steps/sec (FK+SDF+PointNet++)",
             "value": total_envsteps / elapsed,
@@ -358,6 +417,13 @@ def main():
                 "envs_per_gpu": B, "global_envs": B * n_gpus, "points_per_env": int(prob["xyz"].size(1)),
                 "parallelism": f"env-sharded x{n_gpus}, no collective on the step",
                 "weights": "random-init (seed 0)",
+                "scene_pool": f"{min(args.scene_pool, B * n_gpus)} distinct host-generated primitive sets tiled over the "
+                              f"{B * n_gpus} global environments (env g uses set g mod pool); every environment draws its "
+                              "own scene cloud on the device, keyed by its global id",
+                "env_ids": [envs.start, envs.stop] if n_gpus == 1 else f"rank r owns [r*{B}, (r+1)*{B})",
+                **({"devices_shared": True, "physical_gpus": ndev,
+                    "note": "DEVELOPMENT RUN: the ranks share GPUs (MPX_SHARE_GPU=1, gloo) -- not a scaling number"}
+                   if shared_devices else {}),
             },
             "roofline": {
                 "kernel": "sa_mlp_packed_kernel<64,128,128,256,8,true> (SA2 fused group + MLP layers 2-3 + maxpool; layer 1 factored out)",
@@ -396,7 +462,7 @@ def main():
                 "sa2_executed_tflops": tiles_lockstep(cnt2, 4) * 32 * SA2_ROW_MACS * 2 / (f2_ms * 1e-3) / 1e12,
                 "sa2_frac_of_bf16_peak_2500": tiles_lockstep(cnt2, 4) * 32 * SA2_ROW_MACS * 2 / (f2_ms * 1e-3) / 1e12 / 2500.0,
             }
-        if args.cpu_envs > 0 and ws == 1:  # rank 0 at N = 1 only
+        if args.cpu_envs > 0:  # rank 0's host cores, for every N (the other ranks wait at the final barrier)
             out["cpu_baseline"] = cpu_baseline(prob, model, args.cpu_envs)
         print(json.dumps(out))
     shard.barrier()

@@ -199,13 +199,14 @@ int mpx_segment_max_grad(const float *grad_out, int grad_stride, const int64_t *
 
 /* Per-sample joint quantities of PointCloudBase.get_inputs for a whole batch.  trajectories
  * [n_traj, L, 7] (the HDF5 `hybrid_solutions` / `global_solutions` array, resident in HBM), traj_idx
- * int64 [B], timestep int32 [B] (NULL = 0: the validation dataset).  Outputs: q [B,7] = the waypoint
- * (+ N(0, noise_scale) joint noise clamped to limits when noise_scale > 0; Philox keyed by (seed,
- * sample)), q_norm = normalize(q), sup_norm (optional) = normalize(waypoint min(t+1, L-1)),
+ * int64 [B] (clamped to [0, n_traj)), timestep int32 [B] (NULL = 0: the validation dataset).  Outputs: q [B,7] =
+ * the waypoint (+ N(0, noise_scale) joint noise when noise_scale > 0; Philox keyed by (seed, sample_offset + row),
+ * so a shard of a batch draws what the whole batch draws), clamped to the limits whenever `train` != 0
+ * (data_loader.py:176-178 clamps every TRAIN sample, with or without noise), q_norm = normalize(q), sup_norm (optional) = normalize(waypoint min(t+1, L-1)),
  * target_pose [B,4,4] / target_pos [B,3] = right_gripper FK of the LAST waypoint.                  */
 int mpx_batch_configs(const float *trajectories, int64_t n_traj, int L, const int64_t *traj_idx,
                       const int32_t *timestep, const float *limits, float noise_scale, uint64_t seed,
-                      int B, float finger, float *q, float *q_norm, float *sup_norm, float *target_pose,
+                      int64_t sample_offset, int train, int B, float finger, float *q, float *q_norm, float *sup_norm, float *target_pose,
                       float *target_pos, mpx_stream_t stream);
 /* dst[b, :] = src[idx[b], :] for rows of row_floats floats (primitive rows of the sampled scenes)  */
 int mpx_gather_rows(const float *src, const int64_t *idx, int B, int row_floats, float *dst,
@@ -224,12 +225,12 @@ int mpx_depth_render(const float *cam_poses, float fx, float fy, float cx, float
                      const float *cyl_radii, const float *cyl_heights, int M2, const float *sph_centers,
                      const float *sph_radii, int S, float far_clip, float *depth, mpx_stream_t stream);
 /* np.random.choice(len(cloud), n_out, replace=False) of run_inference.py:78-85 on the device: every valid
- * pixel gets a Philox4x32-10 key (seed, environment, pixel); the n_out smallest keys are written as world
+ * pixel gets a Philox4x32-10 key (seed, env_offset + environment, pixel); the n_out smallest keys are written as world
  * points in key order to out (strides in floats).  count [B] = valid pixels; an environment with fewer than
  * n_out of them is left untouched (the caller raises like numpy).  n_out <= 4096.                    */
 int mpx_depth_select(const float *depth, const float *cam_poses, float fx, float fy, float cx, float cy,
-                     int W, int H, int B, int n_out, uint64_t seed, float *out, int64_t out_batch_stride,
-                     int out_point_stride, int32_t *count, mpx_stream_t stream);
+                     int W, int H, int B, int n_out, uint64_t seed, int64_t env_offset, float *out,
+                     int64_t out_batch_stride, int out_point_stride, int32_t *count, mpx_stream_t stream);
 
 /* ---- scene point clouds: mpinets/geometry.py:571-608 (construct_mixed_point_cloud), batched ----- */
 
@@ -237,7 +238,8 @@ int mpx_depth_select(const float *depth, const float *cam_poses, float fx, float
  * replacement in random order (every slot gets a Philox key, the N smallest keys win in key order;
  * only the owning obstacle matters), one fresh uniform surface sample per slot, labels = shuffled
  * 1..K.  N <= 4096.  Counter RNG Philox4x32-10 keyed by
- * (seed, environment): results depend on nothing else.  Zero-volume primitives are skipped;
+ * (seed, GLOBAL environment id = env_offset + row): results depend on nothing else, so rank r of a sharded batch
+ * (env_offset = its first global environment) draws exactly what one process would for those environments.  Zero-volume primitives are skipped;
  * obstacle ids count cuboids first, then cylinders.  An environment without obstacles gets
  * ids 0xFFFF and zero points (the reference returns an empty array, geometry.py:586-587).
  *   assign uint16 [B,N] (required scratch/output), labels uint8 [B,M1+M2] (optional),
@@ -246,7 +248,7 @@ int mpx_depth_select(const float *depth, const float *cam_poses, float fx, float
 int mpx_scene_cloud(const float *cub_centers, const float *cub_dims, const float *cub_quats, int M1,
                     const float *cyl_centers, const float *cyl_radii, const float *cyl_heights,
                     const float *cyl_quats, int M2, int B, int num_points, uint64_t seed,
-                    uint16_t *assign, uint8_t *labels, int32_t *n_obstacles, float *out,
+                    int64_t env_offset, uint16_t *assign, uint8_t *labels, int32_t *n_obstacles, float *out,
                     int64_t out_batch_stride, int out_point_stride, int write_label,
                     mpx_stream_t stream);
 

@@ -14,12 +14,14 @@ enum { STREAM_JOINT_NOISE = 7 };
 __global__ void __launch_bounds__(64)
     batch_configs_kernel(const float *__restrict__ traj, int64_t n_traj, int L, const int64_t *__restrict__ traj_idx,
                          const int32_t *__restrict__ timestep, const float *__restrict__ limits, float noise_scale,
-                         uint32_t seed_lo, uint32_t seed_hi, int B, float finger, float *__restrict__ q,
+                         uint32_t seed_lo, uint32_t seed_hi, uint32_t sample0, int train, int B, float finger,
+                         float *__restrict__ q,
                          float *__restrict__ q_norm, float *__restrict__ sup_norm, float *__restrict__ target_pose,
                          float *__restrict__ target_pos) {
   const int b = blockIdx.x * 64 + threadIdx.x;
   if (b >= B) return;
-  const int64_t ti = traj_idx[b];
+  int64_t ti = traj_idx[b];
+  ti = ti < 0 ? 0 : (ti >= n_traj ? n_traj - 1 : ti);  // (an out-of-range index would read outside the array)
   int t = timestep ? timestep[b] : 0;
   t = t < 0 ? 0 : (t >= L ? L - 1 : t);                 // data_loader.py:403-404
   const int ts = t + 1 >= L ? L - 1 : t + 1;            // supervision: next waypoint, last one re-used (:408-412)
@@ -28,7 +30,7 @@ __global__ void __launch_bounds__(64)
   if (noise_scale > 0.0f) {  // Box-Muller on two Philox blocks keyed by (seed, sample)
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk) {
-      const Philox r = philox4x32((uint32_t)blk, (uint32_t)b, STREAM_JOINT_NOISE, 0u, seed_lo, seed_hi);
+      const Philox r = philox4x32((uint32_t)blk, sample0 + (uint32_t)b, STREAM_JOINT_NOISE, 0u, seed_lo, seed_hi);
 #pragma unroll
       for (int pr = 0; pr < 2; ++pr) {
         const float u1 = 1.0f - u01(r.c[2 * pr]), u2 = u01(r.c[2 * pr + 1]);  // u1 in (0,1]
@@ -45,10 +47,8 @@ __global__ void __launch_bounds__(64)
   for (int j = 0; j < 7; ++j) {
     const float lo = limits[2 * j], hi = limits[2 * j + 1];
     float v = row[j];
-    if (noise_scale > 0.0f) {
-      v = noise_scale * z[j] + v;                        // data_loader.py:169-171
-      v = fminf(fmaxf(v, lo), hi);                       // :176-178
-    }
+    if (noise_scale > 0.0f) v = noise_scale * z[j] + v;  // data_loader.py:169-171
+    if (train) v = fminf(fmaxf(v, lo), hi);              // :176-178: every TRAIN sample is clamped, noise or not
     q[(size_t)b * 7 + j] = v;
     q_norm[(size_t)b * 7 + j] = (v - lo) / (hi - lo) * 2.0f + -1.0f;             // utils.py:91-93
     if (sup_norm) sup_norm[(size_t)b * 7 + j] = (srow[j] - lo) / (hi - lo) * 2.0f + -1.0f;
@@ -81,14 +81,16 @@ __global__ void __launch_bounds__(256)
 
 MPX_EXPORT int mpx_batch_configs(const float *trajectories, int64_t n_traj, int L, const int64_t *traj_idx,
                                  const int32_t *timestep, const float *limits, float noise_scale, uint64_t seed,
-                                 int B, float finger, float *q, float *q_norm, float *sup_norm, float *target_pose,
+                                 int64_t sample_offset, int train, int B, float finger, float *q, float *q_norm, float *sup_norm, float *target_pose,
                                  float *target_pos, mpx_stream_t stream) {
-  MPX_REQUIRE(B >= 0 && L >= 1 && n_traj >= 0, "mpx_batch_configs: bad size");
+  MPX_REQUIRE(B >= 0 && L >= 1 && n_traj >= 1, "mpx_batch_configs: bad size");
+  MPX_REQUIRE(sample_offset >= 0 && sample_offset + B <= 0xFFFFFFFFll, "mpx_batch_configs: sample_offset + B exceeds 2^32");
   MPX_REQUIRE(trajectories && traj_idx && limits && q && q_norm && target_pose && target_pos,
               "mpx_batch_configs: NULL operand");
   if (B == 0) return 0;
   hipLaunchKernelGGL(batch_configs_kernel, dim3(cdiv(B, 64)), dim3(64), 0, mpx_s(stream), trajectories, n_traj, L,
-                     traj_idx, timestep, limits, noise_scale, (uint32_t)seed, (uint32_t)(seed >> 32), B, finger, q,
+                     traj_idx, timestep, limits, noise_scale, (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)sample_offset,
+                     train, B, finger, q,
                      q_norm, sup_norm, target_pose, target_pos);
   MPX_LAUNCH_CHECK("mpx_batch_configs");
 }

@@ -51,7 +51,7 @@ __global__ void __launch_bounds__(256)
 // writes their world points in key order.  count[b] = number of valid pixels; if it is < n_out nothing is written.
 __global__ void __launch_bounds__(SEL_THREADS)
     depth_select_kernel(const float *__restrict__ depth, const float *__restrict__ cam, float fx, float fy, float cx,
-                        float cy, int W, int H, int n_out, uint32_t k0, uint32_t k1, float *__restrict__ out,
+                        float cy, int W, int H, int n_out, uint32_t k0, uint32_t k1, uint32_t env0, float *__restrict__ out,
                         int64_t obs, int ops, int32_t *__restrict__ count) {
   __shared__ unsigned long long sel[SEL_CAP];
   __shared__ int hist[2048];
@@ -61,7 +61,7 @@ __global__ void __launch_bounds__(SEL_THREADS)
   const int valid = mpx_select_smallest(
       HW, n_out,
       [&](int g, uint32_t (&key)[4], bool (&valid)[4]) {  // one Philox block keys four consecutive pixels
-        const Philox r = philox4x32((uint32_t)g, (uint32_t)b, STREAM_DEPTH, 0u, k0, k1);
+        const Philox r = philox4x32((uint32_t)g, env0 + (uint32_t)b, STREAM_DEPTH, 0u, k0, k1);
 #pragma unroll
         for (int u = 0; u < 4; ++u) key[u] = r.c[u], valid[u] = 4 * g + u < HW && dp[min(4 * g + u, HW - 1)] >= 0.0f;
       },
@@ -95,14 +95,17 @@ MPX_EXPORT int mpx_depth_render(const float *cam_poses, float fx, float fy, floa
 }
 
 MPX_EXPORT int mpx_depth_select(const float *depth, const float *cam_poses, float fx, float fy, float cx, float cy,
-                                int W, int H, int B, int n_out, uint64_t seed, float *out, int64_t out_batch_stride,
+                                int W, int H, int B, int n_out, uint64_t seed, int64_t env_offset, float *out,
+                                int64_t out_batch_stride,
                                 int out_point_stride, int32_t *count, mpx_stream_t stream) {
   MPX_REQUIRE(B >= 0 && W > 0 && H > 0, "mpx_depth_select: bad size");
   MPX_REQUIRE(n_out >= 1 && n_out <= SEL_MAX_OUT, "mpx_depth_select: n_out must be in [1, %d]", SEL_MAX_OUT);
   MPX_REQUIRE(out_point_stride >= 3 && count, "mpx_depth_select: bad output");
+  MPX_REQUIRE(env_offset >= 0 && env_offset + B <= 0xFFFFFFFFll, "mpx_depth_select: env_offset + B exceeds 2^32");
   if (B == 0) return 0;
   hipLaunchKernelGGL(depth_select_kernel, dim3(B), dim3(SEL_THREADS), 0, mpx_s(stream), depth, cam_poses, fx, fy, cx,
-                     cy, W, H, n_out, (uint32_t)seed, (uint32_t)(seed >> 32), out, out_batch_stride, out_point_stride,
+                     cy, W, H, n_out, (uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)env_offset, out, out_batch_stride,
+                     out_point_stride,
                      count);
   MPX_LAUNCH_CHECK("mpx_depth_select");
 }

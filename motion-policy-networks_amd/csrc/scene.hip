@@ -6,7 +6,8 @@
 // obstacle (geometry.py:598-604); np.random.choice(sum n_i, N, replace=False) (:608); labels are a
 // shuffled 1..K (:594-595).  Its samples come from NumPy's global RNG inside geometrout, so only
 // the DISTRIBUTION can be matched.  This kernel draws from exactly that distribution with a counter
-// RNG (Philox4x32-10 keyed by (seed, environment)):
+// RNG (Philox4x32-10 keyed by (seed, GLOBAL environment id = env_offset + row): a shard of a larger batch draws
+// exactly what the unsharded batch draws for the same environments):
 //   * picking N of the pool slots without replacement in random order: every pool slot gets a
 //     Philox key, the N smallest keys win and their order is the output order (one workgroup per
 //     environment: radix select + LDS sort, select_device.h); only the obstacle owning each slot
@@ -39,7 +40,7 @@ __device__ __forceinline__ double obstacle_area(int m, int M1, const float *cd, 
 __global__ void __launch_bounds__(SEL_THREADS)
     scene_assign_kernel(const float *__restrict__ cub_dims, int M1, const float *__restrict__ cyl_radii,
                         const float *__restrict__ cyl_heights, int M2, int B, int N, uint32_t seed_lo,
-                        uint32_t seed_hi, uint16_t *__restrict__ assign, uint8_t *__restrict__ labels,
+                        uint32_t seed_hi, uint32_t env0, uint16_t *__restrict__ assign, uint8_t *__restrict__ labels,
                         int32_t *__restrict__ n_obstacles) {
   __shared__ unsigned long long sel[SEL_CAP];
   __shared__ int hist[2048];
@@ -85,7 +86,7 @@ __global__ void __launch_bounds__(SEL_THREADS)
     // geometry.py:594-595)
     uint32_t ctr = 0;
     for (int i = live - 1; i > 0; --i) {
-      const Philox r = philox4x32(ctr++, (uint32_t)b, STREAM_LABEL, 0, seed_lo, seed_hi);
+      const Philox r = philox4x32(ctr++, env0 + (uint32_t)b, STREAM_LABEL, 0, seed_lo, seed_hi);
       const int jpos = (int)(((uint64_t)r.c[0] * (uint32_t)(i + 1)) >> 32);  // uniform in [0, i]
       const uint8_t tmp = lab_s[who_s[i]];
       lab_s[who_s[i]] = lab_s[who_s[jpos]];
@@ -103,7 +104,7 @@ __global__ void __launch_bounds__(SEL_THREADS)
   mpx_select_smallest(
       T, N,
       [&](int g, uint32_t (&key)[4], bool (&valid)[4]) {  // one Philox block keys four consecutive slots
-        const Philox r = philox4x32((uint32_t)g, (uint32_t)b, STREAM_URN, 0, seed_lo, seed_hi);
+        const Philox r = philox4x32((uint32_t)g, env0 + (uint32_t)b, STREAM_URN, 0, seed_lo, seed_hi);
 #pragma unroll
         for (int u = 0; u < 4; ++u) key[u] = r.c[u], valid[u] = 4 * g + u < T;
       },
@@ -136,7 +137,7 @@ __global__ void __launch_bounds__(256)
                         const float *__restrict__ cub_q, int M1, const float *__restrict__ cyl_c,
                         const float *__restrict__ cyl_r, const float *__restrict__ cyl_h,
                         const float *__restrict__ cyl_q, int M2, int N, uint32_t seed_lo, uint32_t seed_hi,
-                        const uint16_t *__restrict__ assign, const uint8_t *__restrict__ labels,
+                        uint32_t env0, const uint16_t *__restrict__ assign, const uint8_t *__restrict__ labels,
                         float *__restrict__ out, int64_t obs, int ops, int write_label) {
   const int b = blockIdx.y;
   const int j = blockIdx.x * 256 + threadIdx.x;
@@ -148,7 +149,7 @@ __global__ void __launch_bounds__(256)
     if (write_label) o[3] = 0.0f;
     return;
   }
-  const Philox r = philox4x32((uint32_t)j, (uint32_t)b, STREAM_POINT, 0, seed_lo, seed_hi);
+  const Philox r = philox4x32((uint32_t)j, env0 + (uint32_t)b, STREAM_POINT, 0, seed_lo, seed_hi);
   const float u0 = u01(r.c[0]), u1 = u01(r.c[1]), u2 = u01(r.c[2]), u3 = u01(r.c[3]);
   float lx, ly, lz;
   const float *ctr, *quat;
@@ -202,21 +203,22 @@ __global__ void __launch_bounds__(256)
 MPX_EXPORT int mpx_scene_cloud(const float *cub_centers, const float *cub_dims, const float *cub_quats, int M1,
                                const float *cyl_centers, const float *cyl_radii, const float *cyl_heights,
                                const float *cyl_quats, int M2, int B, int num_points, uint64_t seed,
-                               uint16_t *assign, uint8_t *labels, int32_t *n_obstacles, float *out,
+                               int64_t env_offset, uint16_t *assign, uint8_t *labels, int32_t *n_obstacles, float *out,
                                int64_t out_batch_stride, int out_point_stride, int write_label,
                                mpx_stream_t stream) {
   MPX_REQUIRE(B >= 0 && M1 >= 0 && M2 >= 0 && num_points >= 0, "mpx_scene_cloud: negative size");
   MPX_REQUIRE(M1 + M2 <= MAX_OBS, "mpx_scene_cloud: more than %d primitives per environment", MAX_OBS);
   MPX_REQUIRE(num_points <= SEL_MAX_OUT, "mpx_scene_cloud: num_points > %d (the draw is ordered in LDS)", SEL_MAX_OUT);
   MPX_REQUIRE(B <= 65535, "mpx_scene_cloud: B > 65535 (slab the batch)");
+  MPX_REQUIRE(env_offset >= 0 && env_offset + B <= 0xFFFFFFFFll, "mpx_scene_cloud: env_offset + B exceeds 2^32");
   MPX_REQUIRE(out_point_stride >= (write_label ? 4 : 3), "mpx_scene_cloud: out_point_stride too small");
   MPX_REQUIRE(assign != nullptr, "mpx_scene_cloud: assign scratch [B,num_points] uint16 is required");
   if (B == 0 || num_points == 0) return 0;
-  const uint32_t lo = (uint32_t)seed, hi = (uint32_t)(seed >> 32);
+  const uint32_t lo = (uint32_t)seed, hi = (uint32_t)(seed >> 32), env0 = (uint32_t)env_offset;
   hipLaunchKernelGGL(scene_assign_kernel, dim3(B), dim3(SEL_THREADS), 0, mpx_s(stream), cub_dims, M1, cyl_radii,
-                     cyl_heights, M2, B, num_points, lo, hi, assign, labels, n_obstacles);
+                     cyl_heights, M2, B, num_points, lo, hi, env0, assign, labels, n_obstacles);
   hipLaunchKernelGGL(scene_points_kernel, dim3(cdiv(num_points, 256), B), dim3(256), 0, mpx_s(stream), cub_centers,
                      cub_dims, cub_quats, M1, cyl_centers, cyl_radii, cyl_heights, cyl_quats, M2, num_points, lo,
-                     hi, assign, labels, out, out_batch_stride, out_point_stride, write_label);
+                     hi, env0, assign, labels, out, out_batch_stride, out_point_stride, write_label);
   MPX_LAUNCH_CHECK("mpx_scene_cloud");
 }

@@ -41,11 +41,11 @@ PROTOTYPES = {
     "mpx_pack_rows_grad": [P, I, P, P, P, I, I, I, I, P, I, P],
     "mpx_segment_max": [P, I, P, L, P, I, P, P],
     "mpx_segment_max_grad": [P, I, P, L, I, P, P],
-    "mpx_batch_configs": [P, L, I, P, P, P, F, ctypes.c_uint64, I, F, P, P, P, P, P, P],
+    "mpx_batch_configs": [P, L, I, P, P, P, F, ctypes.c_uint64, L, I, I, F, P, P, P, P, P, P],
     "mpx_gather_rows": [P, P, I, I, P, P],
     "mpx_depth_render": [P, F, F, F, F, I, I, I, P, P, I, P, P, P, I, P, P, I, F, P, P],
-    "mpx_depth_select": [P, P, F, F, F, F, I, I, I, I, ctypes.c_uint64, P, L, I, P, P],
-    "mpx_scene_cloud": [P, P, P, I, P, P, P, P, I, I, I, ctypes.c_uint64, P, P, P, P, L, I, I, P],
+    "mpx_depth_select": [P, P, F, F, F, F, I, I, I, I, ctypes.c_uint64, L, P, L, I, P, P],
+    "mpx_scene_cloud": [P, P, P, I, P, P, P, P, I, I, I, ctypes.c_uint64, L, P, P, P, P, L, I, I, P],
     "mpx_fps": [P, I, I, I, I, P, P, I, P],
     "mpx_ball_query": [P, I, P, I, I, I, I, F, I, P, P, P],
     "mpx_sort_queries": [P, L, I, P, P, P],

@@ -107,8 +107,10 @@ class PointCloudBase:
 
     @torch.no_grad()
     def get_inputs_batch(self, trajectory_idx: torch.Tensor, timestep: Optional[torch.Tensor],
-                         with_supervision: bool, seed: Optional[int] = None) -> Dict[str, torch.Tensor]:
-        """Batched ``get_inputs`` (+ the supervision row of ``PointCloudInstanceDataset.__getitem__``)."""
+                         with_supervision: bool, seed: Optional[int] = None, sample_offset: int = 0) -> Dict[str, torch.Tensor]:
+        """Batched ``get_inputs`` (+ the supervision row of ``PointCloudInstanceDataset.__getitem__``).  Every random
+        draw of row b is keyed by (seed, ``sample_offset + b``): a rank holding rows [o, o+n) of a global batch passes
+        ``sample_offset=o`` and draws what a single process would."""
         dev = self.device
         ti = torch.as_tensor(trajectory_idx, dtype=torch.int64, device=dev).contiguous()
         ts = None if timestep is None else torch.as_tensor(timestep, dtype=torch.int32, device=dev).contiguous()
@@ -120,7 +122,7 @@ class PointCloudBase:
         sup = f(7) if with_supervision else None
         _lib.call("mpx_batch_configs", _lib.ptr(self.trajectories), self._num_trajectories, self.expert_length,
                   _lib.ptr(ti), _lib.ptr(ts), _lib.ptr(self.limits), self.random_scale if self.train else 0.0,
-                  seed & (2 ** 64 - 1), B, self.fk_sampler.finger, _lib.ptr(q), _lib.ptr(qn), _lib.ptr(sup),
+                  seed & (2 ** 64 - 1), int(sample_offset), int(self.train), B, self.fk_sampler.finger, _lib.ptr(q), _lib.ptr(qn), _lib.ptr(sup),
                   _lib.ptr(pose), _lib.ptr(pos))
         item = {"configuration": qn, "target_position": pos}
         if sup is not None:
@@ -136,7 +138,7 @@ class PointCloudBase:
         xyz[:, nr:nr + no, 3] = 1
         xyz[:, nr + no:, 3] = 2
         self.fk_sampler.sample_into(q, xyz, self.fk_sampler.draw_subset(nr))
-        sample_scene_clouds(item, no, seed ^ 0x5CE7E, out=xyz[:, nr:nr + no])
+        sample_scene_clouds(item, no, seed ^ 0x5CE7E, out=xyz[:, nr:nr + no], env_offset=sample_offset)
         tgt = self.fk_sampler.sample_end_effector(pose, num_points=nt)
         xyz[:, nr + no:, :3] = tgt
         item["xyz"] = xyz

@@ -79,10 +79,10 @@ class DepthCamera:
 
     @torch.no_grad()
     def sample_cloud(self, depth: torch.Tensor, cam_poses: torch.Tensor, num_points: int, seed: int = 0,
-                     out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                     out: Optional[torch.Tensor] = None, env_offset: int = 0) -> torch.Tensor:
         """``num_points`` of the valid pixels, uniformly without replacement, as world points [B,num_points,3]
         (``out`` may be slab rows ``xyz[:, 2048:6144]``).  Raises ValueError like ``np.random.choice`` if an
-        image has fewer valid pixels."""
+        image has fewer valid pixels.  Row b draws as global environment ``env_offset + b`` (sharded batches)."""
         cam = _lib.f32c(cam_poses)
         B = cam.size(0)
         if out is None:
@@ -91,7 +91,8 @@ class DepthCamera:
         count = torch.empty(B, dtype=torch.int32, device=cam.device)
         d = _lib.f32c(depth)
         _lib.call("mpx_depth_select", _lib.ptr(d), _lib.ptr(cam), self.fx, self.fy, self.cx, self.cy, self.width,
-                  self.height, B, num_points, int(seed) & (2 ** 64 - 1), _lib.ptr(out), out.stride(0), out.stride(1),
+                  self.height, B, num_points, int(seed) & (2 ** 64 - 1), int(env_offset), _lib.ptr(out), out.stride(0),
+                  out.stride(1),
                   _lib.ptr(count))
         self.last_counts = count
         if int(count.min().item()) < num_points:

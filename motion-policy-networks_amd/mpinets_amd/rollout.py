@@ -24,9 +24,13 @@ from .robot import FrankaCollisionSampler, FrankaSampler
 
 class RolloutEngine:
     def __init__(self, model: MotionPolicyNetwork, problem: Dict[str, torch.Tensor], num_robot_points: int = 2048,
-                 robot_subset: Optional[torch.Tensor] = None, rerender_scene: bool = False, scene_seed: int = 0):
+                 robot_subset: Optional[torch.Tensor] = None, rerender_scene: bool = False, scene_seed: int = 0,
+                 env_offset: Optional[int] = None):
         """``rerender_scene``: draw a fresh 4096-point scene cloud from the primitives at the start of every step
-        (BASELINE config 5, "closed-loop point-cloud re-render"); default keeps the scene rows of the slab."""
+        (BASELINE config 5, "closed-loop point-cloud re-render"); default keeps the scene rows of the slab.
+        ``env_offset``: global id of this batch's first environment (default: the problem's own ``env_offset`` entry,
+        else 0).  The re-render draws are keyed by (``scene_seed``, step, global environment id), so a rank that owns
+        environments [o, o+B) of a sharded batch computes exactly what a single process computes for those rows."""
         self.model = model
         dev = problem["xyz"].device
         self.device = dev
@@ -48,6 +52,7 @@ class RolloutEngine:
         self.flags = torch.zeros(self.B, dtype=torch.int32, device=dev)
         self.steps_done = 0
         self.rerender_scene, self.scene_seed = bool(rerender_scene), int(scene_seed)
+        self.env_offset = int(problem.get("env_offset", 0) if env_offset is None else env_offset)
         if self.rerender_scene:
             self._prims = {k: problem[k] for k in ("cuboid_centers", "cuboid_dims", "cuboid_quats", "cylinder_centers",
                                                    "cylinder_radii", "cylinder_heights", "cylinder_quats")}
@@ -57,6 +62,8 @@ class RolloutEngine:
             self._scene_scratch = (torch.empty((self.B, self._n_scene), dtype=torch.int16, device=dev),
                                    torch.zeros((self.B, m), dtype=torch.uint8, device=dev),
                                    torch.zeros(self.B, dtype=torch.int32, device=dev))
+        # tests: a dict here receives the forward's intermediates (FPS / ball-query indices, counts, features)
+        self.capture: Optional[dict] = None
         # success tracking (rollout_until_success): target poses, done flags, per-env step counts
         self.targets = None
         self.done = None
@@ -89,8 +96,8 @@ class RolloutEngine:
 
             sample_scene_clouds(self._prims, self._n_scene, self.scene_seed + 7919 * self.steps_done,
                                 out=self.xyz[:, self._n_robot:self._n_robot + self._n_scene],
-                                scratch=self._scene_scratch)
-        dq = self.model(self.xyz, self.q_norm)
+                                scratch=self._scene_scratch, env_offset=self.env_offset)
+        dq = self.model(self.xyz, self.q_norm) if self.capture is None else self.model(self.xyz, self.q_norm, aux=self.capture)
         lib.call("mpx_joint_step", lib.ptr(self.q_norm), lib.ptr(dq), lib.ptr(self.limits), self.B,
                  lib.ptr(self.q_norm), lib.ptr(self.q), lib.ptr(self.done))
         if self.done is not None:

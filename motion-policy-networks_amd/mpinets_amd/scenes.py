@@ -129,9 +129,12 @@ def sample_scene_clouds_host(scn: Dict[str, np.ndarray], num_points: int, seed: 
     Distributionally equivalent to ``construct_mixed_point_cloud`` (geometry.py:571-608): each
     point picks an unmasked primitive with probability proportional to its surface area and is
     uniform on that surface.  -> float32 [B, num_points, 3].  Host-side set-up code (the batched
-    device sampler is part of the S3 row).
+    device sampler is part of the S3 row).  All uniforms come from ONE array drawn scene by scene,
+    so the cloud of scene b does not depend on how many scenes follow it (a shard that generates a prefix of the
+    scenes gets the same clouds as a process that generates them all).
     """
     rng = np.random.default_rng(seed)
+    U = rng.random((scn["cuboid_dims"].shape[0], num_points, 10))
     cd, yr, yh = scn["cuboid_dims"].astype(np.float64), scn["cylinder_radii"][..., 0].astype(np.float64), \
         scn["cylinder_heights"][..., 0].astype(np.float64)
     B, M1 = cd.shape[:2]
@@ -142,7 +145,7 @@ def sample_scene_clouds_host(scn: Dict[str, np.ndarray], num_points: int, seed: 
     cyl_area[(np.abs(yr) <= 1e-8) | (np.abs(yh) <= 1e-8)] = 0
     area = np.concatenate([cub_area, cyl_area], axis=1)
     cdf = np.cumsum(area, axis=1)
-    u = rng.random((B, num_points)) * cdf[:, -1:]
+    u = U[..., 0] * cdf[:, -1:]
     prim = np.minimum((u[:, :, None] >= cdf[:, None, :]).sum(-1), M1 + M2 - 1)  # [B,P]
     bi = np.arange(B)[:, None]
     is_cyl = prim >= M1
@@ -152,18 +155,18 @@ def sample_scene_clouds_host(scn: Dict[str, np.ndarray], num_points: int, seed: 
     d = cd[bi, ci]
     face_area = np.stack([d[..., 1] * d[..., 2], d[..., 0] * d[..., 2], d[..., 0] * d[..., 1]], -1)
     fc = np.cumsum(face_area, -1)
-    uf = rng.random((B, num_points)) * fc[..., -1]
+    uf = U[..., 1] * fc[..., -1]
     axis = np.minimum((uf[..., None] >= fc).sum(-1), 2)
-    p = (rng.random((B, num_points, 3)) - 0.5) * d
-    sign = np.where(rng.random((B, num_points)) < 0.5, -0.5, 0.5)
+    p = (U[..., 2:5] - 0.5) * d
+    sign = np.where(U[..., 5] < 0.5, -0.5, 0.5)
     np.put_along_axis(p, axis[..., None], (sign * np.take_along_axis(d, axis[..., None], -1)[..., 0])[..., None], -1)
     # cylinder samples
     r, h = yr[bi, yi], yh[bi, yi]
     side, cap = 2 * np.pi * r * h, np.pi * r**2
-    uc = rng.random((B, num_points)) * (side + 2 * cap + 1e-30)
-    th = rng.random((B, num_points)) * 2 * np.pi
-    rho = np.where(uc < side, r, r * np.sqrt(rng.random((B, num_points))))
-    z = np.where(uc < side, (rng.random((B, num_points)) - 0.5) * h, np.where(uc < side + cap, -0.5 * h, 0.5 * h))
+    uc = U[..., 6] * (side + 2 * cap + 1e-30)
+    th = U[..., 7] * 2 * np.pi
+    rho = np.where(uc < side, r, r * np.sqrt(U[..., 8]))
+    z = np.where(uc < side, (U[..., 9] - 0.5) * h, np.where(uc < side + cap, -0.5 * h, 0.5 * h))
     pc = np.stack([rho * np.cos(th), rho * np.sin(th), z], -1)
     local = np.where(is_cyl[..., None], pc, p)
     quat = np.where(is_cyl[..., None], scn["cylinder_quats"][bi, yi], scn["cuboid_quats"][bi, ci]).astype(np.float64)
@@ -179,13 +182,16 @@ def sample_scene_clouds_host(scn: Dict[str, np.ndarray], num_points: int, seed: 
 
 
 def sample_scene_clouds(prims: Dict[str, torch.Tensor], num_points: int, seed: int, out: Optional[torch.Tensor] = None,
-                        write_label: bool = False, return_aux: bool = False, scratch: Optional[tuple] = None):
+                        write_label: bool = False, return_aux: bool = False, scratch: Optional[tuple] = None,
+                        env_offset: int = 0):
     """Device-side batched ``construct_mixed_point_cloud`` (geometry.py:571-608; csrc/scene.hip).
 
     ``prims``: cuboid_{centers,dims,quats} [B,M1,*], cylinder_{centers,radii,heights,quats} [B,M2,*] on the
     GPU (zero-volume rows are skipped like data_loader.py:248,256).  Writes ``out[:, :num_points, :3]``
     (``out`` may be a slab view ``xyz[:, 2048:6144]``; default: a fresh [B,N,3] tensor), plus the
-    shuffled obstacle label in column 3 when ``write_label``.  Deterministic in (seed, env index).
+    shuffled obstacle label in column 3 when ``write_label``.  Deterministic in (seed, GLOBAL environment id =
+    ``env_offset`` + row): rank r of a sharded batch passes the id of its first environment and draws exactly what a
+    single process would draw for those environments.
     """
     from . import _lib
 
@@ -208,7 +214,8 @@ def sample_scene_clouds(prims: Dict[str, torch.Tensor], num_points: int, seed: i
         nb = min(65535, B - b0)
         sl = slice(b0, b0 + nb)
         _lib.call("mpx_scene_cloud", _lib.ptr(cc[sl]), _lib.ptr(cd[sl]), _lib.ptr(cq[sl]), M1, _lib.ptr(yc[sl]),
-                  _lib.ptr(yr[sl]), _lib.ptr(yh[sl]), _lib.ptr(yq[sl]), M2, nb, num_points, int(seed) + b0 * 0x9E3779B97F4A7C15 % (1 << 63),
+                  _lib.ptr(yr[sl]), _lib.ptr(yh[sl]), _lib.ptr(yq[sl]), M2, nb, num_points, int(seed) & (2 ** 64 - 1),
+                  int(env_offset) + b0,
                   _lib.ptr(assign[sl]), _lib.ptr(labels[sl]), _lib.ptr(nobs[sl]), _lib.ptr(out[sl]), out.stride(0),
                   out.stride(1), int(write_label))
     if return_aux:
@@ -231,22 +238,30 @@ def linear_trajectories(B: int, T: int, seed: int = 0) -> np.ndarray:
 
 
 def make_problem_batch(B: int, seed: int = 0, device="cuda:0", kinds=("tabletop",), M1: int = 16, M2: int = 16,
-                       scene_pool: Optional[int] = None, device_clouds: bool = False) -> Dict[str, torch.Tensor]:
+                       scene_pool: Optional[int] = None, device_clouds: bool = False, env_offset: int = 0,
+                       total_envs: Optional[int] = None) -> Dict[str, torch.Tensor]:
     """A batch of planning problems on ``device``: primitives, start configuration, target pose and
     the ``[B, 2048+4096+128, 4]`` slab (robot | scene | target rows, label column 0/1/2 --
     ``mpinets/data_loader.py:261-278``).  ``scene_pool`` bounds the number of distinct scenes
-    generated on the host (they are tiled over the batch) to keep set-up time short."""
+    generated on the host (they are tiled over the batch) to keep set-up time short.
+
+    Sharding: the batch is rows ``[env_offset, env_offset + B)`` of a GLOBAL batch of ``total_envs`` problems
+    (default ``env_offset + B``) that depends on ``seed`` only -- every rank passes the same seed and its own offset
+    and gets exactly the rows one process would generate (scenes, configurations, targets and, with
+    ``device_clouds``, the scene clouds, whose draws are keyed by the global environment id)."""
     from .robot import FrankaSampler, franka_fk, frames_to_matrix
 
     dev = torch.device(device)
-    nscene = B if scene_pool is None else min(B, scene_pool)
-    scn = make_scenes(nscene, seed, kinds, M1, M2)
+    total = env_offset + B if total_envs is None else int(total_envs)
+    assert 0 <= env_offset and env_offset + B <= total
+    nscene = total if scene_pool is None else min(total, scene_pool)
+    gid = env_offset + np.arange(B)  # global environment ids of this batch's rows
+    sid = gid % nscene  # environment g sits in scene g mod nscene
+    scn = make_scenes(nscene if scene_pool is not None else int(sid.max()) + 1 if B else 0, seed, kinds, M1, M2)
     cloud = None if device_clouds else sample_scene_clouds_host(scn, NUM_OBSTACLE_POINTS, seed)
-    rep = (B + nscene - 1) // nscene
-    tile = lambda a: np.tile(a, (rep,) + (1,) * (a.ndim - 1))[:B]
-    out = {k: torch.from_numpy(tile(v)).to(dev) for k, v in scn.items()}
-    q = torch.from_numpy(random_configurations(B, seed)).to(dev)
-    q_target = torch.from_numpy(random_configurations(B, seed + 7)).to(dev)
+    out = {k: torch.from_numpy(np.ascontiguousarray(v[sid])).to(dev) for k, v in scn.items()}
+    q = torch.from_numpy(random_configurations(env_offset + B, seed)[env_offset:]).to(dev)
+    q_target = torch.from_numpy(random_configurations(env_offset + B, seed + 7)[env_offset:]).to(dev)
     lim = torch.as_tensor(ft.JOINT_LIMITS_REAL, dtype=torch.float32, device=dev)
     state = np.random.get_state()
     np.random.seed(seed)
@@ -255,15 +270,16 @@ def make_problem_batch(B: int, seed: int = 0, device="cuda:0", kinds=("tabletop"
                       device=dev)
     xyz[:, NUM_ROBOT_POINTS:NUM_ROBOT_POINTS + NUM_OBSTACLE_POINTS, 3] = 1
     xyz[:, NUM_ROBOT_POINTS + NUM_OBSTACLE_POINTS:, 3] = 2
-    subset = sampler.draw_subset(NUM_ROBOT_POINTS)
+    subset = sampler.draw_subset(NUM_ROBOT_POINTS)  # (one column subset for the whole global batch: same seed, same draw)
     sampler.sample_into(q, xyz, subset)
     if device_clouds:  # every environment gets its own draw, even when the primitives are tiled
-        sample_scene_clouds(out, NUM_OBSTACLE_POINTS, seed, out=xyz[:, NUM_ROBOT_POINTS:NUM_ROBOT_POINTS + NUM_OBSTACLE_POINTS])
+        sample_scene_clouds(out, NUM_OBSTACLE_POINTS, seed, out=xyz[:, NUM_ROBOT_POINTS:NUM_ROBOT_POINTS + NUM_OBSTACLE_POINTS],
+                            env_offset=env_offset)
     else:
-        xyz[:, NUM_ROBOT_POINTS:NUM_ROBOT_POINTS + NUM_OBSTACLE_POINTS, :3] = torch.from_numpy(tile(cloud)).to(dev)
+        xyz[:, NUM_ROBOT_POINTS:NUM_ROBOT_POINTS + NUM_OBSTACLE_POINTS, :3] = torch.from_numpy(cloud[sid]).to(dev)
     target_pose = frames_to_matrix(franka_fk(q_target)[:, ft.LINK_ID["right_gripper"]])
     xyz[:, NUM_ROBOT_POINTS + NUM_OBSTACLE_POINTS:, :3] = sampler.sample_end_effector(target_pose, NUM_TARGET_POINTS)
     np.random.set_state(state)
     out.update(q=q, q_norm=(q - lim[:, 0]) / (lim[:, 1] - lim[:, 0]) * 2 - 1, xyz=xyz, target_pose=target_pose,
-               target_position=target_pose[:, :3, 3].contiguous(), robot_subset=subset)
+               target_position=target_pose[:, :3, 3].contiguous(), robot_subset=subset, env_offset=int(env_offset))
     return out

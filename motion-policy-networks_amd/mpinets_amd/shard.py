@@ -20,10 +20,16 @@ def world() -> Tuple[int, int, int]:
     return int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
 
 
-def init(backend: Optional[str] = None) -> Tuple[int, int, int]:
-    """Join the job torchrun started (no-op for a single process).  Backend: RCCL ("nccl") when GPUs
-    are present, gloo otherwise; ``MPX_DIST_BACKEND`` overrides (tests run 2 ranks on one GPU with gloo)."""
+def init(backend: Optional[str] = None, device: Optional[torch.device] = None) -> Tuple[int, int, int]:
+    """Join the job torchrun started (no-op for a single process) and make this rank's GPU the current device --
+    for EVERY backend: the engine enqueues on torch's current stream of the current device, so a gloo job that
+    skipped ``set_device`` would put every rank's kernels on device 0.  ``device`` defaults to
+    ``cuda:LOCAL_RANK``.  Backend: RCCL ("nccl") when GPUs are present, gloo otherwise; ``MPX_DIST_BACKEND``
+    overrides (tests run 2 ranks on one GPU with gloo)."""
     rank, ws, local = world()
+    if torch.cuda.is_available():
+        device = torch.device("cuda", local) if device is None else torch.device(device)
+        torch.cuda.set_device(device)
     if ws > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
@@ -32,8 +38,7 @@ def init(backend: Optional[str] = None) -> Tuple[int, int, int]:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         kwargs = {}
         if backend == "nccl":
-            torch.cuda.set_device(local)
-            kwargs["device_id"] = torch.device("cuda", local)
+            kwargs["device_id"] = device
         dist.init_process_group(backend, rank=rank, world_size=ws, **kwargs)
     return rank, ws, local
 

@@ -491,9 +491,9 @@ static int orc_cmp_u64_fwd(const void *a, const void *b) {
 
 /* assign uint16 [B,N]; labels uint8 [B,M1+M2]; n_obstacles int32 [B] */
 ORC_API void orc_scene_assign(const float *cub_dims, int M1, const float *cyl_radii, const float *cyl_heights,
-                              int M2, int B, int N, uint64_t seed, uint16_t *assign, uint8_t *labels,
-                              int32_t *n_obstacles) {
-  const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+                              int M2, int B, int N, uint64_t seed, int64_t env_offset, uint16_t *assign,
+                              uint8_t *labels, int32_t *n_obstacles) {
+  const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32), env0 = (uint32_t)env_offset;
   const int M = M1 + M2;
   uint32_t *rem = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(M > 0 ? M : 1));
   for (int b = 0; b < B; ++b) {
@@ -526,7 +526,7 @@ ORC_API void orc_scene_assign(const float *cub_dims, int M1, const float *cyl_ra
     for (int m = M - 1; m >= 0 && i > 0; --m) {
       if (!rem[m]) continue;
       uint32_t r[4];
-      orc_philox(ctr++, (uint32_t)b, 2u, 0u, k0, k1, r);
+      orc_philox(ctr++, env0 + (uint32_t)b, 2u, 0u, k0, k1, r);
       int jpos = (int)(((uint64_t)r[0] * (uint32_t)(i + 1)) >> 32);
       int t = -1;
       for (int mm = 0; mm < M; ++mm)
@@ -544,7 +544,7 @@ ORC_API void orc_scene_assign(const float *cub_dims, int M1, const float *cyl_ra
       uint64_t *keys = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)pool);
       for (uint32_t s = 0; s < pool; ++s) {
         uint32_t r[4];
-        orc_philox(s >> 2, (uint32_t)b, 1u, 0u, k0, k1, r); /* one block keys four consecutive slots */
+        orc_philox(s >> 2, env0 + (uint32_t)b, 1u, 0u, k0, k1, r); /* one block keys four consecutive slots */
         keys[s] = ((uint64_t)r[s & 3] << 32) | s;
       }
       qsort(keys, (size_t)pool, sizeof(uint64_t), orc_cmp_u64_fwd);
@@ -563,8 +563,9 @@ ORC_API void orc_scene_assign(const float *cub_dims, int M1, const float *cyl_ra
 /* out [B,N,3]: one uniform surface sample per assigned obstacle id */
 ORC_API void orc_scene_points(const float *cub_c, const float *cub_d, const float *cub_q, int M1,
                               const float *cyl_c, const float *cyl_r, const float *cyl_h, const float *cyl_q,
-                              int M2, int B, int N, uint64_t seed, const uint16_t *assign, float *out) {
-  const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+                              int M2, int B, int N, uint64_t seed, int64_t env_offset, const uint16_t *assign,
+                              float *out) {
+  const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32), env0 = (uint32_t)env_offset;
   for (int b = 0; b < B; ++b)
     for (int j = 0; j < N; ++j) {
       float *o = out + ((size_t)b * N + j) * 3;
@@ -574,7 +575,7 @@ ORC_API void orc_scene_points(const float *cub_c, const float *cub_d, const floa
         continue;
       }
       uint32_t r[4];
-      orc_philox((uint32_t)j, (uint32_t)b, 3u, 0u, k0, k1, r);
+      orc_philox((uint32_t)j, env0 + (uint32_t)b, 3u, 0u, k0, k1, r);
       float u0 = orc_u01(r[0]), u1 = orc_u01(r[1]), u2 = orc_u01(r[2]), u3 = orc_u01(r[3]);
       float lx, ly, lz;
       const float *ctr, *q;
@@ -811,7 +812,9 @@ static int orc_cmp_u64(const void *a, const void *b) {
 
 /* out [B, n_out, 3]; count [B] = valid pixels; an environment with fewer than n_out valid pixels is left untouched */
 ORC_API void orc_depth_select(const float *depth, const float *cam, float fx, float fy, float cx, float cy, int W,
-                              int H, int B, int n_out, uint32_t k0, uint32_t k1, float *out, int32_t *count) {
+                              int H, int B, int n_out, uint32_t k0, uint32_t k1, int64_t env_offset, float *out,
+                              int32_t *count) {
+  const uint32_t env0 = (uint32_t)env_offset;
   uint64_t *keys = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)W * H);
   for (int b = 0; b < B; ++b) {
     const float *dp = depth + (size_t)b * W * H, *P = cam + 16 * (size_t)b;
@@ -819,7 +822,7 @@ ORC_API void orc_depth_select(const float *depth, const float *cam, float fx, fl
     for (int pix = 0; pix < W * H; ++pix) {
       if (dp[pix] < 0.0f) continue;
       uint32_t r[4];
-      orc_philox((uint32_t)(pix >> 2), (uint32_t)b, 9u, 0u, k0, k1, r); /* one block keys four consecutive pixels */
+      orc_philox((uint32_t)(pix >> 2), env0 + (uint32_t)b, 9u, 0u, k0, k1, r); /* one block keys four consecutive pixels */
       keys[n++] = ((uint64_t)r[pix & 3] << 32) | (uint32_t)pix;
     }
     count[b] = n;

@@ -168,9 +168,10 @@ def philox4x32(ctr, key) -> np.ndarray:
     return out
 
 
-def scene_cloud(scn: dict, num_points: int, seed: int):
+def scene_cloud(scn: dict, num_points: int, seed: int, env_offset: int = 0):
     """Restatement of csrc/scene.hip.  scn: cuboid_{centers,dims,quats}, cylinder_{centers,radii,heights,quats}.
-    -> points float32 [B,N,3], assign uint16 [B,N], labels uint8 [B,M1+M2], n_obstacles int32 [B]."""
+    -> points float32 [B,N,3], assign uint16 [B,N], labels uint8 [B,M1+M2], n_obstacles int32 [B].
+    Row b draws as GLOBAL environment ``env_offset + b`` (Philox counter word 1)."""
     cc, cd, cq = _f(scn["cuboid_centers"]), _f(scn["cuboid_dims"]), _f(scn["cuboid_quats"])
     yc, yr, yh, yq = (_f(scn["cylinder_centers"]), _f(scn["cylinder_radii"]), _f(scn["cylinder_heights"]),
                       _f(scn["cylinder_quats"]))
@@ -179,11 +180,11 @@ def scene_cloud(scn: dict, num_points: int, seed: int):
     assign = np.empty((B, num_points), np.uint16)
     labels = np.zeros((B, M1 + M2), np.uint8)
     nobs = np.zeros(B, np.int32)
-    lib().orc_scene_assign(_p(cd), M1, _p(yr), _p(yh), M2, B, num_points, ctypes.c_uint64(seed), _p(assign),
-                           _p(labels), _p(nobs))
+    lib().orc_scene_assign(_p(cd), M1, _p(yr), _p(yh), M2, B, num_points, ctypes.c_uint64(seed),
+                           ctypes.c_int64(env_offset), _p(assign), _p(labels), _p(nobs))
     pts = np.empty((B, num_points, 3), np.float32)
     lib().orc_scene_points(_p(cc), _p(cd), _p(cq), M1, _p(yc), _p(yr), _p(yh), _p(yq), M2, B, num_points,
-                           ctypes.c_uint64(seed), _p(assign), _p(pts))
+                           ctypes.c_uint64(seed), ctypes.c_int64(env_offset), _p(assign), _p(pts))
     return pts, assign, labels, nobs
 
 
@@ -231,23 +232,26 @@ def depth_render(cam_poses, intr, W, H, cub, cyl, sph_centers=None, sph_radii=No
     return depth
 
 
-def depth_select(depth, cam_poses, intr, W, H, n_out: int, seed: int):
+def depth_select(depth, cam_poses, intr, W, H, n_out: int, seed: int, env_offset: int = 0):
     cam = _f(cam_poses).reshape(-1, 16)
     B = cam.shape[0]
     out = np.zeros((B, n_out, 3), np.float32)
     count = np.zeros(B, np.int32)
     c = ctypes.c_float
     lib().orc_depth_select(_p(_f(depth)), _p(cam), c(intr[0]), c(intr[1]), c(intr[2]), c(intr[3]), W, H, B, n_out,
-                           ctypes.c_uint32(seed & 0xFFFFFFFF), ctypes.c_uint32((seed >> 32) & 0xFFFFFFFF), _p(out),
-                           _p(count))
+                           ctypes.c_uint32(seed & 0xFFFFFFFF), ctypes.c_uint32((seed >> 32) & 0xFFFFFFFF),
+                           ctypes.c_int64(env_offset), _p(out), _p(count))
     return out, count
 
 
 # ---------------------------------------------------------------- batch assembly (row N2)
-def batch_configs(traj, traj_idx, timestep, limits, noise_scale: float = 0.0, seed: int = 0, finger: float = 0.025):
+def batch_configs(traj, traj_idx, timestep, limits, noise_scale: float = 0.0, seed: int = 0, finger: float = 0.025,
+                  sample_offset: int = 0, train: Optional[bool] = None):
     """Restates the joint part of PointCloudBase.get_inputs (data_loader.py:155-185) + the supervision row of
     PointCloudInstanceDataset.__getitem__ (:403-417) for a list of samples; noise = Box-Muller on Philox4x32-10
-    blocks (counter (blk, sample, 7, 0), key = seed), the engine's documented generator."""
+    blocks (counter (blk, sample_offset + sample, 7, 0), key = seed), the engine's documented generator.  ``train``
+    (default: noise_scale > 0): clamp to the limits like every TRAIN sample (data_loader.py:176-178)."""
+    train = noise_scale > 0 if train is None else train
     traj, lim = _f(traj), _f(limits)
     L = traj.shape[1]
     B = len(traj_idx)
@@ -263,14 +267,16 @@ def batch_configs(traj, traj_idx, timestep, limits, noise_scale: float = 0.0, se
         if noise_scale > 0:
             z = np.empty(8, np.float32)
             for blk in range(2):
-                r = philox4x32([blk, b, 7, 0], [seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF])
+                r = philox4x32([blk, sample_offset + b, 7, 0], [seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF])
                 for pr in range(2):
                     u1 = np.float32(1.0) - np.float32(r[2 * pr] >> 8) * np.float32(2.0 ** -24)
                     u2 = np.float32(r[2 * pr + 1] >> 8) * np.float32(2.0 ** -24)
                     rad = np.sqrt(np.float32(-2.0) * np.log(u1, dtype=np.float32), dtype=np.float32)
                     s_, c_ = (float(v[0]) for v in sincos(np.array([np.float32(6.28318530717958647692) * u2], np.float32)))
                     z[4 * blk + 2 * pr], z[4 * blk + 2 * pr + 1] = rad * c_, rad * s_
-            v = np.minimum(np.maximum(np.float32(noise_scale) * z[:7] + v, lo), hi).astype(np.float32)
+            v = (np.float32(noise_scale) * z[:7] + v).astype(np.float32)
+        if train:
+            v = np.minimum(np.maximum(v, lo), hi).astype(np.float32)
         q[b], sup[b], fin[b] = v, traj[ti, ts], traj[ti, L - 1]
     norm = lambda x: ((x - lo) / (hi - lo) * np.float32(2.0) + np.float32(-1.0)).astype(np.float32)
     T = franka_fk(fin, finger)

@@ -51,6 +51,45 @@ def test_two_rank_shard_equals_single_rank(tmp_path):
     np.testing.assert_array_equal(f, (ids % 3 == 0).astype(np.int32))
 
 
+def _scene_worker(rank, world, port, per_rank, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from mpinets_amd import shard
+    from mpinets_amd.scenes import make_scenes
+    from oracle import oracle as orc
+
+    orc.build()
+    r, w, _ = shard.init(backend="gloo")
+    ids = shard.env_range(r, w, per_rank)
+    scn = make_scenes(world * per_rank, 3, ("tabletop", "cubby", "dresser"), 40, 16)  # same seed on every rank
+    mine = {k: v[ids.start:ids.stop] for k, v in scn.items()}
+    pts, assign, labels, _ = orc.scene_cloud(mine, 512, 77, env_offset=ids.start)  # keyed by the GLOBAL env id
+    p_all = shard.gather_to_rank0(torch.from_numpy(pts))
+    a_all = shard.gather_to_rank0(torch.from_numpy(assign.astype(np.int32)))
+    if r == 0:
+        np.save(os.path.join(out_dir, "p.npy"), p_all.numpy())
+        np.save(os.path.join(out_dir, "a.npy"), a_all.numpy())
+    shard.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_sharded_scene_draw_equals_unsharded(tmp_path, oracle):
+    """The per-environment random draws of the step are keyed by the global environment id (env_offset of
+    mpx_scene_cloud, restated by the oracle): two ranks' gathered draws == one process's draw, bit for bit.
+    (The same statement on the real engine, on the GPU: tests/test_gpu_shard.py.)"""
+    from mpinets_amd.scenes import make_scenes
+
+    world, per_rank = 2, 3
+    mp.spawn(_scene_worker, args=(world, _free_port(), per_rank, str(tmp_path)), nprocs=world, join=True)
+    scn = make_scenes(world * per_rank, 3, ("tabletop", "cubby", "dresser"), 40, 16)
+    pts, assign, _, _ = oracle.scene_cloud(scn, 512, 77)
+    np.testing.assert_array_equal(np.load(tmp_path / "p.npy"), pts)
+    np.testing.assert_array_equal(np.load(tmp_path / "a.npy"), assign.astype(np.int32))
+    # and the offset matters: the second shard drawn with offset 0 differs
+    other, _, _, _ = oracle.scene_cloud({k: v[per_rank:] for k, v in scn.items()}, 512, 77)
+    assert not np.array_equal(other, pts[per_rank:])
+
+
 def test_split_even_covers_everything():
     from mpinets_amd.shard import env_range, split_even
 
