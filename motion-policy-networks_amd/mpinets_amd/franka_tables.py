@@ -61,6 +61,14 @@ DEFAULT_Q = np.array([0.00, -1.3, 0.00, -2.87, 0.00, 2.00, 0.75], dtype=np.float
 # /root/reference/config/franka_robot_description.yaml:51-53
 FINGER_OPENING = 0.025
 
+# /root/reference/config/franka_fabric_config.yaml:117-140: the Geometric-Fabrics self-collision model the batched
+# metrics use (csrc/franka.hip trajectory_metrics_kernel): the base body cylinder as a capped segment + radius, and the
+# spheres tested against it.  Of the fabric's seven named spheres the kernel uses the four that sit on frames the FK
+# produces (link7, hand, the two fingertips); panda_wrist_end_pt / panda_face_{left,right} are fabric-only task frames.
+FABRIC_BODY_CYLINDER = {"pt1": (0.0, 0.0, 0.333), "pt2": (0.0, 0.0, -0.3), "radius": 0.15}
+FABRIC_SELF_SPHERES = (("panda_link7", 0.1), ("panda_hand", 0.01), ("panda_leftfingertip", 0.01),
+                       ("panda_rightfingertip", 0.01))
+
 # Frame ids written by the FK kernel, in this order (15 frames x 3x4 row-major floats).
 LINK_NAMES: Tuple[str, ...] = (
     "panda_link0",
@@ -253,6 +261,23 @@ def link_point_table(total_points: int = 4096, with_base_link: bool = True):
         np.ascontiguousarray(np.concatenate(out_p), dtype=np.float32),
         np.ascontiguousarray(np.concatenate(out_l), dtype=np.int32),
     )
+
+
+def load_point_tables(path: str):
+    """Tables written by ``tools/dump_robofin_tables.py`` (run where robofin is installed) -> the arguments the
+    samplers accept: ``{"point_table": (points [P,3], link_ids [P]), "joint_limits_real": [7,2], ...}``.
+    ``FrankaSampler(device, point_table=load_point_tables(p)["point_table"])`` then samples robofin's own mesh points."""
+    d = np.load(path, allow_pickle=False)
+    names = [str(n) for n in d["point_link_name"]]
+    unknown = sorted(set(names) - set(LINK_ID))
+    if unknown:
+        raise ValueError(f"{path}: links {unknown} are not frames of the FK kernel ({LINK_NAMES})")
+    out = {"point_table": (np.ascontiguousarray(d["points"], dtype=np.float32),
+                           np.asarray([LINK_ID[n] for n in names], dtype=np.int32))}
+    for k in ("joint_limits_real", "joint_limits_published"):
+        if k in d.files:
+            out[k] = np.asarray(d[k], dtype=np.float64)
+    return out
 
 
 @functools.lru_cache(maxsize=2)
