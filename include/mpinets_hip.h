@@ -10,7 +10,8 @@
  * Conventions
  *   - every pointer is a DEVICE pointer unless marked "host"; plain C types only;
  *   - all tensors are dense, row-major, float32 / int32; "stride" arguments count floats;
- *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls only enqueue;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls only enqueue (the first launch of
+ *     a large-LDS kernel on a device also raises that kernel's LDS limit, once);
  *   - return 0 on success, non-zero on error (mpx_last_error() gives the text, per thread);
  *   - no call allocates or frees device memory, so every call is hipGraph-capturable
  *     (exception: none).
@@ -257,7 +258,7 @@ int mpx_scene_cloud(const float *cub_centers, const float *cub_dims, const float
 /* furthest_point_sample (+ gather_operation): xyz rows at xyz + (b*N + k)*stride, first three
  * floats used.  idx int32 [B,npoint]; new_xyz (optional) rows at
  * new_xyz + (b*npoint + j)*new_stride.  Index semantics follow pointnet2_ops v3.2.0 exactly
- * (start 0, |p|^2 <= 1e-3 skipped, block-size-dependent tie order).  N <= 16384.           */
+ * (start 0, float |p|^2 <= the double 1e-3 skipped, block-size-dependent tie order).  N <= 8192.  */
 int mpx_fps(const float *xyz, int B, int N, int stride, int npoint, int32_t *idx, float *new_xyz,
             int new_stride, mpx_stream_t stream);
 
@@ -381,7 +382,8 @@ int mpx_append_columns(const float *src, int src_stride, int ncols, int nzero, i
  * For callers without Python (a native planning node): slab + joint configuration in, displacement out.  Host-side
  * orchestration of the kernels above in the order and shapes of mpinets_amd/model.py, whose fp32 output it
  * reproduces bit for bit; the caller's stream (for B <= 512 also an internal second stream, forked and joined with
- * events -- hipGraph-capturable), no allocation, no synchronisation.
+ * events -- hipGraph-capturable; concurrent calls from several host threads on one device are safe: the internal
+ * stream is held exclusively from fork to join), no allocation, no synchronisation.
  *
  * Weights: device pointers, fp32, [out, in] row-major like nn.Linear / 1x1 Conv2d, prepared once:
  *   sa1_pack, sa2_pack   mpx_sa_pack_weights of SA_modules.{0,1} (C = 1 and 64)
@@ -408,7 +410,7 @@ int64_t mpx_policy_workspace(int B, int N);
 int mpx_policy_forward(const mpx_policy_weights *w, const float *xyz, int N, const float *q, int B,
                        float *dq, void *workspace, int64_t workspace_bytes, mpx_stream_t stream);
 
-/* ---- one closed-loop step in one call: TrainingMotionPolicyNetwork.rollout's loop body (model.py:160-181) plus the
+/* ---- closed-loop steps in one call: TrainingMotionPolicyNetwork.rollout's loop body (model.py:160-181) plus the
  * collision check of validation_step (model.py:293-314), i.e. what mpinets_amd.rollout.RolloutEngine.step() does
  * with a static scene:  dq = policy(xyz, q_norm);  q_norm = clamp(q_norm + dq, -1, 1);  q = unnormalise(q_norm);
  * robot rows of the slab <- FK cloud of q;  flags = any collision sphere of q inside a primitive.
@@ -429,10 +431,43 @@ typedef struct mpx_rollout_scene {
   int M2;
 } mpx_rollout_scene;
 
-/* workspace bytes (256-byte aligned) of mpx_rollout_step */
+/* What a multi-step rollout does besides the plain step (all optional; a zeroed struct with steps = 1 is
+ * mpx_rollout_step): the engine-side form of rollout_until_success's loop body (run_inference.py:171-189) and of
+ * the "closed-loop point-cloud re-render" workload.                                                              */
+typedef struct mpx_rollout_options {
+  int steps;                      /* closed-loop steps to enqueue (no host synchronisation in between)            */
+  int first_step;                 /* index of the first of them: the re-render seed schedule continues an earlier call */
+  /* scene re-render at the start of every step (n_scene = 0: the scene rows of the slab stay as they are):
+   * n_scene points per environment drawn from the scene's primitives by mpx_scene_cloud with seed
+   * scene_seed + 7919 * step and global environment ids env_offset + row, written to slab rows
+   * [n_robot, n_robot + n_scene).  Needs the primitives' raw poses beside the frames in mpx_rollout_scene.      */
+  int n_scene;
+  uint64_t scene_seed;
+  int64_t env_offset;
+  const float *cub_centers, *cub_quats;   /* [B,M1,3], [B,M1,4] (w,x,y,z) */
+  const float *cyl_centers, *cyl_quats;   /* [B,M2,3], [B,M2,4]           */
+  /* success tracking (target_poses = NULL: off): after every joint update, environments whose right_gripper is
+   * within pos_tol metres and cos_rot_tol (cosine of the angle) of target_poses [B,4,4] set done[b] (int32 [B],
+   * zeroed by the caller before the first call) and keep their configuration from then on; steps_taken (optional,
+   * int32 [B], zeroed by the caller) counts the policy steps each environment took until it was done.          */
+  const float *target_poses;
+  float pos_tol, cos_rot_tol;
+  int32_t *done, *steps_taken;
+  /* optional [B, trajectory_len, 7]: waypoint trajectory_row + i of every environment receives q after step i of
+   * this call (row 0 is normally the caller's start configuration, so the first call passes trajectory_row = 1)  */
+  float *trajectory;
+  int trajectory_len, trajectory_row;
+} mpx_rollout_options;
+
+/* workspace bytes (256-byte aligned) of mpx_rollout / mpx_rollout_step */
 int64_t mpx_rollout_workspace(int B, int N);
-/* xyz [B,N,4] slab (robot rows rewritten in place), q_norm [B,7] in/out, q [B,7] out (radians), flags int32 [B] out
- * (non-zero: in collision), min_sdf [B, n_spheres] out or NULL.                                                   */
+/* xyz [B,N,4] slab (robot rows -- and scene rows when re-rendering -- rewritten in place), q_norm [B,7] in/out,
+ * q [B,7] out (radians), flags int32 [B] OR-ed into (non-zero: some step's configuration was in collision),
+ * min_sdf [B, n_spheres] out or NULL (last step's).  Bit-identical to RolloutEngine.step() called `steps` times.  */
+int mpx_rollout(const mpx_policy_weights *w, const mpx_rollout_scene *scene, const mpx_rollout_options *options,
+                float *xyz, int N, float *q_norm, float *q, int B, int32_t *flags, float *min_sdf, void *workspace,
+                int64_t workspace_bytes, mpx_stream_t stream);
+/* one plain step (static scene, no success tracking): mpx_rollout with a zeroed options struct and steps = 1 */
 int mpx_rollout_step(const mpx_policy_weights *w, const mpx_rollout_scene *scene, float *xyz, int N,
                      float *q_norm, float *q, int B, int32_t *flags, float *min_sdf, void *workspace,
                      int64_t workspace_bytes, mpx_stream_t stream);

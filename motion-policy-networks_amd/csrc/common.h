@@ -1,6 +1,8 @@
 // common.h -- shared host/device helpers for libmpinets_hip.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include <atomic>
 #include <stdint.h>
 #include <stdio.h>
 
@@ -17,6 +19,23 @@ void mpx_set_error(const char *fmt, ...);
       mpx_set_error(__VA_ARGS__);     \
       return 1;                       \
     }                                 \
+  } while (0)
+
+// Raises a kernel's dynamic-LDS limit to `bytes` (its largest supported launch) ONCE per (kernel, device): the first
+// launch on a device pays the hipFuncSetAttribute, later calls only enqueue.  One static mask per expansion site, so
+// use it once per kernel instantiation.
+#define MPX_LDS_LIMIT_ONCE(kernel, bytes, what)                                                                \
+  do {                                                                                                         \
+    static std::atomic<unsigned long long> lds_done_{0};                                                       \
+    int dev_ = 0;                                                                                              \
+    (void)hipGetDevice(&dev_);                                                                                 \
+    const unsigned long long bit_ = 1ull << (dev_ & 63);                                                       \
+    if (!(lds_done_.load(std::memory_order_acquire) & bit_)) {                                                 \
+      hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),                              \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes));           \
+      MPX_REQUIRE(e_ == hipSuccess, "%s: cannot reserve %d B of LDS: %s", what, (int)(bytes), hipGetErrorString(e_)); \
+      lds_done_.fetch_or(bit_, std::memory_order_release);                                                     \
+    }                                                                                                          \
   } while (0)
 
 #define MPX_LAUNCH_CHECK(name)                                              \

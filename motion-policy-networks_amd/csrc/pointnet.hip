@@ -166,6 +166,9 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PTS <
   }
 }
 
+constexpr int FPS_MAX_N = 8192;                         // 512 threads x 16 points (include/mpinets_hip.h says the same)
+constexpr int FPS_MAX_LDS = 256 + 3 * FPS_MAX_N * 4;    // the cloud copy of the largest supported launch
+
 static int opt_n_threads_log2(int n) {
   int l = 0;
   while ((2 << l) <= n && (2 << l) <= 512) ++l;
@@ -175,7 +178,7 @@ static int opt_n_threads_log2(int n) {
 MPX_EXPORT int mpx_fps(const float *xyz, int B, int N, int stride, int npoint, int32_t *idx, float *new_xyz,
                        int new_stride, mpx_stream_t stream) {
   MPX_REQUIRE(B >= 0 && N >= 1 && npoint >= 0 && stride >= 3, "mpx_fps: bad size");
-  MPX_REQUIRE(N <= 8192, "mpx_fps: N = %d > 8192 unsupported", N);
+  MPX_REQUIRE(N <= FPS_MAX_N, "mpx_fps: N = %d > %d unsupported", N, FPS_MAX_N);
   MPX_REQUIRE(new_xyz == nullptr || new_stride >= 3, "mpx_fps: new_stride < 3");
   if (B == 0 || npoint == 0) return 0;
   const int log2bs = opt_n_threads_log2(N);
@@ -187,11 +190,7 @@ MPX_EXPORT int mpx_fps(const float *xyz, int B, int N, int stride, int npoint, i
   dim3 g(B), t(block);
 #define FPS_LAUNCH(P)                                                                                     \
   do {                                                                                                    \
-    if (lds > 64 * 1024) {                                                                                \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(fps_kernel<P>),                   \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
-      MPX_REQUIRE(e == hipSuccess, "mpx_fps: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e)); \
-    }                                                                                                     \
+    if (lds > 64 * 1024) MPX_LDS_LIMIT_ONCE(fps_kernel<P>, FPS_MAX_LDS, "mpx_fps");                       \
     hipLaunchKernelGGL(fps_kernel<P>, g, t, lds, mpx_s(stream), xyz, N, stride, npoint, log2bs, idx,      \
                        new_xyz, new_stride);                                                              \
   } while (0)
@@ -593,9 +592,7 @@ MPX_EXPORT int mpx_ball_query(const float *new_xyz, int new_stride, const float 
     const size_t lds = (size_t)3 * N * 4 + (size_t)BQG * BQG * 4 + (size_t)(BQG * BQG + 2) * 2 +
                        (size_t)((N + 1) & ~1) * 2 + (size_t)((npoint + 1) & ~1) * 2 * 2 + (size_t)npoint * BQ_HC * 2;
     if (lds <= 158 * 1024) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ball_query_grid_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      MPX_REQUIRE(e == hipSuccess, "mpx_ball_query: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
+      MPX_LDS_LIMIT_ONCE(ball_query_grid_kernel, 158 * 1024, "mpx_ball_query");
       const float inv_h = 1.0f / (radius * 1.0001f);
       hipLaunchKernelGGL(ball_query_grid_kernel, dim3(B), dim3(BQG_THREADS), lds, mpx_s(stream), new_xyz, new_stride, xyz,
                          stride, N, npoint, r2, inv_h, nsample, idx, cnt);

@@ -70,22 +70,41 @@ struct Buffers {
 
 int64_t max_i64(int64_t a, int64_t b) { return a > b ? a : b; }
 
+// Buffers whose lifetimes do not overlap share memory (all on the caller's stream, in launch order):
+//   region A: nbr1 (SA1's neighbour lists, dead after SA1's MLP) -> pre (SA2's per-point first-layer rows, dead after
+//             SA2's MLP) -> h_a (group-all hidden rows);
+//   region B: [f1 | ctr | nbr2] (dead after SA2's MLP) -> h_b.
+// 0.74 MB per environment instead of 1.5 MB (6 GB instead of 12 GB at 8192 environments).
 int64_t carve(char *base, int B, int N, Buffers &bu) {
   Carver c{base};
   const int64_t b = B;
   bu.idx1 = c.take<int32_t>(b * NP1);
   bu.xyz1 = c.take<float>(b * NP1 * 3);
-  bu.nbr1 = c.take<int32_t>(b * NP1 * NS);
   bu.cnt1 = c.take<int32_t>(b * NP1);
-  bu.f1 = c.take<float>(b * NP1 * F1);
   bu.sa3_in = c.take<float>(b * NP2 * K3);
   bu.idx2 = c.take<int32_t>(b * NP2);
-  bu.nbr2 = c.take<int32_t>(b * NP2 * NS);
   bu.cnt2 = c.take<int32_t>(b * NP2);
-  bu.pre = c.take<float>(b * NP1 * 128);
-  bu.ctr = c.take<float>(b * NP2 * 128);
-  bu.h_a = c.take<float>(b * NP2 * (B <= 8 ? C3 : H3));  // (a handful of problems: also the unpooled last layer)
-  bu.h_b = c.take<float>(b * NP2 * H3);
+  {  // region A
+    const int64_t start = c.used;
+    bu.nbr1 = c.take<int32_t>(b * NP1 * NS);
+    const int64_t end_nbr1 = c.used;
+    c.used = start;
+    bu.pre = c.take<float>(b * NP1 * 128);
+    const int64_t end_pre = c.used;
+    c.used = start;
+    bu.h_a = c.take<float>(b * NP2 * (B <= 8 ? C3 : H3));  // (a handful of problems: also the unpooled last layer)
+    c.used = max_i64(max_i64(end_nbr1, end_pre), c.used);
+  }
+  {  // region B
+    const int64_t start = c.used;
+    bu.f1 = c.take<float>(b * NP1 * F1);
+    bu.ctr = c.take<float>(b * NP2 * 128);
+    bu.nbr2 = c.take<int32_t>(b * NP2 * NS);
+    const int64_t end_inputs = c.used;
+    c.used = start;
+    bu.h_b = c.take<float>(b * NP2 * H3);
+    c.used = max_i64(end_inputs, c.used);
+  }
   bu.pooled = c.take<float>(b * C3);
   bu.fc_a = c.take<float>(b * 4096);
   bu.fc_b = c.take<float>(b * 2048);
@@ -109,11 +128,16 @@ int64_t carve(char *base, int B, int N, Buffers &bu) {
 // Small batches cannot fill the chip with any single kernel (FPS is one workgroup per problem), so two independent
 // branches -- SA2's sampling + ball query and the joint-angle encoder -- are issued on a second stream beside SA1's
 // ball query + grouped MLP, forked and joined with events (the same split as model.py's; a fork / join like this is
-// hipGraph-capturable).  One stream + two events per device, created on first use.
+// hipGraph-capturable).  One stream + two events per device, created on first use.  A caller holds the device's
+// Side EXCLUSIVELY from its fork record to its join wait (`busy`): two host threads driving the same device from
+// different streams can therefore never re-record each other's fork / join events between a record and the wait that
+// consumes it (a stream wait captures the event's state at the time of the call, so re-use after the join wait has
+// been enqueued is safe; the side stream itself is in order).
 constexpr int OVERLAP_MAX_BATCH = 512;
 struct Side {
   hipStream_t stream = nullptr;
   hipEvent_t fork = nullptr, join = nullptr;
+  std::mutex busy;
 };
 Side *side_of_current_device() {
   static std::mutex mu;
@@ -201,6 +225,7 @@ MPX_EXPORT int mpx_policy_forward(const mpx_policy_weights *w, const float *xyz,
   MPX_TRY(mpx_fps(xyz, B, N, 4, NP1, bu.idx1, bu.xyz1, 3, stream));
   Side *side = B <= OVERLAP_MAX_BATCH ? side_of_current_device() : nullptr;
   if (side) {
+    std::lock_guard<std::mutex> exclusive(side->busy);  // fork .. join of one call at a time per device
     hipError_t e = hipEventRecord(side->fork, st);
     if (e == hipSuccess) e = hipStreamWaitEvent(side->stream, side->fork, 0);
     MPX_REQUIRE(e == hipSuccess, "mpx_policy_forward: stream fork failed: %s", hipGetErrorString(e));
@@ -244,28 +269,73 @@ MPX_EXPORT int mpx_policy_forward(const mpx_policy_weights *w, const float *xyz,
   MPX_LAUNCH_CHECK("mpx_policy_forward");
 }
 
-// ---- one closed-loop step (RolloutEngine.step with a static scene) ---------------------------------------------
+// ---- closed-loop rollouts: RolloutEngine.step() / .rollout() / the body of rollout_until_success -----------------
+namespace {
+int64_t pad256(int64_t n) { return (n + 255) / 256 * 256; }
+}  // namespace
+
 MPX_EXPORT int64_t mpx_rollout_workspace(int B, int N) {
   if (B <= 0 || N <= 0) return 0;
-  return mpx_policy_workspace(B, N) + ((int64_t)B * 7 * (int64_t)sizeof(float) + 255) / 256 * 256;
+  // policy workspace | dq [B,7] | obstacle ids of a scene re-render [B, N] uint16 (at most N scene rows)
+  return mpx_policy_workspace(B, N) + pad256((int64_t)B * 7 * (int64_t)sizeof(float)) + pad256((int64_t)B * N * 2);
+}
+
+MPX_EXPORT int mpx_rollout(const mpx_policy_weights *w, const mpx_rollout_scene *sc, const mpx_rollout_options *opt,
+                           float *xyz, int N, float *q_norm, float *q, int B, int32_t *flags, float *min_sdf,
+                           void *workspace, int64_t workspace_bytes, mpx_stream_t stream) {
+  MPX_REQUIRE(w && sc && opt && xyz && q_norm && q && flags, "mpx_rollout: NULL operand");
+  MPX_REQUIRE(sc->n_robot >= 1 && sc->n_robot <= N, "mpx_rollout: n_robot = %d outside [1, N]", sc->n_robot);
+  MPX_REQUIRE(opt->steps >= 0 && opt->first_step >= 0, "mpx_rollout: negative step count");
+  const bool rerender = opt->n_scene > 0;
+  if (rerender) {
+    MPX_REQUIRE(sc->n_robot + opt->n_scene <= N, "mpx_rollout: %d robot + %d scene rows exceed the slab's %d", sc->n_robot,
+                opt->n_scene, N);
+    MPX_REQUIRE(opt->cub_centers && opt->cub_quats && opt->cyl_centers && opt->cyl_quats,
+                "mpx_rollout: a scene re-render needs the primitives' centres and quaternions");
+  }
+  MPX_REQUIRE(!opt->target_poses || opt->done, "mpx_rollout: success tracking needs the done flags");
+  MPX_REQUIRE(!opt->trajectory || (opt->trajectory_row >= 0 && opt->trajectory_len >= opt->trajectory_row + opt->steps),
+              "mpx_rollout: trajectory rows hold %d waypoints, rows [%d, %d) are written", opt->trajectory_len,
+              opt->trajectory_row, opt->trajectory_row + opt->steps);
+  if (B == 0 || opt->steps == 0) return 0;
+  const int64_t need = mpx_rollout_workspace(B, N);
+  MPX_REQUIRE(workspace && workspace_bytes >= need, "mpx_rollout: workspace of %lld bytes, mpx_rollout_workspace asks for %lld",
+              (long long)workspace_bytes, (long long)need);
+  const int64_t policy_bytes = mpx_policy_workspace(B, N);
+  char *base = static_cast<char *>(workspace);
+  float *dq = reinterpret_cast<float *>(base + policy_bytes);
+  uint16_t *assign = reinterpret_cast<uint16_t *>(base + policy_bytes + pad256((int64_t)B * 7 * (int64_t)sizeof(float)));
+  for (int i = 0; i < opt->steps; ++i) {
+    const int step = opt->first_step + i;
+    if (rerender)  // a fresh scene cloud from the primitives (seed schedule of RolloutEngine: scene_seed + 7919 * step)
+      MPX_TRY(mpx_scene_cloud(opt->cub_centers, sc->cub_dims, opt->cub_quats, sc->M1, opt->cyl_centers, sc->cyl_radii,
+                              sc->cyl_heights, opt->cyl_quats, sc->M2, B, opt->n_scene,
+                              opt->scene_seed + 7919ull * (uint64_t)step, opt->env_offset, assign, nullptr, nullptr,
+                              xyz + (int64_t)sc->n_robot * 4, (int64_t)N * 4, 4, 0, stream));
+    MPX_TRY(mpx_policy_forward(w, xyz, N, q_norm, B, dq, workspace, policy_bytes, stream));
+    MPX_TRY(mpx_joint_step(q_norm, dq, sc->limits, B, q_norm, q, opt->target_poses ? opt->done : nullptr, stream));
+    if (opt->target_poses)  // 1 cm / 15 deg early-stop test (run_inference.py:176-187): finished environments freeze
+      MPX_TRY(mpx_franka_success(q, opt->target_poses, B, sc->finger, opt->pos_tol, opt->cos_rot_tol, opt->done,
+                                 opt->steps_taken, nullptr, nullptr, stream));
+    MPX_TRY(mpx_franka_cloud(q, B, sc->finger, sc->table_pts, sc->table_link, sc->subset, sc->n_robot, xyz, (int64_t)N * 4, 4,
+                             stream));
+    MPX_TRY(mpx_franka_collision(q, B, 1, sc->finger, sc->sph_centers, sc->sph_radii, sc->sph_link, sc->n_spheres,
+                                 sc->cub_frames, sc->cub_dims, sc->M1, sc->cyl_frames, sc->cyl_radii, sc->cyl_heights, sc->M2,
+                                 flags, min_sdf, stream));
+    if (opt->trajectory) {  // waypoint trajectory_row + i of every environment
+      hipError_t e = hipMemcpy2DAsync(opt->trajectory + (int64_t)(opt->trajectory_row + i) * 7, (size_t)opt->trajectory_len * 7 * sizeof(float),
+                                      q, 7 * sizeof(float), 7 * sizeof(float), (size_t)B, hipMemcpyDeviceToDevice,
+                                      mpx_s(stream));
+      MPX_REQUIRE(e == hipSuccess, "mpx_rollout: trajectory copy failed: %s", hipGetErrorString(e));
+    }
+  }
+  return 0;
 }
 
 MPX_EXPORT int mpx_rollout_step(const mpx_policy_weights *w, const mpx_rollout_scene *sc, float *xyz, int N, float *q_norm,
                                 float *q, int B, int32_t *flags, float *min_sdf, void *workspace, int64_t workspace_bytes,
                                 mpx_stream_t stream) {
-  MPX_REQUIRE(w && sc && xyz && q_norm && q && flags, "mpx_rollout_step: NULL operand");
-  MPX_REQUIRE(sc->n_robot >= 1 && sc->n_robot <= N, "mpx_rollout_step: n_robot = %d outside [1, N]", sc->n_robot);
-  if (B == 0) return 0;
-  const int64_t need = mpx_rollout_workspace(B, N);
-  MPX_REQUIRE(workspace && workspace_bytes >= need, "mpx_rollout_step: workspace of %lld bytes, mpx_rollout_workspace asks for %lld",
-              (long long)workspace_bytes, (long long)need);
-  const int64_t policy_bytes = mpx_policy_workspace(B, N);
-  float *dq = reinterpret_cast<float *>(static_cast<char *>(workspace) + policy_bytes);
-  MPX_TRY(mpx_policy_forward(w, xyz, N, q_norm, B, dq, workspace, policy_bytes, stream));
-  MPX_TRY(mpx_joint_step(q_norm, dq, sc->limits, B, q_norm, q, nullptr, stream));
-  MPX_TRY(mpx_franka_cloud(q, B, sc->finger, sc->table_pts, sc->table_link, sc->subset, sc->n_robot, xyz, (int64_t)N * 4, 4,
-                           stream));
-  return mpx_franka_collision(q, B, 1, sc->finger, sc->sph_centers, sc->sph_radii, sc->sph_link, sc->n_spheres, sc->cub_frames,
-                              sc->cub_dims, sc->M1, sc->cyl_frames, sc->cyl_radii, sc->cyl_heights, sc->M2, flags, min_sdf,
-                              stream);
+  mpx_rollout_options opt = {};
+  opt.steps = 1;
+  return mpx_rollout(w, sc, &opt, xyz, N, q_norm, q, B, flags, min_sdf, workspace, workspace_bytes, stream);
 }

@@ -76,6 +76,7 @@ PROTOTYPES = {
     "mpx_policy_forward": [P, P, I, P, I, P, P, L, P],
     "mpx_rollout_workspace": [I, I],
     "mpx_rollout_step": [P, P, P, I, P, P, I, P, P, P, L, P],
+    "mpx_rollout": [P, P, P, P, I, P, P, I, P, P, P, L, P],
 }
 RESTYPES = {"mpx_last_error": c_char_p, "mpx_sa_pack_size": c_int64, "mpx_sa_pack_bf16x3_size": c_int64,
             "mpx_linear_wgrad_scratch": c_int64, "mpx_linear_workspace": c_int64, "mpx_policy_workspace": c_int64, "mpx_rollout_workspace": c_int64}

@@ -121,11 +121,19 @@ class RolloutEngine:
                     ("M1", ctypes.c_int), ("cyl_frames", ctypes.c_void_p), ("cyl_radii", ctypes.c_void_p),
                     ("cyl_heights", ctypes.c_void_p), ("M2", ctypes.c_int)]
 
+    class _NativeOptions(ctypes.Structure):  # field order = struct mpx_rollout_options (include/mpinets_hip.h)
+        _fields_ = [("steps", ctypes.c_int), ("first_step", ctypes.c_int), ("n_scene", ctypes.c_int),
+                    ("scene_seed", ctypes.c_uint64), ("env_offset", ctypes.c_int64), ("cub_centers", ctypes.c_void_p),
+                    ("cub_quats", ctypes.c_void_p), ("cyl_centers", ctypes.c_void_p), ("cyl_quats", ctypes.c_void_p),
+                    ("target_poses", ctypes.c_void_p), ("pos_tol", ctypes.c_float), ("cos_rot_tol", ctypes.c_float),
+                    ("done", ctypes.c_void_p), ("steps_taken", ctypes.c_void_p), ("trajectory", ctypes.c_void_p),
+                    ("trajectory_len", ctypes.c_int), ("trajectory_row", ctypes.c_int)]
+
     @torch.no_grad()
-    def step_native(self) -> torch.Tensor:
-        """``step()`` as ONE call of ``mpx_rollout_step`` (static scene, fp32, no success tracking): same kernels,
-        same order, bit-identical state."""
-        assert not self.rerender_scene and self.done is None
+    def run_native(self, steps: int = 1, trajectory: Optional[torch.Tensor] = None, trajectory_row: int = 1) -> torch.Tensor:
+        """``steps`` x ``step()`` as ONE call of ``mpx_rollout`` (fp32): same kernels, same order, bit-identical state --
+        including the per-step scene re-render (``rerender_scene``) and the success tracking (``track_success``).
+        ``trajectory`` [B, L, 7] (optional): rows ``trajectory_row ...`` of every environment receive q after each step."""
         if getattr(self, "_native", None) is None:
             c, sc = self.collision, self._NativeScene()
             sc.limits, sc.finger = self.limits.data_ptr(), float(self.sampler.finger)
@@ -139,10 +147,30 @@ class RolloutEngine:
             need = _lib.load().mpx_rollout_workspace(self.B, self.xyz.size(1))
             self._native = (sc, w, keep, torch.empty(need, dtype=torch.uint8, device=self.device), need)
         sc, w, _, ws, need = self._native
-        _lib.call("mpx_rollout_step", ctypes.addressof(w), ctypes.addressof(sc), _lib.ptr(self.xyz), self.xyz.size(1),
-                  _lib.ptr(self.q_norm), _lib.ptr(self.q), self.B, _lib.ptr(self.flags), None, _lib.ptr(ws), need)
-        self.steps_done += 1
+        opt = self._NativeOptions()
+        opt.steps, opt.first_step = int(steps), int(self.steps_done)
+        keep = []
+        if self.rerender_scene:
+            prims = [_lib.f32c(self._prims[k]) for k in ("cuboid_centers", "cuboid_quats", "cylinder_centers", "cylinder_quats")]
+            keep += prims
+            opt.n_scene, opt.scene_seed, opt.env_offset = self._n_scene, self.scene_seed & (2 ** 64 - 1), self.env_offset
+            opt.cub_centers, opt.cub_quats, opt.cyl_centers, opt.cyl_quats = (t.data_ptr() for t in prims)
+        if self.done is not None:
+            opt.target_poses, opt.pos_tol, opt.cos_rot_tol = self.targets.data_ptr(), self.pos_tol, self.cos_tol
+            opt.done, opt.steps_taken = self.done.data_ptr(), self.steps.data_ptr()
+        if trajectory is not None:
+            assert trajectory.is_contiguous() and trajectory.dtype == torch.float32 and trajectory.shape[::2] == (self.B, 7)
+            opt.trajectory, opt.trajectory_len, opt.trajectory_row = trajectory.data_ptr(), trajectory.size(1), int(trajectory_row)
+        _lib.call("mpx_rollout", ctypes.addressof(w), ctypes.addressof(sc), ctypes.addressof(opt), _lib.ptr(self.xyz),
+                  self.xyz.size(1), _lib.ptr(self.q_norm), _lib.ptr(self.q), self.B, _lib.ptr(self.flags), None, _lib.ptr(ws),
+                  need)
+        del keep
+        self.steps_done += int(steps)
         return self.q
+
+    def step_native(self) -> torch.Tensor:
+        """``step()`` through the single C entry point (one step of ``run_native``)."""
+        return self.run_native(1)
 
     def rollout(self, steps: int) -> torch.Tensor:
         """-> trajectory [B, steps+1, 7] (joint space), like ``rollout(..., unnormalize=True)``."""
@@ -157,16 +185,28 @@ class RolloutEngine:
     def has_collision(self) -> torch.Tensor:
         return self.flags != 0
 
-    def rollout_until_success(self, max_steps: int = 150, check_every: int = 1):
+    def rollout_until_success(self, max_steps: int = 150, check_every: int = 1, native: bool = False):
         """Batched ``rollout_until_success`` (run_inference.py:137-191): step until every environment is
         within 1 cm / 15 deg of its target or ``max_steps`` is reached.  The host looks at the done
-        flags only every ``check_every`` steps (1 = the reference's per-step behaviour).
+        flags only every ``check_every`` steps (1 = the reference's per-step behaviour).  ``native``: every
+        ``check_every`` steps are one ``mpx_rollout`` call (same result).
 
         :returns: trajectory [B, L+1, 7] and lengths int32 [B] (number of valid waypoints per env,
                   including the start configuration; later rows repeat the final configuration).
         """
         assert self.done is not None, "call track_success(target_poses) first"
         lim = self.limits
+        if native:
+            traj = torch.empty((self.B, max_steps + 1, 7), dtype=torch.float32, device=self.device)
+            traj[:, 0] = (self.q_norm + 1) * (lim[:, 1] - lim[:, 0]) / 2 + lim[:, 0]
+            taken = 0
+            while taken < max_steps:
+                n = min(check_every, max_steps - taken)
+                self.run_native(n, trajectory=traj, trajectory_row=taken + 1)
+                taken += n
+                if bool(torch.all(self.done != 0)):
+                    break
+            return traj[:, :taken + 1], self.steps + 1
         traj = [(self.q_norm + 1) * (lim[:, 1] - lim[:, 0]) / 2 + lim[:, 0]]
         for i in range(max_steps):
             traj.append(self.step().clone())

@@ -482,3 +482,96 @@ def test_single_call_rollout_step_reproduces_the_engine(B):
         assert torch.equal(qa, qb) and torch.equal(a.q_norm, b.q_norm)
         assert torch.equal(a.xyz, b.xyz) and torch.equal(a.flags, b.flags)
     assert (a.q_norm.abs() <= 1).all()
+
+
+@pytest.mark.parametrize("B", [1, 24])
+def test_native_rollout_with_rerender_and_success_tracking_reproduces_the_engine(B):
+    """mpx_rollout -- several closed-loop steps in ONE C call with the per-step scene re-render (seed schedule, global
+    environment ids) and the on-device early-stop bookkeeping of rollout_until_success (run_inference.py:171-189) --
+    leaves exactly the state the Python engine leaves: joint angles, slab (scene rows included), flags, done flags,
+    per-environment step counts and the trajectory rows."""
+    from mpinets_amd import franka_tables as ft
+    from mpinets_amd.model import MotionPolicyNetwork
+    from mpinets_amd.robot import franka_fk, frames_to_matrix
+    from mpinets_amd.rollout import RolloutEngine
+    from mpinets_amd.scenes import make_problem_batch
+
+    torch.manual_seed(12)
+    mdl = MotionPolicyNetwork().to(dev()).eval()
+    engines, targets = [], None
+    for _ in range(2):
+        prob = make_problem_batch(B, seed=31, device=dev(), kinds=("tabletop", "cubby", "dresser"), M1=40, M2=16,
+                                  device_clouds=True, env_offset=3, total_envs=3 + B)
+        eng = RolloutEngine(mdl, prob, rerender_scene=True, scene_seed=77)
+        if targets is None:  # environment 0 starts at its target (done after the first step's test unless it moves away)
+            targets = prob["target_pose"].clone()
+            targets[0] = frames_to_matrix(franka_fk(prob["q"])[:, ft.LINK_ID["right_gripper"]])[0]
+        eng.track_success(targets, pos_tol=0.5, rot_tol_deg=120.0)  # loose: some environments finish within 4 steps
+        engines.append(eng)
+    a, b = engines
+    L = 4
+    traj_a = [a.step().clone() for _ in range(L)]
+    traj_b = torch.zeros((B, L + 1, 7), device=dev())
+    b.run_native(1, trajectory=traj_b, trajectory_row=1)  # one step, then three in one call (first_step continues)
+    b.run_native(L - 1, trajectory=traj_b, trajectory_row=2)
+    assert a.steps_done == b.steps_done == L
+    assert torch.equal(a.q, b.q) and torch.equal(a.q_norm, b.q_norm)
+    assert torch.equal(a.xyz, b.xyz), "slab (robot + re-rendered scene rows) differs"
+    assert torch.equal(a.flags, b.flags) and torch.equal(a.done, b.done) and torch.equal(a.steps, b.steps)
+    assert torch.equal(torch.stack(traj_a, 1), traj_b[:, 1:])
+    assert (traj_b[:, 0] == 0).all()
+    if B > 1:
+        assert 0 < int((a.done != 0).sum()) < B  # the freeze path and the moving path were both exercised
+
+
+def test_native_rollout_until_success_equals_python_loop():
+    from mpinets_amd.model import MotionPolicyNetwork
+    from mpinets_amd.rollout import RolloutEngine
+    from mpinets_amd.scenes import make_problem_batch
+
+    torch.manual_seed(5)
+    mdl = MotionPolicyNetwork().to(dev()).eval()
+    out = []
+    for native in (False, True):
+        prob = make_problem_batch(6, seed=9, device=dev(), kinds=("tabletop", "cubby"), M1=24, device_clouds=True)
+        eng = RolloutEngine(mdl, prob)
+        eng.track_success(prob["target_pose"], pos_tol=0.6, rot_tol_deg=150.0)
+        out.append(eng.rollout_until_success(max_steps=7, check_every=3, native=native) + (eng.xyz, eng.flags))
+    (ta, la, xa, fa), (tb, lb, xb, fb) = out
+    assert ta.shape == tb.shape and torch.equal(ta, tb) and torch.equal(la, lb) and torch.equal(xa, xb) and torch.equal(fa, fb)
+
+
+def test_policy_forward_is_safe_from_two_host_threads():
+    """Two host threads drive mpx_policy_forward on the same device from different streams (small batches: the
+    internal side stream + fork / join events are shared per device and must be held exclusively per call)."""
+    import threading
+
+    from mpinets_amd.model import MotionPolicyNetwork
+    from mpinets_amd.scenes import make_problem_batch
+
+    torch.manual_seed(2)
+    mdl = MotionPolicyNetwork().to(dev()).eval()
+    probs = [make_problem_batch(3, seed=40 + i, device=dev(), device_clouds=True) for i in range(2)]
+    with torch.no_grad():
+        want = [mdl.forward_native(p["xyz"], p["q_norm"]).clone() for p in probs]
+    torch.cuda.synchronize()
+    got, errs = [[], []], []
+
+    def work(i):
+        try:
+            torch.cuda.set_device(dev())
+            with torch.cuda.stream(torch.cuda.Stream(device=dev())), torch.no_grad():
+                for _ in range(40):
+                    got[i].append(mdl.forward_native(probs[i]["xyz"], probs[i]["q_norm"]))
+                torch.cuda.current_stream().synchronize()
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+
+    mdl.native_weights()  # (pack once, outside the threads)
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    torch.cuda.synchronize()
+    for i in range(2):
+        assert all(torch.equal(g, want[i]) for g in got[i])
