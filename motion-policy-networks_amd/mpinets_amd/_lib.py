@@ -159,9 +159,20 @@ def call(name: str, *args):
 
 
 def require_cuda(*tensors: Optional[torch.Tensor]):
+    """No CPU fallback -- and no silent cross-device launches: every call is enqueued on torch's current stream of
+    the CURRENT device, so operands that live on another GPU (``model.to('cuda:1')`` without
+    ``torch.cuda.set_device(1)``) are rejected instead of being launched on device 0's stream."""
+    cur = None
     for t in tensors:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise MpxError("CPU tensors are not supported by the HIP engine (no CPU fallback)")
+        if cur is None:
+            cur = torch.cuda.current_device()
+        if t.device.index != cur:
+            raise MpxError(f"tensor on cuda:{t.device.index} but the current device is cuda:{cur}: call "
+                           f"torch.cuda.set_device({t.device.index}) (or use `with torch.cuda.device(...)`) first")
 
 
 def f32c(t: torch.Tensor) -> torch.Tensor:

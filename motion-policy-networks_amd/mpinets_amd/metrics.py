@@ -32,6 +32,26 @@ from . import franka_tables as ft
 from .robot import FrankaCollisionSampler
 
 
+def _per_primitive_sdf(volumes, points: torch.Tensor) -> torch.Tensor:
+    """SDF of EVERY primitive of a set at one point per environment: points [B,3] -> [B,M] (zero-volume rows: +inf).
+    The set classes reduce over their primitives; viewing each primitive as its own one-primitive environment gives
+    the unreduced values from the same kernels."""
+    from .geometry import TorchCuboids, TorchCylinders, TorchSpheres
+
+    B, M = volumes.centers.shape[:2]
+    flat = lambda t: t.reshape(B * M, 1, t.size(-1))
+    if isinstance(volumes, TorchCuboids):
+        one = TorchCuboids(flat(volumes.centers), flat(volumes.dims), flat(volumes.quats))
+    elif isinstance(volumes, TorchCylinders):
+        one = TorchCylinders(flat(volumes.centers), flat(volumes.radii), flat(volumes.heights), flat(volumes.quats))
+    elif isinstance(volumes, TorchSpheres):
+        one = TorchSpheres(flat(volumes.centers), flat(volumes.radii))
+    else:
+        raise TypeError(f"unsupported volume set {type(volumes).__name__}")
+    p = points[:, None, :].expand(B, M, 3).reshape(B * M, 1, 3).contiguous()
+    return one.sdf(p).reshape(B, M)
+
+
 class BatchedEvaluator:
     def __init__(self, device, finger: float = ft.FINGER_OPENING):
         self.device = torch.device(device)
@@ -48,7 +68,9 @@ class BatchedEvaluator:
         :param target_poses: [B,4,4] ``right_gripper`` targets
         :param cuboids/cylinders: scene primitives (``geometry.TorchCuboids`` / ``TorchCylinders``) or None
         :param target_volume: optional primitive set (M >= 1 per env); the final position must be inside one
-        :param negative_volumes: optional primitive set; the final position must be outside all of them
+        :param negative_volumes: optional primitive set; the final position must be outside all of them -- except
+            those that contain the TARGET position, which the reference drops first ("Sometimes the target is inside a
+            negative volume. This is obviously a bad negative volume", metrics.py:507-512)
         """
         _lib.require_cuda(trajectories, target_poses)
         B, T, _ = trajectories.shape
@@ -74,7 +96,9 @@ class BatchedEvaluator:
             if target_volume is not None:
                 region &= target_volume.sdf(p)[:, 0] <= 0
             if negative_volumes is not None:
-                region &= negative_volumes.sdf(p)[:, 0] > 0
+                # corrected_negative_volumes = [v for v in volumes if v.sdf(target) > 0]  (metrics.py:507-509)
+                keep = _per_primitive_sdf(negative_volumes, tg[:, :3, 3].contiguous()) > 0  # [B,M]; masked rows: +inf
+                region &= ~((_per_primitive_sdf(negative_volumes, final.contiguous()) <= 0) & keep).any(dim=1)
         jl, sc = jl != 0, sc != 0
         violation = collision | jl | sc
         return {"position_error": pos, "orientation_error": ori, "eff_position_path_length": pp,

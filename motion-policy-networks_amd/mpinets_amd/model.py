@@ -159,6 +159,7 @@ class MPiNetsPointNet(nn.Module):
         """
         if not point_cloud.is_cuda:
             raise _lib.MpxError("CPU tensors not supported (reference: model.py:417)")
+        _lib.require_cuda(point_cloud, self.fc_layer[0].weight)  # (also: operands on the current device)
         assert point_cloud.ndim == 3 and point_cloud.size(2) == 4
         if self.training and torch.is_grad_enabled():
             enc = self.forward_train(point_cloud, aux=aux)
@@ -311,14 +312,37 @@ class MotionPolicyNetwork(nn.Module):
             sa.elide_padding = bool(on)
         return self
 
+    def invalidate_caches(self) -> "MotionPolicyNetwork":
+        """Drop every derived weight buffer (MFMA-stream packs, bf16 hi/lo planes, padded first layers).  They refresh
+        by themselves when a parameter is modified through torch (``_version`` changes: optimizer steps,
+        ``load_state_dict``, ``copy_``); writes through ``param.data`` (EMA swaps, manual init) do not bump the
+        version -- call this after them."""
+        enc = self.point_cloud_encoder
+        for sa in enc.SA_modules:
+            sa._packed.packs.clear()
+            sa._packed._fact = None
+            if hasattr(sa, "_split"):
+                sa._split.cache.clear()
+        enc._split.cache.clear()
+        enc._sa3_w0 = None
+        self._q_w0 = None
+        return self
+
     def configure_optimizers(self):
         return torch.optim.Adam(self.parameters(), lr=1e-4)
 
     @classmethod
     def load_from_checkpoint(cls, path: str, map_location="cpu", **kwargs):
         """Reads a Lightning ``.ckpt`` (``{'state_dict': ...}``) or a bare state dict
-        (run_inference.py:262)."""
-        ckpt = torch.load(path, map_location=map_location)
+        (run_inference.py:262).  Real Lightning checkpoints also pickle callback / hyper-parameter objects, which
+        torch >= 2.6's default ``weights_only=True`` refuses: such (trusted, local) files are re-read with
+        ``weights_only=False``, like ``LightningModule.load_from_checkpoint`` does."""
+        import pickle
+
+        try:
+            ckpt = torch.load(path, map_location=map_location, weights_only=True)
+        except (pickle.UnpicklingError, RuntimeError):
+            ckpt = torch.load(path, map_location=map_location, weights_only=False)
         sd = ckpt.get("state_dict", ckpt)
         mdl = cls(**kwargs)
         mdl.load_state_dict({k: v for k, v in sd.items() if not k.startswith("loss_fun")})

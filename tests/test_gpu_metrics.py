@@ -81,4 +81,23 @@ def test_final_region_check():
     ev = BatchedEvaluator(dev())
     assert ev.evaluate_trajectories(q, pose, target_volume=inside, negative_volumes=far)["correct_final_region"].all()
     assert not ev.evaluate_trajectories(q, pose, target_volume=far)["correct_final_region"].any()
-    assert not ev.evaluate_trajectories(q, pose, negative_volumes=inside)["success"].any()
+    # a negative volume that contains the TARGET is a bad volume and is dropped first (metrics.py:507-512): the final
+    # pose sits on the target here, so `inside` does not count against it ...
+    assert ev.evaluate_trajectories(q, pose, negative_volumes=inside)["success"].all()
+    # ... but the same volume counts when the target lies elsewhere (outside of it)
+    away = pose.clone()
+    away[:, :3, 3] += 1.0
+    out = ev.evaluate_trajectories(q, away, negative_volumes=inside)
+    assert not out["correct_final_region"].any() and not out["success"].any()
+    # mixed set: [contains target and final (dropped), far from both (harmless), zero-volume padding row]
+    cc = torch.cat([c, c + 1.0, c * 0], dim=1)
+    dd = torch.cat([torch.full((2, 2, 3), 0.2, device=dev()), torch.zeros((2, 1, 3), device=dev())], dim=1)
+    mixed = TorchCuboids(cc, dd, ident.repeat(1, 3, 1))
+    assert ev.evaluate_trajectories(q, pose, negative_volumes=mixed)["correct_final_region"].all()
+    # env 0: the final position is inside volume 1, which does not contain its (shifted) target
+    tgt = pose.clone()
+    tgt[0, :3, 3] += 0.5
+    cc2 = torch.cat([c + 1.0, c], dim=1)
+    mixed2 = TorchCuboids(cc2, torch.full((2, 2, 3), 0.2, device=dev()), ident.repeat(1, 2, 1))
+    r = ev.evaluate_trajectories(q, tgt, negative_volumes=mixed2)["correct_final_region"].cpu().numpy()
+    assert r.tolist() == [False, True]

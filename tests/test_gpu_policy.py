@@ -575,3 +575,43 @@ def test_policy_forward_is_safe_from_two_host_threads():
     torch.cuda.synchronize()
     for i in range(2):
         assert all(torch.equal(g, want[i]) for g in got[i])
+
+
+def test_lightning_style_checkpoint_and_cache_invalidation(tmp_path):
+    """A checkpoint that pickles non-tensor objects (Lightning callbacks / hyper-parameters) loads; writes through
+    ``param.data`` need ``invalidate_caches()`` (they do not bump the parameter version)."""
+    import argparse
+
+    from mpinets_amd.model import MotionPolicyNetwork
+    from mpinets_amd.scenes import make_problem_batch
+
+    torch.manual_seed(8)
+    mdl = MotionPolicyNetwork()
+    path = tmp_path / "lightning.ckpt"
+    torch.save({"state_dict": mdl.state_dict(), "epoch": 3, "hyper_parameters": argparse.Namespace(lr=1e-4),
+                "callbacks": {"ModelCheckpoint": {"best": argparse.Namespace(score=0.1)}}}, path)
+    m2 = MotionPolicyNetwork.load_from_checkpoint(str(path)).to(dev()).eval()
+    for k, v in mdl.state_dict().items():
+        assert torch.equal(v, m2.state_dict()[k].cpu())
+    prob = make_problem_batch(2, seed=3, device=dev())
+    with torch.no_grad():
+        a = m2(prob["xyz"], prob["q_norm"]).clone()
+        conv = m2.point_cloud_encoder.SA_modules[1].convs()[1]
+        conv.weight.data.mul_(1.5)  # behind torch's back: the packed weights are stale ...
+        stale = m2(prob["xyz"], prob["q_norm"]).clone()
+        fresh = m2.invalidate_caches()(prob["xyz"], prob["q_norm"]).clone()  # ... until the caches are dropped
+    assert torch.equal(stale, a) and not torch.equal(fresh, a)
+
+
+def test_operands_on_another_device_are_rejected():
+    from mpinets_amd import _lib
+
+    if torch.cuda.device_count() < 2:
+        class FakeOther:  # a stand-in with the attributes require_cuda looks at
+            is_cuda = True
+            device = torch.device("cuda", torch.cuda.current_device() + 1)
+        with pytest.raises(_lib.MpxError, match="current device"):
+            _lib.require_cuda(FakeOther())
+    else:
+        with pytest.raises(_lib.MpxError, match="current device"):
+            _lib.require_cuda(torch.zeros(1, device="cuda:1"))
