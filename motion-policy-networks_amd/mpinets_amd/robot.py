@@ -117,9 +117,17 @@ class FrankaSampler:
     def __init__(self, device, num_fixed_points: Optional[int] = None, use_cache: bool = False,
                  with_base_link: bool = True, point_table: Optional[Tuple[np.ndarray, np.ndarray]] = None,
                  finger: float = ft.FINGER_OPENING):
-        self.device = torch.device(device)
-        if self.device.type != "cuda":
-            raise _lib.MpxError("FrankaSampler needs a GPU device (the HIP engine has no CPU fallback)")
+        # ``FrankaSampler("cpu", use_cache=True)`` is how the reference builds its host-side clouds
+        # (run_inference.py:262, data_loader.py:101): accepted as a HOST-FACING handle -- inputs and results are CPU
+        # tensors, the arithmetic still runs in the HIP library on the current GPU (there is no CPU implementation;
+        # without a GPU this raises).
+        self.io_device = torch.device(device)
+        if self.io_device.type == "cuda":
+            self.device = self.io_device
+        else:
+            if not torch.cuda.is_available():
+                raise _lib.MpxError("FrankaSampler needs a GPU (the HIP engine has no CPU fallback)")
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.with_base_link = with_base_link
         self.num_fixed_points = num_fixed_points
         self.finger = float(finger)
@@ -147,6 +155,9 @@ class FrankaSampler:
         """q [B,7] (or [7]) joint angles -> [B,P,3]."""
         if q.ndim == 1:
             q = q.unsqueeze(0)
+        if self.io_device.type != "cuda":  # host-facing handle: compute on the GPU, hand the result back
+            assert not (torch.is_grad_enabled() and q.requires_grad), "differentiable sampling needs the GPU handle"
+            q = q.to(self.device, dtype=torch.float32)
         _lib.require_cuda(q)
         if self._fixed is not None:
             subset = self._fixed
@@ -159,7 +170,7 @@ class FrankaSampler:
             return _SampleFn.apply(q, self, subset, n_out)
         out = torch.empty((q.size(0), n_out, 3), dtype=torch.float32, device=q.device)
         self.sample_into(q, out, subset)
-        return out
+        return out.to(self.io_device)
 
     def sample_into(self, q: torch.Tensor, out: torch.Tensor, subset: Optional[torch.Tensor]) -> None:
         """Write ``out[:, :n, :3]`` in place; ``out`` may be the xyz slab itself ([B,N,4] or [B,n,3])."""
@@ -175,6 +186,7 @@ class FrankaSampler:
         """poses [B,4,4] of ``frame`` -> gripper points [B,num_points,3] (run_inference.py:66-69)."""
         if poses.ndim == 2:
             poses = poses.unsqueeze(0)
+        poses = poses.to(self.device, dtype=torch.float32)  # (no-op for the GPU handle)
         _lib.require_cuda(poses)
         assert poses.shape[1:] == (4, 4)
         table = self.eef_table if frame == "right_gripper" else torch.as_tensor(
@@ -184,13 +196,13 @@ class FrankaSampler:
         pc = _lib.f32c(poses)
         _lib.call("mpx_pose_cloud", _lib.ptr(pc), poses.size(0), _lib.ptr(table), _lib.ptr(subset), num_points,
                   _lib.ptr(out), out.stride(0), out.stride(1))
-        return out
+        return out.to(self.io_device)
 
     def end_effector_pose(self, q: torch.Tensor, frame: str = "right_gripper") -> torch.Tensor:
         """q [B,7] -> [B,4,4] (model.py:275)."""
         if q.ndim == 1:
             q = q.unsqueeze(0)
-        return frames_to_matrix(franka_fk(q, self.finger)[:, ft.LINK_ID[frame]])
+        return frames_to_matrix(franka_fk(q.to(self.device, dtype=torch.float32), self.finger)[:, ft.LINK_ID[frame]]).to(self.io_device)
 
 
 class FrankaCollisionSampler:
