@@ -134,7 +134,8 @@ def test_inference_driver_replay_matches_oracle(oracle, reach_target):
             mdl.decoder[6].bias.zero_()
     cpu_fk_sampler = FrankaSampler("cpu", use_cache=True)      # run_inference.py:264 -- host-facing handle
     gpu_fk_sampler = FrankaSampler("cuda:0", use_cache=True)   # run_inference.py:265
-    q0 = ft.DEFAULT_Q.astype(np.float32) + np.float32(0.05)
+    q0 = np.array([0.1, -0.8, 0.1, -2.0, 0.1, 2.0, 0.7], np.float32)  # inside FrankaRealRobot's limits (the YAML's default_q is not)
+    assert (q0 > ft.JOINT_LIMITS_REAL[:, 0]).all() and (q0 < ft.JOINT_LIMITS_REAL[:, 1]).all()
     q_goal = q0 if reach_target else q0 + np.array([0.4, 0.3, -0.3, 0.2, 0.1, 0.3, -0.2], np.float32)
     target = Target(FrankaRobot.fk(q_goal, eff_frame="right_gripper").matrix)
     obstacles = _obstacles()
