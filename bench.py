@@ -167,6 +167,7 @@ def main():
     ap.add_argument("--fast-steps", type=int, default=3, help="steps of the secondary bf16x3 measurement (0 = skip)")
     ap.add_argument("--extra", type=int, default=1, help="also time BASELINE configs 2 and 4 (collision validation only)")
     ap.add_argument("--static-steps", type=int, default=2, help="steps of the extra without scene re-render on tabletop-only scenes (BASELINE config 3 shape at this batch size); 0 = skip")
+    ap.add_argument("--pipeline-steps", type=int, default=3, help="steps of the two-stream pipelined measurement of the headline workload (0 = skip)")
     ap.add_argument("--cpu-envs", type=int, default=64, help="env-steps in the CPU baseline sample (0 = skip)")
     ap.add_argument("--scene-pool", type=int, default=1024, help="distinct host-generated primitive sets tiled over the batch (clouds are drawn per env on the device)")
     args = ap.parse_args()
@@ -331,6 +332,32 @@ def main():
                                "what": "FK + sphere SDF, flags + min-sdf [1024,56] written"},
         }
 
+    # ---- extra: the SAME headline workload with the batch cut into two shares on two HIP streams, one a stage behind
+    # the other (PipelinedRollout): share B's sampling kernels run while share A is in its matrix kernels.  All ranks.
+    pipelined = None
+    if args.pipeline_steps > 0:
+        from mpinets_amd.rollout import PipelinedRollout
+
+        prob_p = make_problem_batch(B, seed=1000, device=dev, kinds=("tabletop", "cubby", "dresser"), M1=40, M2=16,
+                                    scene_pool=args.scene_pool, device_clouds=True, env_offset=envs.start,
+                                    total_envs=B * n_gpus)
+        pr = PipelinedRollout(model, prob_p, ways=2, rerender_scene=True, scene_seed=17)
+        pr.run(args.warmup + 1)
+        torch.cuda.synchronize()
+        shard.barrier()
+        tp0 = time.perf_counter()
+        pr.run(args.pipeline_steps)
+        torch.cuda.synchronize()
+        shard.barrier()
+        el_p = shard.max_over_ranks(time.perf_counter() - tp0, dev)
+        pipelined = {"ways": 2, "steps": args.pipeline_steps, "ms_per_step": el_p / args.pipeline_steps * 1e3,
+                     "env_steps_per_s": B * n_gpus * args.pipeline_steps / el_p, "dtype": "f32",
+                     "what": "the headline workload with the batch in two shares on two HIP streams, one a stage behind "
+                             "the other (mpinets_amd.rollout.PipelinedRollout); state bit-identical to the single-stream "
+                             "run (tools/pipeline_timing.py).  The matrix kernels leave only 32 VGPRs per SIMD free, so a "
+                             "sampling workgroup cannot share a CU with them: the two streams mostly time-slice"}
+        del pr, prob_p
+
     # ---- extra: the same closed-loop step WITHOUT the scene re-render, on tabletop-only scenes (16 cuboids + 16
     # cylinders): the reference's rollout re-samples only the robot points (model.py:180-181); all ranks, weak scaling
     static = None
@@ -449,6 +476,8 @@ def main():
         }
         if extra is not None:
             out["extra_configs"] = extra
+        if pipelined is not None:
+            out["pipelined_two_streams"] = pipelined
         if fast is not None:
             fel, f1_ms, f2_ms, fdense_ms = fast
             out["fast_mode"] = {

@@ -290,11 +290,14 @@ int mpx_group_points(const float *xyz, int stride, const float *new_xyz, int new
  * cnt (optional, from mpx_ball_query): only the DISTINCT neighbours are evaluated -- slots
  * [cnt, nsample) repeat the first neighbour, the MLP is per point and max-pooling is idempotent,
  * so the output is bit-identical to walking all nsample slots (cnt == NULL).  Several queries
- * share a wave and their rows are packed at 4-row granularity into the 32-row MFMA tiles.    */
+ * share a wave and their rows are packed at 4-row granularity into the 32-row MFMA tiles.
+ * append_centre != 0 (needs cnt, out_stride >= c3 + 4): columns [c3, c3+3) of every output row also receive the
+ * query point's coordinates and column c3+3 a zero -- the rows are then the operand [f | xyz | 0] of the next
+ * module's per-point first-layer GEMM (mpx_sa_mlp_factored), model.py:404-407's torch.cat without a second pass. */
 int mpx_sa_mlp(const float *xyz, int stride, const float *new_xyz, int new_stride,
                const float *feat, int feat_stride, int C, const int32_t *idx, const int32_t *cnt,
                int B, int N, int npoint, int nsample, const float *wpack, int c1, int c2, int c3,
-               float *out, int out_stride, mpx_stream_t stream);
+               float *out, int out_stride, int append_centre, mpx_stream_t stream);
 /* Same module with the first layer factored out of the per-(query, neighbour) work:
  *   W1.[p_j - c_i ; f_j] + b1 = pre[j] - ctr[i],  pre = [p ; f].W1^T  (one row per POINT, [B*N, c1]),
  *                                                 ctr = c.W1x^T - b1  (one row per QUERY, [B*npoint, c1]),

@@ -216,8 +216,9 @@ MPX_EXPORT int mpx_policy_forward(const mpx_policy_weights *w, const float *xyz,
   };
   auto module_sa1 = [&]() -> int {  // neighbours within 5 cm, grouped MLP over [p - c ; label] rows
     MPX_TRY(mpx_ball_query(bu.xyz1, 3, xyz, 4, B, N, NP1, R1, NS, bu.nbr1, bu.cnt1, stream));
+    // (its rows come out as [f1 | xyz1 | 0]: the operand of SA2's per-point first-layer GEMM)
     MPX_TRY(mpx_sa_mlp(xyz, 4, bu.xyz1, 3, xyz + 3, 4, 1, bu.nbr1, bu.cnt1, B, N, NP1, NS, w->sa1_pack, 64, 64, C1, bu.f1,
-                       F1, stream));
+                       F1, 1, stream));
     return 0;
   };
 
@@ -241,7 +242,6 @@ MPX_EXPORT int mpx_policy_forward(const mpx_policy_weights *w, const float *xyz,
     MPX_TRY(sample_sa2_and_encode_q(stream));
   }
   // ---- SA2: first layer per point / per query, layers 2-3 + max-pool fused ------------------------------------
-  MPX_TRY(mpx_append_columns(bu.xyz1, 3, 3, 1, (int64_t)B * NP1, bu.f1, F1, C1, stream));  // rows [f1 | xyz1 | 0]
   MPX_TRY(lin(bu.f1, F1, w->sa2_wpoint, nullptr, B * NP1, 128, F1, MPX_ACT_NONE, bu.pre, 128));
   MPX_TRY(lin(bu.sa3_in, K3, w->sa2_wcentre, w->sa2_nb1, B * NP2, 128, 4, MPX_ACT_NONE, bu.ctr, 128));
   MPX_TRY(mpx_sa_mlp_factored(bu.pre, bu.ctr, bu.nbr2, bu.cnt2, B, NP1, NP2, NS, w->sa2_pack, C1, 128, 128, C2,

@@ -296,7 +296,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CF == 1
                          int new_stride, const float *__restrict__ feat, int feat_stride,
                          const int32_t *__restrict__ idx, const int32_t *__restrict__ cnt, int64_t n_query, int N,
                          int npoint, int nsample, const float *__restrict__ wpack, float *__restrict__ out,
-                         int out_stride, int bpe, const float *__restrict__ pre_rows, const float *__restrict__ ctr) {
+                         int out_stride, int bpe, const float *__restrict__ pre_rows, const float *__restrict__ ctr,
+                         int append_centre) {
   using Cfg = SaCfg<CF, C1, C2, C3>;
   __shared__ float ctr_s[FACT ? Q * C1 : 1];
   // biases in LDS: they initialise the accumulators at every tile and are added at every flush -- as global loads
@@ -371,6 +372,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CF == 1
   };
 
   const int qbase = (int)q0;  // query ids fit 31 bits (checked by the launcher)
+  if constexpr (!FACT) {
+    // columns [C3, C3+4) of this wave's output rows <- [centre xyz | 0]: the rows become the operand [f | xyz | 0] of
+    // the next module's per-point first-layer GEMM (mpx_sa_mlp_factored) without a separate pass over them
+    if (append_centre && lane < 4 * nq) {
+      const int qi = lane >> 2, c = lane & 3;
+      out[(int64_t)(qbase + qi) * out_stride + C3 + c] = c < 3 ? new_xyz[(int64_t)(qbase + qi) * new_stride + c] : 0.0f;
+    }
+  }
   float run[Cfg::OT3];  // running max of the query being merged, per output tile (this lane's half of the rows)
   int cur = 0;          // ... and which of this wave's queries that is (wave-uniform; the same for every output tile
                         // between two row tiles, so it advances once per row tile)
@@ -612,9 +621,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CF == 1
 template <int CF, int C1, int C2, int C3>
 static int launch_sa(const float *xyz, int stride, const float *new_xyz, int new_stride, const float *feat,
                      int feat_stride, const int32_t *idx, const int32_t *cnt, int B, int N, int npoint, int nsample,
-                     const float *wpack, float *out, int out_stride, mpx_stream_t stream) {
+                     const float *wpack, float *out, int out_stride, int append_centre, mpx_stream_t stream) {
   const int64_t nq = (int64_t)B * npoint;
   MPX_REQUIRE(nq / 4 + 1 < ((int64_t)1 << 31), "mpx_sa_mlp: too many query points");
+  MPX_REQUIRE(!append_centre || (cnt && out_stride >= C3 + 4),
+              "mpx_sa_mlp: append_centre needs the hit counts and out_stride >= c3 + 4");
   if (cnt) {
     // queries per wave: 6-9 tiles of work on typical scenes.  A small batch (a single planning problem up to a few
     // dozen) would leave most CUs idle at that size, so it runs QS queries per wave instead: same rows, same
@@ -627,7 +638,7 @@ static int launch_sa(const float *xyz, int stride, const float *new_xyz, int new
       const int bpe = (npoint % Q == 0 && B % 8 == 0) ? npoint / Q : 0;
       hipLaunchKernelGGL((sa_mlp_packed_kernel<CF, C1, C2, C3, Q, false>), dim3((unsigned)nw), dim3(64), 0,
                          mpx_s(stream), xyz, stride, new_xyz, new_stride, feat, feat_stride, idx, cnt, nq, N, npoint,
-                         nsample, wpack, out, out_stride, bpe, nullptr, nullptr);
+                         nsample, wpack, out, out_stride, bpe, nullptr, nullptr, append_centre);
     };
     if (nq >= 1024 * QL) go(std::integral_constant<int, QL>{});
     else go(std::integral_constant<int, QS>{});
@@ -650,7 +661,7 @@ static int launch_sa(const float *xyz, int stride, const float *new_xyz, int new
 MPX_EXPORT int mpx_sa_mlp(const float *xyz, int stride, const float *new_xyz, int new_stride,
                           const float *feat, int feat_stride, int C, const int32_t *idx, const int32_t *cnt, int B,
                           int N, int npoint, int nsample, const float *wpack, int c1, int c2, int c3, float *out,
-                          int out_stride, mpx_stream_t stream) {
+                          int out_stride, int append_centre, mpx_stream_t stream) {
   MPX_REQUIRE(B >= 0 && N >= 1 && npoint >= 0, "mpx_sa_mlp: bad size");
   MPX_REQUIRE(nsample > 0 && nsample % 32 == 0, "mpx_sa_mlp: nsample must be a positive multiple of 32");
   MPX_REQUIRE(stride >= 3 && new_stride >= 3 && out_stride >= c3, "mpx_sa_mlp: bad stride");
@@ -659,7 +670,7 @@ MPX_EXPORT int mpx_sa_mlp(const float *xyz, int stride, const float *new_xyz, in
   MPX_REQUIRE(((uintptr_t)wpack & 15) == 0, "mpx_sa_mlp: wpack must be 16-byte aligned");
   if (B == 0 || npoint == 0) return 0;
 #define CALL(a, b, c, d) \
-  return launch_sa<a, b, c, d>(xyz, stride, new_xyz, new_stride, feat, feat_stride, idx, cnt, B, N, npoint, nsample, wpack, out, out_stride, stream)
+  return launch_sa<a, b, c, d>(xyz, stride, new_xyz, new_stride, feat, feat_stride, idx, cnt, B, N, npoint, nsample, wpack, out, out_stride, append_centre, stream)
   SA_DISPATCH(CALL)
 #undef CALL
 }
@@ -683,7 +694,7 @@ MPX_EXPORT int mpx_sa_mlp_factored(const float *pre, const float *ctr, const int
     const int bpe = (npoint % Q == 0 && B % 8 == 0) ? npoint / Q : 0;
     hipLaunchKernelGGL((sa_mlp_packed_kernel<64, 128, 128, 256, Q, true>), dim3((unsigned)nw), dim3(64), 0,
                        mpx_s(stream), nullptr, 0, nullptr, 0, nullptr, 0, idx, cnt, nq, N, npoint, nsample, wpack, out,
-                       out_stride, bpe, pre, ctr);
+                       out_stride, bpe, pre, ctr, 0);
   };
   if (nq >= 1024 * 8) go(std::integral_constant<int, 8>{});
   else if (nq >= 1024) go(std::integral_constant<int, 2>{});

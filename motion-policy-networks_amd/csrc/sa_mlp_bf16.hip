@@ -22,10 +22,16 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 #define PAD_CH (-1)
-constexpr int G = 8;                      // step-tiles per chunk
+#ifndef MPX_BF16_G
+#define MPX_BF16_G 8
+#endif
+#ifndef MPX_BF16_WAVES
+#define MPX_BF16_WAVES 8
+#endif
+constexpr int G = MPX_BF16_G;             // step-tiles per chunk
 constexpr int TILE_BYTES = 2048;          // w_hi (64 lanes x 16 B) + w_lo
 constexpr int CHUNK_BYTES = G * TILE_BYTES;
-constexpr int WAVES = 8;
+constexpr int WAVES = MPX_BF16_WAVES;
 
 template <int CF, int C1, int C2, int C3>
 struct BCfg {
@@ -263,7 +269,7 @@ __device__ __forceinline__ f32x16 bias_tile_lds(const float *bias_lds, int ot, i
 // FACT: the first layer is evaluated per point / per query by the caller (see sa_mlp.hip): the kernel starts at
 // relu(pre[j] - ctr[i]) and walks only the chunks of layers 2 and 3.
 template <int CF, int C1, int C2, int C3, int Q, bool FACT>
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2)))
     sa_mlp_bf16_kernel(const float *__restrict__ xyz, int stride, const float *__restrict__ new_xyz, int new_stride,
                        const float *__restrict__ feat, int feat_stride, const int32_t *__restrict__ idx,
                        const int32_t *__restrict__ cnt, const int32_t *__restrict__ order, int64_t n_query, int N,

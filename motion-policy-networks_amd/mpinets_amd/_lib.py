@@ -50,7 +50,7 @@ PROTOTYPES = {
     "mpx_ball_query": [P, I, P, I, I, I, I, F, I, P, P, P],
     "mpx_sort_queries": [P, L, I, P, P, P],
     "mpx_group_points": [P, I, P, I, P, I, I, P, I, I, I, I, P, P],
-    "mpx_sa_mlp": [P, I, P, I, P, I, I, P, P, I, I, I, I, P, I, I, I, P, I, P],
+    "mpx_sa_mlp": [P, I, P, I, P, I, I, P, P, I, I, I, I, P, I, I, I, P, I, I, P],
     "mpx_sa_mlp_factored": [P, P, P, P, I, I, I, I, P, I, I, I, I, P, I, P],
     "mpx_sa_mlp_bf16x3_factored": [P, P, P, P, P, I, I, I, I, P, I, I, I, I, P, I, P],
     "mpx_sa_pack_size": [I, I, I, I],

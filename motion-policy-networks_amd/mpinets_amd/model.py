@@ -65,6 +65,7 @@ class MPiNetsPointNet(nn.Module):
             nn.LeakyReLU(inplace=True),
             nn.Linear(2048, 2048),
         )
+        self.after_sampling = None  # optional callable, invoked once SA1's sampling + neighbour search are enqueued
         self._sa3_w0 = None  # first group-all layer with K padded 259 -> 272 (whole 16-float slabs: direct-to-LDS GEMM)
         self.dense_precision = "fp32"  # "bf16x3": the large dense layers on the bf16 matrix cores (set_precision)
         self._split = SplitWeights()
@@ -204,10 +205,16 @@ class MPiNetsPointNet(nn.Module):
         def module_sa1():
             lib.call("mpx_ball_query", lib.ptr(xyz1), 3, lib.ptr(pc), 4, B, N, sa1.npoint, float(sa1.radius),
                      sa1.nsample, lib.ptr(nbr1), lib.ptr(cnt1))
-            launch_sa(sa1.precision, lib.ptr(pc), 4, lib.ptr(xyz1), 3, lib.ptr(pc) + 12, 4, 1, nbr1,
-                      cnt1 if sa1.elide_padding else None, B, N, sa1.npoint, sa1.nsample, w1,
-                      tuple(c.out_channels for c in c1), lib.ptr(f1), f1.stride(1))
+            if self.after_sampling is not None:  # (PipelinedRollout: the next share may start its own sampling now)
+                self.after_sampling()
+            # (SA1 also completes its rows to [f1 | xyz1 | 0] when SA2's first layer is evaluated per point)
+            state["centre_done"] = launch_sa(sa1.precision, lib.ptr(pc), 4, lib.ptr(xyz1), 3, lib.ptr(pc) + 12, 4, 1, nbr1,
+                                             cnt1 if sa1.elide_padding else None, B, N, sa1.npoint, sa1.nsample, w1,
+                                             tuple(c.out_channels for c in c1), lib.ptr(f1), f1.stride(1),
+                                             append_centre=want_rows)
 
+        want_rows = bool(sa2.factored and (C1o,) + tuple(c.out_channels for c in c2) == FACTORED_SHAPE)
+        state = {"centre_done": False}
         keep = None
         if B <= OVERLAP_MAX_BATCH:  # two independent chains, two streams (buffers were allocated above, on `main`)
             main, side = torch.cuda.current_stream(), side_stream(dev)
@@ -224,8 +231,9 @@ class MPiNetsPointNet(nn.Module):
             module_sa1()
             sample_sa2()
         del keep
-        if sa2.factored and (C1o,) + tuple(c.out_channels for c in c2) == FACTORED_SHAPE:
-            lib.call("mpx_append_columns", lib.ptr(xyz1), 3, 3, 1, B * sa1.npoint, lib.ptr(f1buf), C1o + 4, C1o)
+        if want_rows:
+            if not state["centre_done"]:
+                lib.call("mpx_append_columns", lib.ptr(xyz1), 3, 3, 1, B * sa1.npoint, lib.ptr(f1buf), C1o + 4, C1o)
             sa_mlp_factored(f1buf.view(B * sa1.npoint, C1o + 4), sa3_in.view(B * sa2.npoint, K3)[:, :4], nbr2,
                             cnt2 if sa2.elide_padding else torch.full_like(cnt2, sa2.nsample), sa2._packed, c2, C1o,
                             sa1.npoint, lib.ptr(sa3_in) + 12, K3, precision=sa2.precision, split=self._split)

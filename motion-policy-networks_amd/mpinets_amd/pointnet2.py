@@ -199,15 +199,19 @@ class SAWeights:
 
 def launch_sa(precision: str, xyz_ptr: int, stride: int, new_xyz_ptr: int, new_stride: int, feat_ptr: int,
               feat_stride: int, C: int, idx: torch.Tensor, cnt: Optional[torch.Tensor], B: int, N: int, npoint: int,
-              nsample: int, wpack: torch.Tensor, widths: Tuple[int, int, int], out_ptr: int, out_stride: int) -> None:
+              nsample: int, wpack: torch.Tensor, widths: Tuple[int, int, int], out_ptr: int, out_stride: int,
+              append_centre: bool = False) -> bool:
     """One fused group + MLP + max-pool launch in either precision (raw pointers: slab views welcome).
     ``cnt`` (from the ball query) lets the kernel skip neighbourhood tiles that hold only padding --
-    bit-identical output; for the lockstep bf16x3 kernel the queries are first ordered by tile count."""
+    bit-identical output; for the lockstep bf16x3 kernel the queries are first ordered by tile count.
+    ``append_centre``: also write [query xyz | 0] into columns [c3, c3+4) of the output rows (fp32 kernel with counts
+    only); returns whether that was done (False: the caller appends them with ``mpx_append_columns``)."""
     c1, c2, c3 = widths
     if precision == "fp32":
+        fused = bool(append_centre and cnt is not None)
         _lib.call("mpx_sa_mlp", xyz_ptr, stride, new_xyz_ptr, new_stride, feat_ptr, feat_stride, C, _lib.ptr(idx),
-                  _lib.ptr(cnt), B, N, npoint, nsample, _lib.ptr(wpack), c1, c2, c3, out_ptr, out_stride)
-        return
+                  _lib.ptr(cnt), B, N, npoint, nsample, _lib.ptr(wpack), c1, c2, c3, out_ptr, out_stride, int(fused))
+        return fused
     order = None
     if cnt is not None:
         order = torch.empty(B * npoint, dtype=torch.int32, device=idx.device)
@@ -215,6 +219,7 @@ def launch_sa(precision: str, xyz_ptr: int, stride: int, new_xyz_ptr: int, new_s
         _lib.call("mpx_sort_queries", _lib.ptr(cnt), B * npoint, nsample, _lib.ptr(order), _lib.ptr(scratch))
     _lib.call("mpx_sa_mlp_bf16x3", xyz_ptr, stride, new_xyz_ptr, new_stride, feat_ptr, feat_stride, C, _lib.ptr(idx),
               _lib.ptr(cnt), _lib.ptr(order), B, N, npoint, nsample, _lib.ptr(wpack), c1, c2, c3, out_ptr, out_stride)
+    return False
 
 
 def sa_mlp_fused(xyz: torch.Tensor, new_xyz: torch.Tensor, feat: torch.Tensor, feat_stride: int, C: int,

@@ -59,12 +59,12 @@ def main():
     r = {}
     r["fps1"] = timeit(lambda: lib.call("mpx_fps", lib.ptr(xyz), B, N, 4, 512, lib.ptr(idx1), lib.ptr(xyz1), 3))
     r["ball1"] = timeit(lambda: lib.call("mpx_ball_query", lib.ptr(xyz1), 3, lib.ptr(xyz), 4, B, N, 512, 0.05, 128, lib.ptr(nbr1), lib.ptr(cnt1)))
-    r["sa1_mlp"] = timeit(lambda: lib.call("mpx_sa_mlp", lib.ptr(xyz), 4, lib.ptr(xyz1), 3, lib.ptr(xyz) + 12, 4, 1, lib.ptr(nbr1), None, B, N, 512, 128, lib.ptr(w1), 64, 64, 64, lib.ptr(f1), 64))
-    r["sa1_mlp_elide"] = timeit(lambda: lib.call("mpx_sa_mlp", lib.ptr(xyz), 4, lib.ptr(xyz1), 3, lib.ptr(xyz) + 12, 4, 1, lib.ptr(nbr1), lib.ptr(cnt1), B, N, 512, 128, lib.ptr(w1), 64, 64, 64, lib.ptr(f1), 64))
+    r["sa1_mlp"] = timeit(lambda: lib.call("mpx_sa_mlp", lib.ptr(xyz), 4, lib.ptr(xyz1), 3, lib.ptr(xyz) + 12, 4, 1, lib.ptr(nbr1), None, B, N, 512, 128, lib.ptr(w1), 64, 64, 64, lib.ptr(f1), 64, 0))
+    r["sa1_mlp_elide"] = timeit(lambda: lib.call("mpx_sa_mlp", lib.ptr(xyz), 4, lib.ptr(xyz1), 3, lib.ptr(xyz) + 12, 4, 1, lib.ptr(nbr1), lib.ptr(cnt1), B, N, 512, 128, lib.ptr(w1), 64, 64, 64, lib.ptr(f1), 64, 0))
     r["fps2"] = timeit(lambda: lib.call("mpx_fps", lib.ptr(xyz1), B, 512, 3, 128, lib.ptr(idx2), lib.ptr(xyz2), 3))
     r["ball2"] = timeit(lambda: lib.call("mpx_ball_query", lib.ptr(xyz2), 3, lib.ptr(xyz1), 3, B, 512, 128, 0.3, 128, lib.ptr(nbr2), lib.ptr(cnt2)))
-    r["sa2_mlp"] = timeit(lambda: lib.call("mpx_sa_mlp", lib.ptr(xyz1), 3, lib.ptr(xyz2), 3, lib.ptr(f1), 64, 64, lib.ptr(nbr2), None, B, 512, 128, 128, lib.ptr(w2), 128, 128, 256, lib.ptr(f2), 256))
-    r["sa2_mlp_elide"] = timeit(lambda: lib.call("mpx_sa_mlp", lib.ptr(xyz1), 3, lib.ptr(xyz2), 3, lib.ptr(f1), 64, 64, lib.ptr(nbr2), lib.ptr(cnt2), B, 512, 128, 128, lib.ptr(w2), 128, 128, 256, lib.ptr(f2), 256))
+    r["sa2_mlp"] = timeit(lambda: lib.call("mpx_sa_mlp", lib.ptr(xyz1), 3, lib.ptr(xyz2), 3, lib.ptr(f1), 64, 64, lib.ptr(nbr2), None, B, 512, 128, 128, lib.ptr(w2), 128, 128, 256, lib.ptr(f2), 256, 0))
+    r["sa2_mlp_elide"] = timeit(lambda: lib.call("mpx_sa_mlp", lib.ptr(xyz1), 3, lib.ptr(xyz2), 3, lib.ptr(f1), 64, 64, lib.ptr(nbr2), lib.ptr(cnt2), B, 512, 128, 128, lib.ptr(w2), 128, 128, 256, lib.ptr(f2), 256, 0))
     wb1 = sa1._packed.get(sa1.convs(), 1, "bf16x3")
     wb2 = sa2._packed.get(sa2.convs(), 64, "bf16x3")
     r["sa1_bf16x3"] = timeit(lambda: lib.call("mpx_sa_mlp_bf16x3", lib.ptr(xyz), 4, lib.ptr(xyz1), 3, lib.ptr(xyz) + 12, 4, 1, lib.ptr(nbr1), None, None, B, N, 512, 128, lib.ptr(wb1), 64, 64, 64, lib.ptr(f1), 64))
