@@ -310,6 +310,9 @@ int mpx_sa_mlp_factored(const float *pre, const float *ctr, const int32_t *idx, 
                         float *out, int out_stride, mpx_stream_t stream);
 /* mpx_sa_mlp_factored on the bf16 matrix cores (split products, see mpx_sa_mlp_bf16x3): wpack from
  * mpx_sa_pack_bf16x3 (its layer-1 blocks are not read); order (optional) from mpx_sort_queries.          */
+/* host query: does mpx_sa_mlp_bf16x3_factored use `order` (1: the lockstep variant, pass mpx_sort_queries' output for
+ * balanced workgroups) or ignore it (0: the persistent variant takes queries in a static XCD-aware stride)?         */
+int mpx_sa_mlp_bf16x3_factored_wants_order(void);
 int mpx_sa_mlp_bf16x3_factored(const float *pre, const float *ctr, const int32_t *idx, const int32_t *cnt,
                                const int32_t *order, int B, int N, int npoint, int nsample, const void *wpack,
                                int C, int c1, int c2, int c3, float *out, int out_stride, mpx_stream_t stream);

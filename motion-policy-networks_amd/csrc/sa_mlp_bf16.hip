@@ -17,6 +17,8 @@
 // split into packed bf16 hi/lo pairs in place and are the next layer's B operand as they are.
 #include "common.h"
 
+#include <stdlib.h>
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -559,6 +561,332 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
   for (int ot = 0; ot < Cfg::OT3; ++ot) flush(ot, cur[ot]);
 }
 
+// ---- v2 of the factored (64+3, 128, 128, 256) module: persistent workgroups, ONE software-pipelined wave per SIMD ----
+// The lockstep kernel above keeps its matrix pipes ~40 % busy: its non-matrix work (forming relu(pre - ctr) and
+// splitting it into bf16 hi / lo, splitting the layer-2 accumulators, pooling, operand reads -- ~1000-1400 instructions
+// per 288 MFMAs) sits in phases of its own, and a v_mfma_f32_32x32x16_bf16 occupies the pipe for only 32 cycles, so two
+// waves per SIMD cannot cover each other's phases (one wave per SIMD runs the same code at the same speed: measured).
+// This variant is built the way MI355X_MICROARCH.md describes a 512-register wave: ONE wave per SIMD that interleaves
+// <= 4 single-issue instructions behind every MFMA, by construction:
+//   * one persistent workgroup of 4 waves per CU (grid = CU count); a wave takes units of Q = 8 consecutive queries in
+//     a static, XCD-aware stride (all queries of an environment on one XCD: its 512 x 128 first-layer rows stay in one
+//     L2), so no sorting pass is needed and no wave ever waits for another (one barrier, after the LDS fill);
+//   * the layer-3 weights (64 step-tiles x (1 KB hi + 1 KB lo) = 128 KB) live in LDS for the whole kernel, the layer-2
+//     weights (64 KB per tile) stream from L2 through a 4-stage register ring, three K16 steps ahead;
+//   * every layer runs two output tiles at a time on two accumulators (consecutive MFMAs never depend on each other);
+//   * the tile loop is a software pipeline written out in issue order (sched_barrier fences keep it): pair A of layer
+//     2 | pair B + the split of pair A's accumulators | output pair 0 of layer 3 + the split of pair B | output pairs
+//     1-3 + the pooling of the pair before + the NEXT tile's relu(pre - ctr) + split, whose rows were requested when
+//     layer 2 ended.
+// Arithmetic, operand layouts and the weight pack are exactly those of sa_mlp_bf16_kernel<64,128,128,256,Q,true>.
+namespace v2 {
+using Cfg = BCfg<64, 128, 128, 256>;
+constexpr int Q = 8, WV = 4;
+constexpr int C1 = 128, C2 = 128, C3 = 256;
+constexpr int W2_OFF = Cfg::O2 * TILE_BYTES;                 // first layer-2 step-tile (s-major, output tile inner)
+constexpr int W3_OFF = Cfg::O3 * TILE_BYTES;                 // first layer-3 step-tile (output tile major, s inner)
+constexpr int W3_BYTES = Cfg::ST3 * TILE_BYTES;              // 131072
+constexpr int LDS_BIAS2 = W3_BYTES, LDS_BIAS3 = LDS_BIAS2 + 4 * C2, LDS_CTR = LDS_BIAS3 + 4 * C3;
+constexpr int LDS_BYTES = LDS_CTR + WV * Q * C1 * 4;         // 148992
+constexpr int RS = 8, RD = 7;  // layer-2 ring: stages, prefetch distance in K16 steps (7 x 192 pipe cycles of L2 latency cover)
+static_assert(Cfg::ST2 == 32 && Cfg::ST3 == 64 && Cfg::KS1 == 8 && Cfg::KS2 == 8 && Cfg::OT2 == 4 && Cfg::OT3 == 8, "shape");
+}  // namespace v2
+
+#define V2_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+__global__ void __launch_bounds__(64 * v2::WV) __attribute__((amdgpu_waves_per_eu(1, 1)))
+    sa2_bf16x3_persistent_kernel(const int32_t *__restrict__ idx, const int32_t *__restrict__ cnt, int64_t n_query, int N,
+                                 int npoint, int nsample, const unsigned char *__restrict__ wpack, float *__restrict__ out,
+                                 int out_stride, const float *__restrict__ pre_rows, const float *__restrict__ ctr,
+                                 int xcd_aware) {
+  using namespace v2;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int half = lane >> 5, col = lane & 31;
+  {  // layer-3 weights + the two bias vectors -> LDS, once
+    const uint4 *src = reinterpret_cast<const uint4 *>(wpack + W3_OFF);
+    uint4 *dst = reinterpret_cast<uint4 *>(smem);
+    for (int i = threadIdx.x; i < W3_BYTES / 16; i += 64 * WV) dst[i] = src[i];
+    float *b2 = reinterpret_cast<float *>(smem + LDS_BIAS2);
+    for (int i = threadIdx.x; i < C2 + C3; i += 64 * WV)
+      b2[i] = reinterpret_cast<const float *>(wpack + Cfg::B2_OFF)[i];  // b2 | b3 are contiguous in the pack
+  }
+  __syncthreads();  // the only barrier: from here on the waves are independent
+  const float *bias2_s = reinterpret_cast<const float *>(smem + LDS_BIAS2);
+  const float *bias3_s = reinterpret_cast<const float *>(smem + LDS_BIAS3);
+  float *ctr_w = reinterpret_cast<float *>(smem + LDS_CTR) + wave * Q * C1;
+  const unsigned char *w3_lane = smem + lane * 16;
+
+  const __amdgpu_buffer_rsrc_t wrsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(wpack), 0, (int)Cfg::TOTAL_BYTES, 0x00020000);
+  const int wvoff = lane * 16;
+  // layer-2 operand ring: one stage = the (hi, lo) blocks of TWO output tiles (a pair) at one K16 step; running
+  // step n = pair * 8 + s lives in stage n % RS
+  u32x4 ring[RS][4];
+  auto fetch2 = [&](int n) __attribute__((always_inline)) {
+    const int pair = n >> 3, s = n & 7;
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+      const int off = W2_OFF + (s * 4 + 2 * pair + o) * TILE_BYTES;
+      ring[n % RS][2 * o] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff, off, 0);
+      ring[n % RS][2 * o + 1] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff, off + 1024, 0);
+    }
+  };
+  auto as_bf = [](const u32x4 &v) __attribute__((always_inline)) { return __builtin_bit_cast(bf16x8, v); };
+#pragma unroll
+  for (int n = 0; n < RD; ++n) fetch2(n);
+
+  // relu + hi / lo split of elements (2e, 2e+1) of a 16-float accumulator tile into the packed bf16 operand pairs
+  // (one "quantum": ~8 VALU) -- relu_split_tile, two elements at a time
+  auto split_q = [&](const f32x16 &acc, bf16x8 (&hi)[2], bf16x8 (&lo)[2], int e) __attribute__((always_inline)) {
+    const int u = e >> 2, k = 2 * (e & 3);
+    const float v0 = fmaxf(acc[8 * u + k], 0.0f), v1 = fmaxf(acc[8 * u + k + 1], 0.0f);
+    const __bf16 h0 = (__bf16)v0, h1 = (__bf16)v1;
+    hi[u][k] = h0;
+    hi[u][k + 1] = h1;
+    lo[u][k] = (__bf16)(v0 - (float)h0);
+    lo[u][k + 1] = (__bf16)(v1 - (float)h1);
+  };
+
+  // ---- the units of this wave ------------------------------------------------------------------------------------
+  const int64_t n_units = (n_query + Q - 1) / Q;
+  const int upe = npoint / Q;  // units per environment (xcd_aware only)
+  int64_t j, j_end, j_step;
+  int xcd = 0;
+  if (xcd_aware) {
+    xcd = blockIdx.x & 7;
+    j = (int64_t)(blockIdx.x >> 3) * WV + wave;
+    j_step = (int64_t)(gridDim.x >> 3) * WV;
+    j_end = (n_query / npoint / 8) * upe;  // units of this XCD: environments xcd, xcd + 8, ...
+  } else {
+    j = (int64_t)blockIdx.x * WV + wave;
+    j_step = (int64_t)gridDim.x * WV;
+    j_end = n_units;
+  }
+  for (; j < j_end; j += j_step) {
+    const int64_t unit = xcd_aware ? ((j / upe) * 8 + xcd) * upe + j % upe : j;
+    const int64_t q0 = unit * Q;
+    const int nq = (int)min((int64_t)Q, n_query - q0);
+    int my_cnt = 1, my_rows = 0, my_env = 0;
+    if (lane < nq) {
+      const int c = cnt[q0 + lane];
+      my_cnt = c <= 0 ? 1 : (c > nsample ? nsample : c);  // no hit: the zero-initialised row = point 0
+      my_rows = (my_cnt + 3) & ~3;
+      my_env = (int)((q0 + lane) / npoint);
+    }
+    int pre = my_rows;
+#pragma unroll
+    for (int o = 1; o < Q; o <<= 1) {
+      const int t = __shfl_up(pre, o);
+      if (lane >= o) pre += t;
+    }
+    const int total = __builtin_amdgcn_readlane(pre, Q - 1);
+    pre -= my_rows;
+    int s_pre[Q], s_cnt[Q], s_env[Q];
+#pragma unroll
+    for (int i = 0; i < Q; ++i) {
+      s_pre[i] = __builtin_amdgcn_readlane(pre, i);
+      s_cnt[i] = __builtin_amdgcn_readlane(my_cnt, i);
+      s_env[i] = __builtin_amdgcn_readlane(my_env, i);
+    }
+    const int n_rows = total <= 32 ? 32 : ((total + 31) & ~31);
+    // this unit's per-query first-layer terms -> this wave's LDS rows (Q x 32 float4: Q / 2 per lane)
+#pragma unroll
+    for (int u = 0; u < Q / 2; ++u) {
+      const int i = lane + 64 * u, qi = i >> 5, c4 = i & 31;
+      if (qi < nq)
+        *reinterpret_cast<float4 *>(ctr_w + qi * C1 + 4 * c4) =
+            *reinterpret_cast<const float4 *>(ctr + (q0 + qi) * C1 + 4 * c4);
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    // row -> (local query, environment, neighbour slot); rows past the end repeat the last query's first slot
+    auto map_row = [&](int p, int &qi, int &env, int &off) __attribute__((always_inline)) {
+      int qpre = 0, qcnt = s_cnt[0];
+      qi = 0;
+      env = s_env[0];
+#pragma unroll
+      for (int i = 1; i < Q; ++i) {
+        const bool ge = i < nq && p >= s_pre[i];
+        qi = ge ? i : qi;
+        env = ge ? s_env[i] : env;
+        qpre = ge ? s_pre[i] : qpre;
+        qcnt = ge ? s_cnt[i] : qcnt;
+      }
+      const int slot = p - qpre;
+      off = slot < qcnt ? slot : 0;
+    };
+    float raw_pre[C1 / 2];  // this lane-half's 4-channel groups of the gathered first-layer row
+    auto gather = [&](int env, int k) __attribute__((always_inline)) {
+      const float *pa = pre_rows + ((int64_t)env * N + k) * (int64_t)C1 + 4 * half;
+#pragma unroll
+      for (int i = 0; i < C1 / 8; ++i) {
+        const float4 v = *reinterpret_cast<const float4 *>(pa + 8 * i);
+        raw_pre[4 * i + 0] = v.x, raw_pre[4 * i + 1] = v.y, raw_pre[4 * i + 2] = v.z, raw_pre[4 * i + 3] = v.w;
+      }
+    };
+    float run[Cfg::OT3];
+#pragma unroll
+    for (int ot = 0; ot < Cfg::OT3; ++ot) run[ot] = -__builtin_inff();
+    int cur = 0;  // local query being merged (wave-uniform)
+    auto flush = [&](int ot, int qi) __attribute__((always_inline)) {
+      float v = run[ot];
+      v = mpx_max_across_halves(v);
+      const int ch = ot * 32 + col;
+      v = fmaxf(v + bias3_s[ch], 0.0f);
+      if (half == 0) out[(q0 + qi) * out_stride + ch] = v;
+      run[ot] = -__builtin_inff();
+    };
+
+    // layer-2 operands of the tile being computed; formed for the NEXT tile during layer 3 of this one
+    bf16x8 h1[4][2], l1[4][2];
+    float4 cq[4];  // the four ctr float4 of the 32-channel group being formed
+    // quantum g (0..31) of relu(pre - ctr) + split for the row in raw_pre and its query's LDS row `cqp`: channels
+    // 4-group i = g >> 1 (tile ot = i >> 2, register group i & 3), element pair (g & 1)
+    auto form_q = [&](const float *cqp, int g) __attribute__((always_inline)) {
+      const int i = g >> 1, ot = i >> 2, gg = i & 3, pr2 = g & 1;
+      if (pr2 == 0) cq[gg] = *reinterpret_cast<const float4 *>(cqp + 8 * i);
+      const float c0 = pr2 ? cq[gg].z : cq[gg].x, c1 = pr2 ? cq[gg].w : cq[gg].y;
+      const float v0 = fmaxf(raw_pre[4 * i + 2 * pr2] - c0, 0.0f), v1 = fmaxf(raw_pre[4 * i + 2 * pr2 + 1] - c1, 0.0f);
+      // accumulator register r = 4 * gg + 2 * pr2 (+1) of tile ot -> operand pair u = r >> 3, element r & 7
+      const int r = 4 * gg + 2 * pr2, u = r >> 3, k = r & 7;
+      const __bf16 h0 = (__bf16)v0, hh1 = (__bf16)v1;
+      h1[ot][u][k] = h0;
+      h1[ot][u][k + 1] = hh1;
+      l1[ot][u][k] = (__bf16)(v0 - (float)h0);
+      l1[ot][u][k + 1] = (__bf16)(v1 - (float)hh1);
+    };
+
+    // row pipeline: the neighbour index of a tile's row is loaded a tile before its first-layer row is gathered (at the
+    // end of layer 2 of the tile before), which is formed during layer 3 of that tile
+    int ql_cur, ql_next = 0, env_next = 0, k_next = 0;
+    {  // unit prologue: the first tile's rows, formed without cover (once per ~16 tiles)
+      int env, off;
+      map_row(col, ql_cur, env, off);
+      const int k0 = idx[(q0 + ql_cur) * nsample + off];
+      gather(env, k0);
+      map_row(32 + col, ql_next, env_next, off);
+      k_next = idx[(q0 + ql_next) * nsample + off];
+      const float *cqp = ctr_w + ql_cur * C1 + 4 * half;
+#pragma unroll
+      for (int g = 0; g < 32; ++g) form_q(cqp, g);
+    }
+
+    for (int rt = 0; rt < n_rows; rt += 32) {
+      const int ql_tile = ql_cur;
+      const int env_gather = env_next, k_gather = k_next;
+      const float *cq_next = ctr_w + ql_next * C1 + 4 * half;  // LDS row of the next tile's query (this lane's row)
+      ql_cur = ql_next;
+      V2_FENCE();
+      {  // index of the row after next: issued now, consumed a tile later (rows past the end are clamped by map_row)
+        int off;
+        map_row(rt + 64 + col, ql_next, env_next, off);
+        k_next = idx[(q0 + ql_next) * nsample + off];
+      }
+      int gq[8];
+#pragma unroll
+      for (int g = 0; g < 8; ++g) gq[g] = __builtin_amdgcn_readlane(ql_tile, 4 * g);
+      V2_FENCE();
+      // ---- layer 2: Ht = W . Xt, pair A then pair B; MFMA m of a pair = (s, pass, o) = (m / 6, (m % 6) / 2, m % 2) -----
+      f32x16 a2[4];
+      bf16x8 h2[4][2], l2[4][2];
+      a2[0] = bias_tile_lds(bias2_s, 0, half);
+      a2[1] = bias_tile_lds(bias2_s, 1, half);
+      a2[2] = bias_tile_lds(bias2_s, 2, half);
+      a2[3] = bias_tile_lds(bias2_s, 3, half);
+      V2_FENCE();
+#pragma unroll
+      for (int m = 0; m < 96; ++m) {
+        const int pair = m / 48, mm = m % 48, s = mm / 6, pass = (mm % 6) / 2, o = mm % 2, n = pair * 8 + s;
+        if (mm % 6 == 0 && n + RD < 16) fetch2(n + RD);  // (the ring never holds more than RS = RD + 1 steps)
+        a2[2 * pair + o] = mfma_bf16(as_bf(ring[n % RS][2 * o + (pass == 1 ? 1 : 0)]),
+                                     pass == 2 ? l1[s >> 1][s & 1] : h1[s >> 1][s & 1], a2[2 * pair + o]);
+        // pair A's accumulators are final after MFMA 47: their relu + split rides behind pair B's MFMAs (16 quanta)
+        if (pair == 1 && mm % 3 == 2) split_q(a2[(mm / 3) >> 3], h2[(mm / 3) >> 3], l2[(mm / 3) >> 3], (mm / 3) & 7);
+        V2_FENCE();
+      }
+      // the next tile's rows are requested now: layer 3 reads LDS only, so these slower loads are not in front of
+      // anything the matrix stream waits for; they are consumed from output pair 2 on (~3000 cycles from here)
+      gather(env_gather, k_gather);
+      V2_FENCE();
+      // ---- layer 3 (roles flipped: activations are A, weights B), output tiles in pairs, weights from LDS ------------
+      bf16x8 w3r[3][4];  // operand stages: running step n3 = pr * 8 + s lives in stage n3 % 3, read two steps ahead
+      auto load3 = [&](int n3) __attribute__((always_inline)) {
+        const int pr = n3 >> 3, s = n3 & 7;
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+          const unsigned char *p = w3_lane + ((2 * pr + o) * 8 + s) * TILE_BYTES;
+          w3r[n3 % 3][2 * o] = *reinterpret_cast<const bf16x8 *>(p);
+          w3r[n3 % 3][2 * o + 1] = *reinterpret_cast<const bf16x8 *>(p + 1024);
+        }
+      };
+      load3(0);
+      load3(1);
+      f32x16 a3[2][2];
+      auto pool = [&](int pr, int part) __attribute__((always_inline)) {  // output pair pr, tile o = part
+        const int ot = 2 * pr + part;
+        const f32x16 &a = a3[pr & 1][part];
+        float gm[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+          gm[jj] = fmaxf(fmaxf(a[4 * jj], a[4 * jj + 1]), fmaxf(a[4 * jj + 2], a[4 * jj + 3]));
+        if (gq[7] == cur) {  // the whole tile belongs to the query being merged (the common case)
+          run[ot] = fmaxf(run[ot], fmaxf(fmaxf(gm[0], gm[1]), fmaxf(gm[2], gm[3])));
+        } else {
+          int c = cur;
+#pragma unroll
+          for (int g = 0; g < 8; ++g) {
+            if (gq[g] != c) {
+              flush(ot, c);
+              c = gq[g];
+            }
+            run[ot] = fmaxf(run[ot], ((g & 1) == half) ? gm[g >> 1] : -__builtin_inff());
+          }
+        }
+      };
+      V2_FENCE();
+#pragma unroll
+      for (int m = 0; m < 192; ++m) {
+        const int pr = m / 48, mm = m % 48, s = mm / 6, pass = (mm % 6) / 2, o = mm % 2, n3 = pr * 8 + s;
+        if (mm % 6 == 0) {
+          if (n3 + 2 < 32) load3(n3 + 2);
+        }
+        {
+          const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+          const bf16x8 x = pass == 2 ? l2[s >> 1][s & 1] : h2[s >> 1][s & 1];
+          const bf16x8 w = w3r[n3 % 3][2 * o + (pass == 1 ? 1 : 0)];
+          a3[pr & 1][o] = mfma_bf16(x, w, (s == 0 && pass == 0) ? zero : a3[pr & 1][o]);
+        }
+        // fillers, by position in the tile:
+        if (pr == 0) {  // pair B's split: tile 2 behind the first 12 MFMAs (needed from s = 4), tile 3 behind the next 12
+          if (mm < 24 && mm % 3 == 0) split_q(a2[2 + mm / 12], h2[2 + mm / 12], l2[2 + mm / 12], (mm % 12) / 3 * 2);
+          if (mm < 24 && mm % 3 == 1) split_q(a2[2 + mm / 12], h2[2 + mm / 12], l2[2 + mm / 12], (mm % 12) / 3 * 2 + 1);
+        } else {
+          // pooling of the pair before: its two tiles behind MFMAs 0 and 24 of this pair
+          if (mm == 0) pool(pr - 1, 0);
+          if (mm == 24) pool(pr - 1, 1);
+          // the NEXT tile's layer-2 operands: 32 quanta over output pairs 2 and 3 (the rows were requested at the end of
+          // layer 2)
+          if (pr >= 2 && mm % 3 == 1) form_q(cq_next, (pr - 2) * 16 + mm / 3);
+        }
+        if (m == 191) {  // the first layer-2 stages of the NEXT tile (the weights never change)
+#pragma unroll
+          for (int n = 0; n < RD; ++n) fetch2(n);
+        }
+        V2_FENCE();
+      }
+      pool(3, 0);
+      pool(3, 1);
+      cur = gq[7];
+      V2_FENCE();
+    }
+#pragma unroll
+    for (int ot = 0; ot < Cfg::OT3; ++ot) flush(ot, cur);
+    __builtin_amdgcn_wave_barrier();  // (this wave's ctr rows are rewritten by the next unit)
+  }
+}
+
 // ---- host entry points --------------------------------------------------------------------------------------------
 #define SA_DISPATCH(CALL)                                                                   \
   if (C == 1 && c1 == 64 && c2 == 64 && c3 == 64) { CALL(1, 64, 64, 64); }                  \
@@ -583,19 +911,44 @@ static int launch_sa_bf16(const float *xyz, int stride, const float *new_xyz, in
   MPX_LAUNCH_CHECK("mpx_sa_mlp_bf16x3");
 }
 
+static int bf16_factored_v2() {
+  static const int use_v2 = getenv("MPX_BF16_V2") ? atoi(getenv("MPX_BF16_V2")) : 1;
+  return use_v2;
+}
+
+// 1: the factored kernel walks the queries in the caller's `order` (lockstep variant); 0: it ignores it
+MPX_EXPORT int mpx_sa_mlp_bf16x3_factored_wants_order(void) { return bf16_factored_v2() ? 0 : 1; }
+
 MPX_EXPORT int mpx_sa_mlp_bf16x3_factored(const float *pre, const float *ctr, const int32_t *idx, const int32_t *cnt,
                                           const int32_t *order, int B, int N, int npoint, int nsample, const void *wpack,
                                           int C, int c1, int c2, int c3, float *out, int out_stride, mpx_stream_t stream) {
   MPX_REQUIRE(C == 64 && c1 == 128 && c2 == 128 && c3 == 256,
               "mpx_sa_mlp_bf16x3_factored: built for the (64+3, 128, 128, 256) module (C=%d, %d, %d, %d)", C, c1, c2, c3);
   MPX_REQUIRE(B >= 0 && N >= 1 && npoint >= 0 && nsample > 0, "mpx_sa_mlp_bf16x3_factored: bad size");
-  MPX_REQUIRE(pre && ctr && idx, "mpx_sa_mlp_bf16x3_factored: NULL operand");
+  MPX_REQUIRE(pre && ctr && idx && cnt, "mpx_sa_mlp_bf16x3_factored: NULL operand (hit counts are required)");
   MPX_REQUIRE(out_stride >= c3, "mpx_sa_mlp_bf16x3_factored: bad stride");
   MPX_REQUIRE((((uintptr_t)wpack | (uintptr_t)pre | (uintptr_t)ctr) & 15) == 0,
               "mpx_sa_mlp_bf16x3_factored: operands must be 16-byte aligned");
   if (B == 0 || npoint == 0) return 0;
   const int64_t nq = (int64_t)B * npoint;
   MPX_REQUIRE(nq < ((int64_t)1 << 31), "mpx_sa_mlp_bf16x3_factored: too many query points");
+  if (bf16_factored_v2()) {  // persistent, barrier-free variant (ignores `order`: no sorting pass is needed)
+    static int cus[64];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!cus[dev & 63]) {
+      int n = 0;
+      MPX_REQUIRE(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0,
+                  "mpx_sa_mlp_bf16x3_factored: cannot query the CU count");
+      cus[dev & 63] = n;
+    }
+    const int grid = cus[dev & 63];
+    const int xcd_aware = (B % 8 == 0 && grid % 8 == 0 && npoint % v2::Q == 0) ? 1 : 0;
+    MPX_LDS_LIMIT_ONCE(sa2_bf16x3_persistent_kernel, v2::LDS_BYTES, "mpx_sa_mlp_bf16x3_factored");
+    hipLaunchKernelGGL(sa2_bf16x3_persistent_kernel, dim3(grid), dim3(64 * v2::WV), v2::LDS_BYTES, mpx_s(stream), idx, cnt, nq, N,
+                       npoint, nsample, static_cast<const unsigned char *>(wpack), out, out_stride, pre, ctr, xcd_aware);
+    MPX_LAUNCH_CHECK("mpx_sa_mlp_bf16x3_factored");
+  }
   constexpr int Q = 4;
   const int64_t per_block = (int64_t)WAVES * Q;
   hipLaunchKernelGGL((sa_mlp_bf16_kernel<64, 128, 128, 256, Q, true>), dim3((unsigned)((nq + per_block - 1) / per_block)),

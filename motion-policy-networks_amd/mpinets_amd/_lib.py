@@ -52,6 +52,7 @@ PROTOTYPES = {
     "mpx_group_points": [P, I, P, I, P, I, I, P, I, I, I, I, P, P],
     "mpx_sa_mlp": [P, I, P, I, P, I, I, P, P, I, I, I, I, P, I, I, I, P, I, I, P],
     "mpx_sa_mlp_factored": [P, P, P, P, I, I, I, I, P, I, I, I, I, P, I, P],
+    "mpx_sa_mlp_bf16x3_factored_wants_order": [],
     "mpx_sa_mlp_bf16x3_factored": [P, P, P, P, P, I, I, I, I, P, I, I, I, I, P, I, P],
     "mpx_sa_pack_size": [I, I, I, I],
     "mpx_sa_pack_weights": [P, P, P, P, P, P, I, I, I, I, P, P],
