@@ -21,7 +21,7 @@ for arg in "$@"; do
       timeout 1200 python bench.py $val > gpurun_out/bench.log 2> gpurun_out/bench.err
       echo "bench exit: $?" >> gpurun_out/bench.err; tail -3 gpurun_out/bench.err; cat gpurun_out/bench.log ;;
     prof)
-      ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof && timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o run -- python $REPO/bench.py ${val:---steps 3 --warmup 1 --cpu-envs 0 --extra 0 --fast-steps 0} > $REPO/gpurun_out/prof_bench.log 2> $REPO/gpurun_out/prof.err
+      ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof && timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o run -- python $REPO/bench.py ${val:---steps 3 --warmup 1 --cpu-envs 0 --extra 0 --fast-steps 0 --pipeline-steps 0} > $REPO/gpurun_out/prof_bench.log 2> $REPO/gpurun_out/prof.err
         echo "prof exit: $?" >> $REPO/gpurun_out/prof.err
         mkdir -p $REPO/gpurun_out/prof; find /tmp/prof -name "*stats*" -exec cp {} $REPO/gpurun_out/prof/ \; ; ls -la /tmp/prof/* | head -20 >> $REPO/gpurun_out/prof.err )
       tail -3 gpurun_out/prof.err; cat gpurun_out/prof_bench.log | tail -1 | cut -c1-200; head -12 gpurun_out/prof/*kernel_stats.csv ;;
@@ -30,7 +30,7 @@ for arg in "$@"; do
       i=0
       for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY"; do
         i=$((i+1))
-        ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/pmc$i && timeout 900 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d /tmp/pmc$i -o run -- python $REPO/bench.py ${val:---envs 2048 --steps 2 --warmup 1 --cpu-envs 0} > $REPO/gpurun_out/pmc${i}_bench.log 2> $REPO/gpurun_out/pmc$i.err
+        ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/pmc$i && timeout 900 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d /tmp/pmc$i -o run -- python $REPO/bench.py ${val:---envs 8192 --steps 2 --warmup 1 --cpu-envs 0 --extra 0 --fast-steps 0 --pipeline-steps 0} > $REPO/gpurun_out/pmc${i}_bench.log 2> $REPO/gpurun_out/pmc$i.err
           echo "pmc$i exit: $?" >> $REPO/gpurun_out/pmc$i.err
           mkdir -p $REPO/gpurun_out/pmc; for f in $(find /tmp/pmc$i -name "*counter_collection.csv"); do python $REPO/tools/pmc_summary.py $f > $REPO/gpurun_out/pmc/pass${i}_summary.csv 2>> $REPO/gpurun_out/pmc$i.err; done )
         tail -2 gpurun_out/pmc$i.err; head -20 gpurun_out/pmc/pass${i}_summary.csv
