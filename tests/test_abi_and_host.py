@@ -68,6 +68,20 @@ def test_library_loads_and_reports_errors_without_gpu():
     assert b"multiples of 4" in lib.mpx_last_error()
     assert lib.mpx_fps(None, 1, 100000, 3, 4, None, None, 3, None) != 0
     assert b"8192" in lib.mpx_last_error()
+    # round-2 entry points: the global-environment offset is range-checked, the rollout options are validated
+    import ctypes
+
+    one = ctypes.c_void_p(256)  # any non-NULL "device pointer": validation fails before it is touched
+    assert lib.mpx_scene_cloud(one, one, one, 1, one, one, one, one, 1, 4, 8, 0, -1, one, None, None, one, 32, 4, 0, None) != 0
+    assert b"env_offset" in lib.mpx_last_error()
+    assert lib.mpx_scene_cloud(one, one, one, 1, one, one, one, one, 1, 4, 8, 0, (1 << 32), one, None, None, one, 32, 4, 0, None) != 0
+    assert lib.mpx_depth_select(one, one, 1.0, 1.0, 0.0, 0.0, 4, 4, 1, 4, 0, -5, one, 12, 3, one, None) != 0
+    assert lib.mpx_batch_configs(one, 1, 2, one, None, one, 0.0, 0, -1, 0, 1, 0.025, one, one, None, one, one, None) != 0
+    assert lib.mpx_rollout(None, None, None, None, 6272, None, None, 1, None, None, None, 0, None) != 0
+    assert b"NULL operand" in lib.mpx_last_error()
+    assert lib.mpx_sa_mlp_bf16x3_factored_wants_order() in (0, 1)
+    assert lib.mpx_rollout_workspace(4, 6272) > lib.mpx_policy_workspace(4, 6272) > 0
+    assert lib.mpx_policy_workspace(8192, 6272) < 8 * (1 << 30)  # (round 1: 11.5 GB; dead buffers share memory now)
 
 
 def test_header_is_plain_c_and_a_c_client_links(tmp_path):

@@ -615,3 +615,23 @@ def test_operands_on_another_device_are_rejected():
     else:
         with pytest.raises(_lib.MpxError, match="current device"):
             _lib.require_cuda(torch.zeros(1, device="cuda:1"))
+
+
+def test_persistent_sa2_kernel_is_bit_identical_to_the_two_wave_kernel():
+    """MPX_SA2_PERSISTENT=1 (one software-pipelined wave per SIMD, layer-3 weights in LDS, device-side unit queue) walks
+    every output tile's k-steps in the two-wave kernel's order: pooled rows, policy output and a 3-step closed loop hash
+    the same.  (The switch is read once per process: two subprocesses.)"""
+    import os
+    import re
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for v in ("0", "1"):
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "sa2_ab.py"), "1024", "2"],
+                           env=dict(os.environ, MPX_SA2_PERSISTENT=v), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[v] = re.findall(r"(?:sa2 rows|dq|q hash) ([0-9a-f]{16})", r.stdout)
+        assert len(out[v]) == 3, r.stdout
+    assert out["0"] == out["1"], out

@@ -79,3 +79,29 @@ def test_problem_batch_rows_do_not_depend_on_the_shard():
             for k, v in whole.items():
                 if torch.is_tensor(v) and v.size(0) == 14:
                     assert torch.equal(part[k], v[o:o + n]), (k, pool, clouds, o)
+
+
+def test_pipelined_rollout_equals_single_engine():
+    """rollout.PipelinedRollout (the batch in shares on their own HIP streams, a stage apart) leaves exactly the state one
+    engine over the whole batch leaves -- shares of >= 1025 environments keep the whole batch's launch shapes."""
+    from mpinets_amd.model import MotionPolicyNetwork
+    from mpinets_amd.rollout import PipelinedRollout, RolloutEngine
+    from mpinets_amd.scenes import make_problem_batch
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    mdl = MotionPolicyNetwork().to(dev).eval()
+    B, steps = 2080, 3
+    mk = lambda: make_problem_batch(B, seed=12, device=dev, kinds=("tabletop", "cubby", "dresser"), M1=40, M2=16, scene_pool=64,
+                                    device_clouds=True, env_offset=7, total_envs=B + 7)
+    one = RolloutEngine(mdl, mk(), rerender_scene=True, scene_seed=3)
+    for _ in range(steps):
+        one.step()
+    prob = mk()
+    pr = PipelinedRollout(mdl, prob, ways=2, rerender_scene=True, scene_seed=3)
+    assert [e.env_offset for e in pr.engines] == [7, 7 + B // 2]
+    pr.run(2)
+    pr.run(steps - 2)  # (continues: the stagger is applied once, the step counters carry over)
+    torch.cuda.synchronize()
+    assert torch.equal(pr.q, one.q) and torch.equal(pr.q_norm, one.q_norm) and torch.equal(pr.flags, one.flags)
+    assert torch.equal(prob["xyz"], one.xyz)  # the shares are views of the caller's slab: updated in place
