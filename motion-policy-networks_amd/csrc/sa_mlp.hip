@@ -655,7 +655,7 @@ static_assert(G2 == 64 && G3 == 128 && GPT == 16 && Cfg::OT2 == 4 && Cfg::OT3 ==
 // (stream-ordered, hipGraph-capturable).  Launches on different streams use different slots unless more than 64 are in
 // flight on one device at once.
 __device__ unsigned int sa2p_queues[64 * 8];
-static unsigned int *sa2p_next_queue(hipStream_t stream) {
+unsigned int *mpx_next_unit_queue(hipStream_t stream) {
   static std::atomic<unsigned int> turn{0};
   static unsigned int *base[64];
   int dev = 0;
@@ -1074,7 +1074,7 @@ MPX_EXPORT int mpx_sa_mlp_factored(const float *pre, const float *ctr, const int
     const int grid = cus[dev & 63];
     const int xcd_aware = (B % 8 == 0 && grid % 8 == 0 && npoint % sa2p::Q == 0) ? 1 : 0;
     MPX_LDS_LIMIT_ONCE(sa2_fp32_persistent_kernel, sa2p::LDS_BYTES, "mpx_sa_mlp_factored");
-    unsigned int *queue = sa2p_next_queue(mpx_s(stream));
+    unsigned int *queue = mpx_next_unit_queue(mpx_s(stream));
     MPX_REQUIRE(queue != nullptr, "mpx_sa_mlp_factored: cannot reset the unit queue");
     hipLaunchKernelGGL(sa2_fp32_persistent_kernel, dim3(grid), dim3(64 * sa2p::WV), sa2p::LDS_BYTES, mpx_s(stream), idx, cnt, nq,
                        N, npoint, nsample, wpack, out, out_stride, pre, ctr, xcd_aware, queue);

@@ -569,8 +569,9 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
 // This variant is built the way MI355X_MICROARCH.md describes a 512-register wave: ONE wave per SIMD that interleaves
 // <= 4 single-issue instructions behind every MFMA, by construction:
 //   * one persistent workgroup of 4 waves per CU (grid = CU count); a wave takes units of Q = 8 consecutive queries in
-//     a static, XCD-aware stride (all queries of an environment on one XCD: its 512 x 128 first-layer rows stay in one
-//     L2), so no sorting pass is needed and no wave ever waits for another (one barrier, after the LDS fill);
+//     the order of a device-side queue (one counter per XCD: all queries of an environment on one XCD, its 512 x 128
+//     first-layer rows stay in one L2), so no sorting pass is needed and no wave ever waits for another (one barrier,
+//     after the LDS fill);
 //   * the layer-3 weights (64 step-tiles x (1 KB hi + 1 KB lo) = 128 KB) live in LDS for the whole kernel, the layer-2
 //     weights (64 KB per tile) stream from L2 through a 4-stage register ring, three K16 steps ahead;
 //   * every layer runs two output tiles at a time on two accumulators (consecutive MFMAs never depend on each other);
@@ -598,7 +599,7 @@ __global__ void __launch_bounds__(64 * v2::WV) __attribute__((amdgpu_waves_per_e
     sa2_bf16x3_persistent_kernel(const int32_t *__restrict__ idx, const int32_t *__restrict__ cnt, int64_t n_query, int N,
                                  int npoint, int nsample, const unsigned char *__restrict__ wpack, float *__restrict__ out,
                                  int out_stride, const float *__restrict__ pre_rows, const float *__restrict__ ctr,
-                                 int xcd_aware) {
+                                 int xcd_aware, unsigned int *__restrict__ queue) {
   using namespace v2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63;
@@ -626,12 +627,11 @@ __global__ void __launch_bounds__(64 * v2::WV) __attribute__((amdgpu_waves_per_e
   u32x4 ring[RS][4];
   auto fetch2 = [&](int n) __attribute__((always_inline)) {
     const int pair = n >> 3, s = n & 7;
+    // one scalar offset per stage; the four 1 KB blocks (hi, lo of the pair's two tiles) sit in the instruction's
+    // 12-bit immediate (lane * 16 + 3072 < 4096): a fourth of the s_mov's of one-offset-per-load
+    const int base = W2_OFF + (s * 4 + 2 * pair) * TILE_BYTES;
 #pragma unroll
-    for (int o = 0; o < 2; ++o) {
-      const int off = W2_OFF + (s * 4 + 2 * pair + o) * TILE_BYTES;
-      ring[n % RS][2 * o] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff, off, 0);
-      ring[n % RS][2 * o + 1] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff, off + 1024, 0);
-    }
+    for (int k = 0; k < 4; ++k) ring[n % RS][k] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff + 1024 * k, base, 0);
   };
   auto as_bf = [](const u32x4 &v) __attribute__((always_inline)) { return __builtin_bit_cast(bf16x8, v); };
 #pragma unroll
@@ -649,22 +649,23 @@ __global__ void __launch_bounds__(64 * v2::WV) __attribute__((amdgpu_waves_per_e
     lo[u][k + 1] = (__bf16)(v1 - (float)h1);
   };
 
-  // ---- the units of this wave ------------------------------------------------------------------------------------
+  // ---- the units of this wave: handed out by a device-side queue (one counter per XCD: an environment's units go to
+  // the waves of one XCD, in order); the next unit is requested when the current one starts.  Unit sizes differ 1 : 30:
+  // with a static stride the waves were resident 87 % of the kernel. ---------------------------------------------
   const int64_t n_units = (n_query + Q - 1) / Q;
   const int upe = npoint / Q;  // units per environment (xcd_aware only)
-  int64_t j, j_end, j_step;
-  int xcd = 0;
-  if (xcd_aware) {
-    xcd = blockIdx.x & 7;
-    j = (int64_t)(blockIdx.x >> 3) * WV + wave;
-    j_step = (int64_t)(gridDim.x >> 3) * WV;
-    j_end = (n_query / npoint / 8) * upe;  // units of this XCD: environments xcd, xcd + 8, ...
-  } else {
-    j = (int64_t)blockIdx.x * WV + wave;
-    j_step = (int64_t)gridDim.x * WV;
-    j_end = n_units;
-  }
-  for (; j < j_end; j += j_step) {
+  const int xcd = xcd_aware ? (blockIdx.x & 7) : 0;
+  const int64_t j_end = xcd_aware ? (n_query / npoint / 8) * upe : n_units;  // units of this queue
+  auto next_unit = [&]() __attribute__((always_inline)) {
+    unsigned int v = 0;
+    if (lane == 0) v = atomicAdd(queue + xcd, 1u);
+    return (int64_t)(unsigned int)__builtin_amdgcn_readfirstlane((int)v);
+  };
+  int64_t j_next = next_unit();
+  while (true) {
+    const int64_t j = j_next;
+    if (j >= j_end) break;
+    j_next = next_unit();
     const int64_t unit = xcd_aware ? ((j / upe) * 8 + xcd) * upe + j % upe : j;
     const int64_t q0 = unit * Q;
     const int nq = (int)min((int64_t)Q, n_query - q0);
@@ -945,8 +946,10 @@ MPX_EXPORT int mpx_sa_mlp_bf16x3_factored(const float *pre, const float *ctr, co
     const int grid = cus[dev & 63];
     const int xcd_aware = (B % 8 == 0 && grid % 8 == 0 && npoint % v2::Q == 0) ? 1 : 0;
     MPX_LDS_LIMIT_ONCE(sa2_bf16x3_persistent_kernel, v2::LDS_BYTES, "mpx_sa_mlp_bf16x3_factored");
+    unsigned int *queue = mpx_next_unit_queue(mpx_s(stream));
+    MPX_REQUIRE(queue != nullptr, "mpx_sa_mlp_bf16x3_factored: cannot reset the unit queue");
     hipLaunchKernelGGL(sa2_bf16x3_persistent_kernel, dim3(grid), dim3(64 * v2::WV), v2::LDS_BYTES, mpx_s(stream), idx, cnt, nq, N,
-                       npoint, nsample, static_cast<const unsigned char *>(wpack), out, out_stride, pre, ctr, xcd_aware);
+                       npoint, nsample, static_cast<const unsigned char *>(wpack), out, out_stride, pre, ctr, xcd_aware, queue);
     MPX_LAUNCH_CHECK("mpx_sa_mlp_bf16x3_factored");
   }
   constexpr int Q = 4;
