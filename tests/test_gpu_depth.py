@@ -123,3 +123,36 @@ def test_full_resolution_draw_matches_oracle(oracle):
     assert ocount.min() >= 4096
     np.testing.assert_allclose(pts.cpu().numpy(), opts, rtol=0, atol=2e-6)
     assert torch.minimum(cub.sdf(pts), cyl.sdf(pts)).abs().max().item() < 2e-5
+
+
+def test_render_is_the_first_hit_of_the_reference_pinned_sdf():
+    """An oracle-free statement about the ray cast: with the SDF classes whose values are pinned to the reference's
+    own ``geometry.py`` (tests/golden), every valid pixel's world point is ON a primitive (|sdf| ~ 0), every point of
+    the ray in front of it is OUTSIDE all primitives (sdf > 0: the hit is the first one), and a pixel marked empty has
+    no primitive anywhere on its ray up to the far clip (sampled)."""
+    from mpinets_amd.depth import DepthCamera, camera_pose
+
+    B, W, H = 2, 96, 72
+    kinds = ("tabletop", "cubby")
+    scn, t, cub, cyl, q = problem(B, kinds, 5)
+    cam = DepthCamera(W, H)
+    poses = torch.from_numpy(np.stack([camera_pose(k) for k in kinds])).to(dev())
+    depth = cam.render(poses, cub, cyl).reshape(B, H * W)  # no robot: every miss is a true miss
+    # ray of every pixel: world = origin + s * dir, OpenGL camera axes (x right, y up, looking along -z), pixel centres
+    v, u = torch.meshgrid(torch.arange(H, device=dev()), torch.arange(W, device=dev()), indexing="ij")
+    dc = torch.stack([(u + 0.5 - cam.cx) / cam.fx, -(v + 0.5 - cam.cy) / cam.fy, -torch.ones_like(u, dtype=torch.float32)], -1)
+    dc = (dc / dc.norm(dim=-1, keepdim=True)).reshape(1, H * W, 3).float()
+    R, o = poses[:, :3, :3], poses[:, None, :3, 3]
+    dw = torch.einsum("bij,bpj->bpi", R, dc.expand(B, -1, -1))
+    sdf = lambda p: torch.minimum(cub.sdf(p.contiguous()), cyl.sdf(p.contiguous()))
+    valid = depth >= 0
+    assert 0.05 < valid.float().mean().item() < 0.98
+    hit = o + depth.clamp(min=0)[..., None] * dw
+    assert sdf(hit)[valid].abs().max().item() < 5e-5  # on a surface
+    for frac in (0.1, 0.3, 0.5, 0.7, 0.9, 0.97):  # nothing in front of the hit
+        s = sdf(o + (frac * depth.clamp(min=0))[..., None] * dw)
+        assert (s[valid] > -1e-5).all(), frac
+    miss = ~valid
+    for dist in np.linspace(0.2, cam.far_clip, 60):  # an empty pixel's ray never enters a primitive (sampled every 17 cm:
+        s = sdf(o + float(dist) * dw)                 # the thinnest plates are 1 cm, so this is a one-sided check)
+        assert (s[miss] > -5e-3).all(), dist
