@@ -307,7 +307,10 @@ __global__ void __launch_bounds__(256)
 // order with ballot-ordered compaction (rare: a dense cluster such as the target gripper cloud).
 // Same distance arithmetic, same strict comparison, so idx and cnt are bit-identical to the brute-force kernel.
 constexpr int BQG = 48;            // columns per side
-constexpr int BQG_THREADS = 512;
+#ifndef MPX_BQG_THREADS
+#define MPX_BQG_THREADS 1024
+#endif
+constexpr int BQG_THREADS = MPX_BQG_THREADS;  // 16 waves: the query walk is LDS-latency bound, two lanes share a query
 constexpr int BQ_HC = 48;          // hits of a query kept in LDS (the rest of a long row goes through its global row)
 
 __device__ __forceinline__ int bq_cell(float v, float origin, float inv_h) {
@@ -363,6 +366,7 @@ __global__ void __launch_bounds__(BQG_THREADS)
   unsigned short *qcnt = order + ((N + 1) & ~1);                                    // [npoint] hits per query
   unsigned short *ovf = qcnt + ((npoint + 1) & ~1);                                 // [npoint] overflowing queries
   unsigned short *hbuf = ovf + ((npoint + 1) & ~1);                                 // [npoint][BQ_HC] first hits of a row
+  int *cnt_s = reinterpret_cast<int *>(hbuf + (size_t)npoint * BQ_HC);              // [npoint] hits found so far (atomic)
   __shared__ float red[2 * (BQG_THREADS / 64)];
   __shared__ int scan_s[BQG_THREADS / 64];
   __shared__ int n_ovf;
@@ -385,6 +389,7 @@ __global__ void __launch_bounds__(BQG_THREADS)
     }
   }
   for (int i = tid; i < BQG * BQG; i += BQG_THREADS) ccount[i] = 0;
+  for (int i = tid; i < npoint; i += BQG_THREADS) cnt_s[i] = 0;
   if (tid == 0) n_ovf = 0;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) mnx = fminf(mnx, __shfl_xor(mnx, o)), mny = fminf(mny, __shfl_xor(mny, o));
@@ -452,23 +457,25 @@ __global__ void __launch_bounds__(BQG_THREADS)
     y0 = min(max(iy - 1, 0), BQG - 1), y1 = min(max(iy + 1, 0), BQG - 1);
   };
 
-  // ---- one thread per query: hits of the 3 x 3 columns around it, appended unsorted to its row
-  for (int j = tid; j < npoint; j += BQG_THREADS) {
+  // ---- TWO lanes per query (the walk is a chain of dependent LDS reads: twice the lanes, twice the reads in flight):
+  // each takes one half of every column range of the 3 x 3 neighbourhood; hits are appended unsorted to the query's row
+  // at slots handed out by an LDS counter (the rows are sorted by point index afterwards, so the order of arrival is
+  // irrelevant: idx / cnt stay bit-identical)
+  for (int w = tid; w < 2 * npoint; w += BQG_THREADS) {
+    const int j = w >> 1, h = w & 1;
     const float cx = ctr[(size_t)j * new_stride], cy = ctr[(size_t)j * new_stride + 1], cz = ctr[(size_t)j * new_stride + 2];
     int x0, x1, y0, y1;
     col_range(cx, cy, x0, x1, y0, y1);
     int32_t *out = rows + (size_t)j * nsample;
-    int cnt = 0;
-    bool over = false;
     auto hit = [&](int k) __attribute__((always_inline)) {
-      if (cnt < BQ_HC) hbuf[j * BQ_HC + cnt] = (unsigned short)k;
-      else if (cnt < nsample) out[cnt] = k;
-      else over = true;
-      ++cnt;
+      const int slot = atomicAdd(&cnt_s[j], 1);
+      if (slot < BQ_HC) hbuf[j * BQ_HC + slot] = (unsigned short)k;
+      else if (slot < nsample) out[slot] = k;
     };
     for (int gx = x0; gx <= x1; ++gx) {
-      // columns y0..y1 of one x are adjacent in the sorted order: one contiguous range
-      const int e0 = cstart[gx * BQG + y0], e1 = cstart[gx * BQG + y1 + 1];
+      // columns y0..y1 of one x are adjacent in the sorted order: one contiguous range, halved between the two lanes
+      const int r0 = cstart[gx * BQG + y0], r1 = cstart[gx * BQG + y1 + 1], mid = r0 + ((r1 - r0 + 1) >> 1);
+      const int e0 = h ? mid : r0, e1 = h ? r1 : mid;
       int e = e0;
       for (; e + 4 <= e1; e += 4) {  // four candidates in flight
         float d2[4];
@@ -486,8 +493,13 @@ __global__ void __launch_bounds__(BQG_THREADS)
         if (mpx_fma(dz, dz, mpx_fma(dy, dy, dx * dx)) < radius2) hit(order[e]);
       }
     }
-    if (over) ovf[atomicAdd(&n_ovf, 1)] = (unsigned short)j;
-    qcnt[j] = (unsigned short)(cnt < nsample ? cnt : nsample);
+  }
+  __threadfence_block();
+  __syncthreads();
+  for (int j = tid; j < npoint; j += BQG_THREADS) {
+    const int c = cnt_s[j];
+    if (c > nsample) ovf[atomicAdd(&n_ovf, 1)] = (unsigned short)j;  // needs the nsample SMALLEST indices: redone below
+    qcnt[j] = (unsigned short)(c < nsample ? c : nsample);
   }
   __threadfence_block();
   __syncthreads();
@@ -590,7 +602,8 @@ MPX_EXPORT int mpx_ball_query(const float *new_xyz, int new_stride, const float 
   if (use_grid && N >= 2048 && N <= 8192 && nsample <= 128 && nsample > BQ_HC && npoint <= 4096 && radius > 0.0f &&
       radius * BQG < 4.0f) {  // columns of side ~radius must still resolve the scene (48 x radius < 4 m)
     const size_t lds = (size_t)3 * N * 4 + (size_t)BQG * BQG * 4 + (size_t)(BQG * BQG + 2) * 2 +
-                       (size_t)((N + 1) & ~1) * 2 + (size_t)((npoint + 1) & ~1) * 2 * 2 + (size_t)npoint * BQ_HC * 2;
+                       (size_t)((N + 1) & ~1) * 2 + (size_t)((npoint + 1) & ~1) * 2 * 2 + (size_t)npoint * BQ_HC * 2 +
+                       (size_t)npoint * 4;
     if (lds <= 158 * 1024) {
       MPX_LDS_LIMIT_ONCE(ball_query_grid_kernel, 158 * 1024, "mpx_ball_query");
       const float inv_h = 1.0f / (radius * 1.0001f);
