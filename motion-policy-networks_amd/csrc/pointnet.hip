@@ -535,8 +535,11 @@ __global__ void __launch_bounds__(BQG_THREADS)
     if (e >= n) return 0x7FFFFFFF;
     return e < BQ_HC ? (int)hbuf[j * BQ_HC + e] : rows[(size_t)j * nsample + e];
   };
-  for (int j0 = wave * 64; j0 < npoint; j0 += BQG_THREADS) {
-    const int jn = min(64, npoint - j0);
+  // rows are dealt to the waves in chunks (a multiple of 4: short rows are sorted four at a time) sized so that every
+  // wave of the workgroup gets some: 512 rows on 16 waves = 32 each
+  const int rpw = min(64, max(4, ((npoint + BQG_THREADS / 64 - 1) / (BQG_THREADS / 64) + 3) & ~3));
+  for (int j0 = wave * rpw; j0 < npoint; j0 += rpw * (BQG_THREADS / 64)) {
+    const int jn = min(rpw, npoint - j0);
     int q = 0;
     while (q < jn) {
       const int j = j0 + q, n = qcnt[j];
