@@ -166,6 +166,95 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PTS <
   }
 }
 
+// ---- farthest point sampling of a SMALL cloud (N <= 512: the second set-abstraction module samples 128 of 512) -------
+// One WAVE per environment, the whole cloud in its registers (8 points per lane): a pick is one pass of VALU work, one
+// DPP arg-max inside the wave and three v_readlane's for the picked point's coordinates -- no LDS, no barrier, and up to
+// 32 environments per CU instead of 4.  Same arithmetic, same 64-bit keys and tie ranks as fps_kernel.
+template <int PTS>
+__global__ void __launch_bounds__(64)
+    fps_wave_kernel(const float *__restrict__ xyz, int N, int stride, int npoint, int log2bs, int32_t *__restrict__ idx,
+                    float *__restrict__ new_xyz, int new_stride) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const float *pts = xyz + (size_t)b * N * stride;
+  int32_t *out = idx + (size_t)b * npoint;
+  float *nxyz = new_xyz ? new_xyz + (size_t)b * npoint * new_stride : nullptr;
+  const unsigned bsmask = (1u << log2bs) - 1u;
+  float x[PTS], y[PTS], z[PTS];
+  u64 key[PTS];
+#pragma unroll
+  for (int i = 0; i < PTS; ++i) {
+    const int k = lane + i * 64;
+    x[i] = y[i] = z[i] = 0.0f;
+    key[i] = 0;
+    if (k < N) {
+      x[i] = pts[(size_t)k * stride + 0];
+      y[i] = pts[(size_t)k * stride + 1];
+      z[i] = pts[(size_t)k * stride + 2];
+      const float mag = mpx_fma(z[i], z[i], mpx_fma(y[i], y[i], x[i] * x[i]));
+      if (!((double)mag <= 1e-3)) {
+        const unsigned rank = (__brev((unsigned)k & bsmask) & 0xFFFF0000u) | ((unsigned)k >> log2bs);
+        key[i] = pack64(0xFFFFFFFFu - rank, __float_as_uint(1e10f));
+      }
+    }
+  }
+  // coordinates of point `old` (wave-uniform): slot old / 64 of lane old % 64
+  auto coords = [&](int old, float &ox, float &oy, float &oz) __attribute__((always_inline)) {
+    const int slot = old >> 6, ln = old & 63;
+    float sx = x[0], sy = y[0], sz = z[0];
+#pragma unroll
+    for (int i = 1; i < PTS; ++i) {
+      sx = slot == i ? x[i] : sx;
+      sy = slot == i ? y[i] : sy;
+      sz = slot == i ? z[i] : sz;
+    }
+    ox = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(sx), ln));
+    oy = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(sy), ln));
+    oz = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(sz), ln));
+  };
+  int old = 0;
+  for (int j = 1; j < npoint; ++j) {
+    float x1, y1, z1;
+    coords(old, x1, y1, z1);
+    if (lane == 0) {
+      out[j - 1] = old;
+      if (nxyz) {
+        nxyz[(size_t)(j - 1) * new_stride + 0] = x1;
+        nxyz[(size_t)(j - 1) * new_stride + 1] = y1;
+        nxyz[(size_t)(j - 1) * new_stride + 2] = z1;
+      }
+    }
+    u64 best = 0;
+#pragma unroll
+    for (int i = 0; i < PTS; ++i) {
+      const float dx = x[i] - x1, dy = y[i] - y1, dz = z[i] - z1;
+      const float d = mpx_fma(dz, dz, mpx_fma(dy, dy, dx * dx));
+      float d2;
+      asm("v_min_f32 %0, %1, %2" : "=v"(d2) : "v"(d), "v"(__uint_as_float((unsigned)(key[i] >> 32))));
+      key[i] = pack64((unsigned)key[i], __float_as_uint(d2));
+      best = umax64(best, key[i]);
+    }
+    const u64 m = wave_max64(best);
+    if (m == 0) {
+      old = 0;
+    } else {
+      const unsigned rank = 0xFFFFFFFFu - (unsigned)m;
+      old = (int)(((rank & 0xFFFFu) << log2bs) | __brev(rank & 0xFFFF0000u));
+    }
+  }
+  if (npoint > 0) {
+    float x1, y1, z1;
+    coords(old, x1, y1, z1);
+    if (lane == 0) {
+      out[npoint - 1] = old;
+      if (nxyz) {
+        nxyz[(size_t)(npoint - 1) * new_stride + 0] = x1;
+        nxyz[(size_t)(npoint - 1) * new_stride + 1] = y1;
+        nxyz[(size_t)(npoint - 1) * new_stride + 2] = z1;
+      }
+    }
+  }
+}
+
 constexpr int FPS_MAX_N = 8192;                         // 512 threads x 16 points (include/mpinets_hip.h says the same)
 constexpr int FPS_MAX_LDS = 256 + 3 * FPS_MAX_N * 4;    // the cloud copy of the largest supported launch
 
@@ -182,6 +271,19 @@ MPX_EXPORT int mpx_fps(const float *xyz, int B, int N, int stride, int npoint, i
   MPX_REQUIRE(new_xyz == nullptr || new_stride >= 3, "mpx_fps: new_stride < 3");
   if (B == 0 || npoint == 0) return 0;
   const int log2bs = opt_n_threads_log2(N);
+  static const int use_wave = getenv("MPX_FPS_WAVE") ? atoi(getenv("MPX_FPS_WAVE")) : 1;
+  if (use_wave && N <= 512) {  // small cloud: one wave per environment, no LDS, no barrier
+    dim3 g1(B), t1(64);
+#define FPS_WAVE(P) hipLaunchKernelGGL(fps_wave_kernel<P>, g1, t1, 0, mpx_s(stream), xyz, N, stride, npoint, log2bs, idx, new_xyz, new_stride)
+    switch ((N + 63) / 64) {
+      case 1: FPS_WAVE(1); break;
+      case 2: FPS_WAVE(2); break;
+      case 3: case 4: FPS_WAVE(4); break;
+      default: FPS_WAVE(8); break;
+    }
+#undef FPS_WAVE
+    MPX_LAUNCH_CHECK("mpx_fps");
+  }
   int block = ((N + 63) / 64) * 64;
   static const int block_cap = getenv("MPX_FPS_BLOCK") ? atoi(getenv("MPX_FPS_BLOCK")) : 512;  // measured: 512 x 13 pts beats 1024 x 7
   if (block > block_cap) block = block_cap;
