@@ -167,3 +167,41 @@ def test_fps_skip_threshold_is_the_double_comparison(oracle):
     ref = oracle.fps(x, expect.shape[1])
     np.testing.assert_array_equal(ref, expect)
     np.testing.assert_array_equal(furthest_point_sample(T(x), expect.shape[1]).cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("N,npoint", [(1, 1), (2, 2), (63, 40), (64, 64), (65, 33), (127, 100), (128, 128), (300, 77), (511, 128),
+                                      (512, 128), (512, 512)])
+def test_fps_small_clouds_one_wave_per_environment(oracle, N, npoint):
+    """N <= 512 takes fps_wave_kernel (one wave per environment, cloud in registers): every lane occupancy from a single
+    point to all 8 register slots, with duplicated points (exact ties), lattice points and skipped points mixed in."""
+    from mpinets_amd.pointnet2 import furthest_point_sample
+
+    rng = np.random.default_rng(N * 1000 + npoint)
+    x = rng.uniform(-1, 1, (5, N, 3)).astype(np.float32)
+    x[1] = np.round(x[1] * 4) / 4                      # lattice: many exact ties
+    if N >= 4:
+        x[2, N // 2:] = x[2, :N - N // 2]              # duplicates
+        x[3, ::3] *= 0.01                              # a third of the points inside the skipped ball
+    x[4] = 0.001                                       # nothing is a candidate: all indices 0
+    idx, nx = furthest_point_sample(T(x), npoint, return_xyz=True)
+    ref = oracle.fps(x, npoint)
+    np.testing.assert_array_equal(idx.cpu().numpy(), ref)
+    np.testing.assert_array_equal(nx.cpu().numpy(), oracle.gather_points(x, ref))
+
+
+@pytest.mark.parametrize("N,npoint,nsample", [(2048, 513, 64), (3000, 1000, 128), (8192, 37, 128), (6272, 4096, 96), (5000, 7, 128)])
+def test_ball_query_bucketed_ragged_query_counts(oracle, N, npoint, nsample):
+    """Query counts that do not divide the workgroup's 16 waves / two lanes per query evenly, incl. a dense cluster that
+    overflows nsample (redone in index order)."""
+    from mpinets_amd.pointnet2 import ball_query
+
+    rng = np.random.default_rng(N + npoint)
+    xyz = rng.uniform(-0.6, 0.6, (2, N, 3)).astype(np.float32)
+    xyz[1, : N // 8] = xyz[1, 0] + rng.normal(0, 0.01, (N // 8, 3)).astype(np.float32)  # > nsample hits around one spot
+    q = xyz[:, rng.permutation(N)[:npoint] if npoint <= N else rng.integers(0, N, npoint)].copy()
+    q[:, 0] = xyz[:, 0]  # (environment 1: the centre of the dense cluster)
+    idx, cnt = ball_query(0.05, nsample, T(xyz), T(q), return_counts=True)
+    ridx, rcnt = oracle.ball_query(q, xyz, 0.05, nsample, return_counts=True)
+    np.testing.assert_array_equal(cnt.cpu().numpy(), rcnt)
+    np.testing.assert_array_equal(idx.cpu().numpy(), ridx)
+    assert rcnt.max() == nsample and rcnt.min() >= 1
