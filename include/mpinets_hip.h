@@ -130,6 +130,22 @@ int mpx_linear_bf16x3(const float *x, int ldx, const void *w_hi, const void *w_l
                       int N, int K, int act, float *y, int ldy, mpx_stream_t stream);
 int mpx_linear_rowmax_bf16x3(const float *x, int ldx, const void *w_hi, const void *w_lo, const float *bias,
                              int M, int N, int K, int rows, float *y, int ldy, mpx_stream_t stream);
+/* Chains of such layers (the group-all module's 259 -> 512 -> 512 -> 1024 MLP, model.py:383) keep their
+ * intermediate activations as the two bf16 planes the next layer multiplies with, [M, ldp] each (same bytes as the fp32
+ * rows): mpx_linear_bf16x3_to_planes is mpx_linear_bf16x3 writing planes (y_hi / y_lo, N and ldp multiples of 4)
+ * instead of fp32 rows; mpx_linear_bf16x3_planes reads planes (a_hi / a_lo [M, lda], K a multiple of 32, lda of 8, each
+ * plane under 4 GB) and writes EITHER fp32 rows (y, y_hi = y_lo = NULL) OR planes (y = NULL);
+ * mpx_linear_rowmax_bf16x3_planes is mpx_linear_rowmax_bf16x3 on plane input.  A value's planes are
+ * hi = bf16(v), lo = bf16(v - hi) wherever they are made, and the products are accumulated in the same order, so a chain
+ * through planes equals the chain through fp32 rows bit for bit.                                             */
+int mpx_linear_bf16x3_to_planes(const float *x, int ldx, const void *w_hi, const void *w_lo, const float *bias,
+                                int M, int N, int K, int act, void *y_hi, void *y_lo, int ldp, mpx_stream_t stream);
+int mpx_linear_bf16x3_planes(const void *a_hi, const void *a_lo, int lda, const void *w_hi, const void *w_lo,
+                             const float *bias, int M, int N, int K, int act, float *y, int ldy, void *y_hi,
+                             void *y_lo, int ldp, mpx_stream_t stream);
+int mpx_linear_rowmax_bf16x3_planes(const void *a_hi, const void *a_lo, int lda, const void *w_hi, const void *w_lo,
+                                    const float *bias, int M, int N, int K, int rows, float *y, int ldy,
+                                    mpx_stream_t stream);
 
 /* ---- training losses with analytic gradients (row N1; mpinets/loss.py:31-166) -------------------- */
 

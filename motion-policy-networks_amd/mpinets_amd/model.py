@@ -75,6 +75,32 @@ class MPiNetsPointNet(nn.Module):
             return linear_x3(x, weight, bias, act, self._split, out=out, source=source)
         return linear(x, weight, bias, act, out=out)
 
+    def _sa3_through_planes(self, h: torch.Tensor, c3, B: int) -> torch.Tensor:
+        """The group-all MLP in ``bf16x3`` with its intermediate activations kept as hi / lo bf16 planes (the operand
+        form of the next layer: nothing is split on the way in, all four operand planes are staged by DMA) instead of
+        fp32 rows.  Bit-identical to the fp32-row chain (same split, same accumulation order).  Rows go in chunks that
+        keep a plane under the 4 GB a buffer descriptor spans."""
+        lib, dev = _lib, h.device
+        w = [self._sa3_first_weight(), c3[1].weight.view(c3[1].out_channels, -1), c3[2].weight.view(c3[2].out_channels, -1)]
+        planes = [self._split.get(w[0], c3[0].weight), self._split.get(w[1]), self._split.get(w[2])]
+        n1, n2, n3 = (x.size(0) for x in w)
+        pooled = torch.empty((B, n3), dtype=torch.float32, device=dev)
+        step = max(1, min(65535, ((1 << 32) - 4096) // (128 * 2 * max(n1, n2))))  # environments per call
+        nb0 = min(step, B)
+        p1 = torch.empty((2, nb0 * 128, n1), dtype=torch.bfloat16, device=dev)
+        p2 = torch.empty((2, nb0 * 128, n2), dtype=torch.bfloat16, device=dev)
+        for b0 in range(0, B, step):
+            nb = min(step, B - b0)
+            M = nb * 128
+            x = h[b0 * 128:]
+            lib.call("mpx_linear_bf16x3_to_planes", lib.ptr(x), h.stride(0), lib.ptr(planes[0][0]), lib.ptr(planes[0][1]),
+                     lib.ptr(c3[0].bias), M, n1, w[0].size(1), ACT_RELU, lib.ptr(p1[0]), lib.ptr(p1[1]), n1)
+            lib.call("mpx_linear_bf16x3_planes", lib.ptr(p1[0]), lib.ptr(p1[1]), n1, lib.ptr(planes[1][0]),
+                     lib.ptr(planes[1][1]), lib.ptr(c3[1].bias), M, n2, n1, ACT_RELU, None, 0, lib.ptr(p2[0]), lib.ptr(p2[1]), n2)
+            lib.call("mpx_linear_rowmax_bf16x3_planes", lib.ptr(p2[0]), lib.ptr(p2[1]), n2, lib.ptr(planes[2][0]),
+                     lib.ptr(planes[2][1]), lib.ptr(c3[2].bias), M, n3, n2, 128, lib.ptr(pooled[b0:]), pooled.stride(0))
+        return pooled
+
     @staticmethod
     def _break_up_pc(pc: torch.Tensor):
         xyz = pc[..., 0:3].contiguous()
@@ -245,6 +271,14 @@ class MPiNetsPointNet(nn.Module):
         # ---- SA3 (group-all): three GEMMs over B*128 rows + max over each environment's rows ------------
         c3 = sa3.convs()
         h = sa3_in.view(B * sa2.npoint, K3)
+        if (self.dense_precision == "bf16x3" and sa2.npoint == 128 and os.environ.get("MPX_BF16_PLANES", "1") != "0"
+                and all(c.out_channels % 32 == 0 for c in c3)):
+            pooled = self._sa3_through_planes(h, c3, B)
+            self.last_counts = (cnt1, cnt2)
+            if aux is not None:
+                aux.update(fps_idx1=idx1, xyz1=xyz1, ball_idx1=nbr1, ball_cnt1=cnt1, f1=f1, fps_idx2=idx2, ball_idx2=nbr2,
+                           ball_cnt2=cnt2, sa3_in=sa3_in, f3=pooled)
+            return self._fc(pooled, out=out)
         h = self._lin(h, self._sa3_first_weight(), c3[0].bias, ACT_RELU, source=c3[0].weight)
         h = self._lin(h, c3[1].weight.view(c3[1].out_channels, -1), c3[1].bias, ACT_RELU)
         # last layer + max over each environment's 128 points in one kernel (nothing [B*128,1024] is stored)

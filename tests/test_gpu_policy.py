@@ -429,6 +429,96 @@ def test_linear_bf16x3_matches_fp32_layer():
     np.testing.assert_allclose(y2.cpu().numpy(), (x.double() @ w.double().T + b.double()).cpu().numpy(), atol=3e-4)
 
 
+def _planes_of(x):
+    hi = x.to(torch.bfloat16)
+    return hi.contiguous(), (x - hi.float()).to(torch.bfloat16).contiguous()
+
+
+def test_linear_bf16x3_plane_chain_is_bit_identical_to_the_row_chain():
+    """The plane-input / plane-output forms of the bf16x3 dense layer (operands already split by the layer before,
+    staged by DMA) == the fp32-row form bit for bit: fp32 rows out, planes out, and the pooled variant; ragged M / N,
+    every activation; and the three-layer group-all chain through planes == the chain through fp32 rows."""
+    from mpinets_amd import _lib
+    from mpinets_amd.pointnet2 import SplitWeights, linear_x3
+
+    rng = np.random.default_rng(23)
+    split = SplitWeights()
+    for (M, N, K) in [(128, 128, 32), (257, 200, 64), (5, 4096, 1024), (1000, 64, 2112), (640, 1024, 512), (1, 4, 32)]:
+        x = T(rng.normal(size=(M, K)).astype(np.float32))
+        w = T((rng.normal(size=(N, K)) / np.sqrt(K)).astype(np.float32))
+        b = T(rng.normal(size=N).astype(np.float32))
+        wh, wl = split.get(w)
+        xh, xl = _planes_of(x)
+        for act in (0, 1, 2):
+            ref = linear_x3(x, w, b, act, split)
+            y = torch.full((M, N), 7.0, device=dev())
+            _lib.call("mpx_linear_bf16x3_planes", _lib.ptr(xh), _lib.ptr(xl), K, _lib.ptr(wh), _lib.ptr(wl), _lib.ptr(b), M, N,
+                      K, act, _lib.ptr(y), N, None, None, 0)
+            assert torch.equal(y, ref), (M, N, K, act)
+            rh, rl = _planes_of(ref)
+            for fn, args in (("mpx_linear_bf16x3_planes", (_lib.ptr(xh), _lib.ptr(xl), K)), ("mpx_linear_bf16x3_to_planes", (_lib.ptr(x), K))):
+                ph = torch.zeros((M, N), dtype=torch.bfloat16, device=dev())
+                pl = torch.zeros((M, N), dtype=torch.bfloat16, device=dev())
+                tail = (None, 0, _lib.ptr(ph), _lib.ptr(pl), N) if fn.endswith("_planes") and "to_" not in fn else (
+                    _lib.ptr(ph), _lib.ptr(pl), N)
+                _lib.call(fn, *args, _lib.ptr(wh), _lib.ptr(wl), _lib.ptr(b), M, N, K, act, *tail)
+                assert torch.equal(ph, rh) and torch.equal(pl, rl), (fn, M, N, K, act)
+    # padded leading dimensions (planes with lda > K, output planes with ldp > N: the columns beyond stay untouched)
+    M, N, K = 300, 96, 64
+    x = T(rng.normal(size=(M, K)).astype(np.float32))
+    w = T(rng.normal(size=(N, K)).astype(np.float32))
+    wh, wl = split.get(w)
+    xh, xl = (torch.nn.functional.pad(p, (0, 8)).contiguous() for p in _planes_of(x))
+    ph = torch.full((M, N + 4), 3.0, dtype=torch.bfloat16, device=dev())
+    pl = torch.full((M, N + 4), 3.0, dtype=torch.bfloat16, device=dev())
+    _lib.call("mpx_linear_bf16x3_planes", _lib.ptr(xh), _lib.ptr(xl), K + 8, _lib.ptr(wh), _lib.ptr(wl), None, M, N, K, 0, None,
+              0, _lib.ptr(ph), _lib.ptr(pl), N + 4)
+    rh, rl = _planes_of(linear_x3(x, w, None, 0, split))
+    assert torch.equal(ph[:, :N], rh) and torch.equal(pl[:, :N], rl) and bool((ph[:, N:] == 3).all() and (pl[:, N:] == 3).all())
+    # the group-all chain: 272 -> 512 -> 512 -> 1024 + max over 128 rows, 5 environments
+    x = T(np.maximum(rng.normal(size=(640, 272)), 0).astype(np.float32))
+    ws = [T((rng.normal(size=s) * 0.05).astype(np.float32)) for s in ((512, 272), (512, 512), (1024, 512))]
+    bs = [T(rng.normal(size=n).astype(np.float32)) for n in (512, 512, 1024)]
+    h = linear_x3(linear_x3(x, ws[0], bs[0], 1, split), ws[1], bs[1], 1, split)
+    hi, lo = split.get(ws[2])
+    ref = torch.empty((5, 1024), device=dev())
+    _lib.call("mpx_linear_rowmax_bf16x3", _lib.ptr(h), 512, _lib.ptr(hi), _lib.ptr(lo), _lib.ptr(bs[2]), 640, 1024, 512, 128,
+              _lib.ptr(ref), 1024)
+    p1 = torch.empty((2, 640, 512), dtype=torch.bfloat16, device=dev())
+    p2 = torch.empty_like(p1)
+    s0, s1 = split.get(ws[0]), split.get(ws[1])
+    _lib.call("mpx_linear_bf16x3_to_planes", _lib.ptr(x), 272, _lib.ptr(s0[0]), _lib.ptr(s0[1]), _lib.ptr(bs[0]), 640, 512, 272, 1,
+              _lib.ptr(p1[0]), _lib.ptr(p1[1]), 512)
+    _lib.call("mpx_linear_bf16x3_planes", _lib.ptr(p1[0]), _lib.ptr(p1[1]), 512, _lib.ptr(s1[0]), _lib.ptr(s1[1]), _lib.ptr(bs[1]),
+              640, 512, 512, 1, None, 0, _lib.ptr(p2[0]), _lib.ptr(p2[1]), 512)
+    out = torch.full((5, 1024), -1.0, device=dev())
+    _lib.call("mpx_linear_rowmax_bf16x3_planes", _lib.ptr(p2[0]), _lib.ptr(p2[1]), 512, _lib.ptr(hi), _lib.ptr(lo),
+              _lib.ptr(bs[2]), 640, 1024, 512, 128, _lib.ptr(out), 1024)
+    assert torch.equal(out, ref)
+    # argument checks: K must be whole 32-k slabs, exactly one output form
+    with pytest.raises(_lib.MpxError):
+        _lib.call("mpx_linear_bf16x3_planes", _lib.ptr(p1[0]), _lib.ptr(p1[1]), 512, _lib.ptr(s1[0]), _lib.ptr(s1[1]), None, 640,
+                  512, 48, 0, None, 0, _lib.ptr(p2[0]), _lib.ptr(p2[1]), 512)
+    with pytest.raises(_lib.MpxError):
+        _lib.call("mpx_linear_bf16x3_planes", _lib.ptr(p1[0]), _lib.ptr(p1[1]), 512, _lib.ptr(s1[0]), _lib.ptr(s1[1]), None, 640,
+                  512, 512, 0, _lib.ptr(out), 512, _lib.ptr(p2[0]), _lib.ptr(p2[1]), 512)
+
+
+def test_policy_forward_bf16x3_planes_on_and_off_agree(monkeypatch):
+    """The policy forward in bf16x3 with the group-all MLP through planes (default) == with fp32 rows, bit for bit."""
+    from mpinets_amd.model import MotionPolicyNetwork
+    from mpinets_amd.scenes import make_problem_batch
+
+    torch.manual_seed(5)
+    mdl = MotionPolicyNetwork().to(dev()).eval().set_precision("bf16x3")
+    prob = make_problem_batch(6, seed=31, device=dev())
+    with torch.no_grad():
+        a = mdl(prob["xyz"], prob["q_norm"]).clone()
+        monkeypatch.setenv("MPX_BF16_PLANES", "0")
+        b = mdl(prob["xyz"], prob["q_norm"]).clone()
+    assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("B", [1, 5, 9, 40])
 def test_single_call_c_forward_reproduces_the_python_path(oracle, B):
     """mpx_policy_forward (one C call, caller workspace, no Python orchestration) == MotionPolicyNetwork.forward
