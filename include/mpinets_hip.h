@@ -346,12 +346,16 @@ int mpx_sa_pack_weights(const float *w1, const float *b1, const float *w2, const
  * mpx_sa_pack_bf16x3_size).  Opt-in: the fp32 kernel is the parity default.  cnt as in mpx_sa_mlp
  * (distinct neighbours only, rows packed; NULL = all slots).  `order` (optional, from
  * mpx_sort_queries) is the order in which waves take the queries: the 8 waves of a workgroup walk
- * the weight stream in lockstep and run max(tiles) of their row counts.                      */
+ * the weight stream in lockstep and run max(tiles) of their row counts.  A module whose whole pack fits
+ * LDS (the first one, 1+3 -> 64 -> 64 -> 64) runs a weight-resident kernel instead that takes the queries
+ * in their natural order: mpx_sa_mlp_bf16x3_wants_order (host query) says whether `order` is used for a
+ * module.  append_centre as in mpx_sa_mlp (only where `order` is not used).                              */
+int mpx_sa_mlp_bf16x3_wants_order(int C, int c1, int c2, int c3);
 int mpx_sa_mlp_bf16x3(const float *xyz, int stride, const float *new_xyz, int new_stride,
                       const float *feat, int feat_stride, int C, const int32_t *idx,
                       const int32_t *cnt, const int32_t *order, int B, int N, int npoint,
                       int nsample, const void *wpack, int c1, int c2, int c3, float *out,
-                      int out_stride, mpx_stream_t stream);
+                      int out_stride, int append_centre, mpx_stream_t stream);
 int64_t mpx_sa_pack_bf16x3_size(int C, int c1, int c2, int c3);
 int mpx_sa_pack_bf16x3(const float *w1, const float *b1, const float *w2, const float *b2,
                        const float *w3, const float *b3, int C, int c1, int c2, int c3, void *wpack,

@@ -561,6 +561,238 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
   for (int ot = 0; ot < Cfg::OT3; ++ot) flush(ot, cur[ot]);
 }
 
+// ---- weight-resident form for a module whose whole pack fits LDS (the first module: 1+3 -> 64 -> 64 -> 64, 18 real
+// step-tiles = 36 KB) -------------------------------------------------------------------------------------------------
+// The lockstep kernel above walks an 8-wave workgroup through the weight stream with one barrier per chunk; for this
+// module the stream is 36 KB and the walk costs more than the matrix work (54 MFMAs = 1.7 k pipe cycles per 32-row
+// tile).  Here a workgroup copies the real step-tiles and the biases into LDS once and its four waves are independent
+// from then on (no barrier, no ring, no sorting pass): a wave packs the distinct neighbours of Q consecutive queries into
+// 32-row tiles exactly as above, reads every weight operand from LDS (lane-linear 16-byte reads), and keeps the same
+// arithmetic (split products, fp32 accumulate, exact fp32 bias) and operand layouts -- the pack of mpx_sa_pack_bf16x3 is
+// used as it is.  Four waves per SIMD cover each other's gather / split / pooling phases.
+#ifndef MPX_RES_OCC
+#define MPX_RES_OCC 4
+#endif
+namespace res {
+constexpr int WV = 4;
+}
+template <int CF, int C1, int C2, int C3, int Q>
+__global__ void __launch_bounds__(64 * res::WV) __attribute__((amdgpu_waves_per_eu(MPX_RES_OCC, MPX_RES_OCC)))
+    sa_mlp_bf16_resident_kernel(const float *__restrict__ xyz, int stride, const float *__restrict__ new_xyz,
+                                int new_stride, const float *__restrict__ feat, int feat_stride,
+                                const int32_t *__restrict__ idx, const int32_t *__restrict__ cnt, int64_t n_query, int N,
+                                int npoint, int nsample, const unsigned char *__restrict__ wpack, float *__restrict__ out,
+                                int out_stride, int wpe, int row16, int append_centre) {
+  using Cfg = BCfg<CF, C1, C2, C3>;
+  static_assert(CF == 1, "written for the one-feature first module (layer-1 operand forming)");
+  constexpr int NT = Cfg::ST1 + Cfg::ST2 + Cfg::ST3;  // real step-tiles
+  constexpr int T2 = Cfg::ST1, T3 = Cfg::ST1 + Cfg::ST2;  // first LDS tile of layers 2, 3
+  __shared__ __attribute__((aligned(16))) unsigned char wlds[NT * TILE_BYTES + 4 * (C1 + C2 + C3)];
+  static_assert(sizeof(wlds) <= 40960, "four workgroups per CU");
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int half = lane >> 5, col = lane & 31;
+  {  // real step-tiles (the pack pads every layer to whole chunks: skip the dummies) and b1 | b2 | b3
+    const uint4 *src = reinterpret_cast<const uint4 *>(wpack);
+    uint4 *dst = reinterpret_cast<uint4 *>(wlds);
+    constexpr int PER = TILE_BYTES / 16;
+    for (int i = threadIdx.x; i < NT * PER; i += 64 * res::WV) {
+      const int t = i / PER, r = i % PER;
+      const int st = t < T2 ? t : (t < T3 ? Cfg::O2 + (t - T2) : Cfg::O3 + (t - T3));
+      dst[i] = src[st * PER + r];
+    }
+    float *b = reinterpret_cast<float *>(wlds + NT * TILE_BYTES);
+    for (int i = threadIdx.x; i < C1 + C2 + C3; i += 64 * res::WV)
+      b[i] = reinterpret_cast<const float *>(wpack + Cfg::B1_OFF)[i];
+  }
+  __syncthreads();  // the only barrier
+  const float *b1_s = reinterpret_cast<const float *>(wlds + NT * TILE_BYTES), *b2_s = b1_s + C1, *b3_s = b2_s + C2;
+  // (the LDS image never changes, so the compiler would hoist every operand read out of the tile loop -- 36 KB of
+  // "loop invariants" per wave, spilled to scratch: the lane's base offset is made opaque once per tile instead)
+  int w_off = lane * 16;
+  auto operands = [&](int t, bf16x8 &hi, bf16x8 &lo) __attribute__((always_inline)) {
+    hi = *reinterpret_cast<const bf16x8 *>(wlds + w_off + t * TILE_BYTES);
+    lo = *reinterpret_cast<const bf16x8 *>(wlds + w_off + t * TILE_BYTES + 1024);
+  };
+
+  // XCD-aware order (hardware dispatches workgroup h to XCD h % 8): all workgroups of an environment on one XCD, so its
+  // cloud is fetched into one L2 (wpe = workgroups per environment; 0: natural order)
+  int64_t wg = blockIdx.x;
+  if (wpe > 0) {
+    const int64_t xcd = wg & 7, slot = wg >> 3;
+    wg = ((slot / wpe) * 8 + xcd) * wpe + slot % wpe;
+  }
+  const int64_t q0 = (wg * res::WV + wave) * Q;
+  if (q0 >= n_query) return;  // (after the barrier)
+  const int nq = (int)min((int64_t)Q, n_query - q0);
+
+  // lane i < nq: distinct-neighbour count, row count (multiple of 4) and row offset of query q0 + i
+  int my_cnt = 1, my_rows = 0;
+  if (lane < nq) {
+    const int c = cnt ? cnt[q0 + lane] : nsample;
+    my_cnt = c <= 0 ? 1 : (c > nsample ? nsample : c);  // no hit: the zero-initialised row = point 0
+    my_rows = (my_cnt + 3) & ~3;
+  }
+  int pre = my_rows;
+#pragma unroll
+  for (int o = 1; o < Q; o <<= 1) {
+    const int t = __shfl_up(pre, o);
+    if (lane >= o) pre += t;
+  }
+  const int total = __builtin_amdgcn_readlane(pre, Q - 1);
+  pre -= my_rows;
+  int s_pre[Q];
+#pragma unroll
+  for (int i = 0; i < Q; ++i) s_pre[i] = __builtin_amdgcn_readlane(pre, i);
+  const int n_rows = total <= 32 ? 32 : ((total + 31) & ~31);
+  if (append_centre && lane < 4 * nq) {  // [centre xyz | 0] behind the pooled features: the next module's operand row
+    const int qi = lane >> 2, c = lane & 3;
+    out[(q0 + qi) * out_stride + C3 + c] = c < 3 ? new_xyz[(q0 + qi) * new_stride + c] : 0.0f;
+  }
+
+  // row -> (local query, neighbour slot): the query is counted (one compare + add per query), its row offset and hit
+  // count come from the lanes that hold them; rows past the end repeat the last query's first slot
+  auto map_row = [&](int p, int &ql, int &off) __attribute__((always_inline)) {
+    int n = 0;
+#pragma unroll
+    for (int i = 1; i < Q; ++i) n += (i < nq && p >= s_pre[i]) ? 1 : 0;
+    ql = n;
+    const int qpre = __builtin_amdgcn_ds_bpermute(4 * n, pre), qcnt = __builtin_amdgcn_ds_bpermute(4 * n, my_cnt);
+    const int slot = p - qpre;
+    off = slot < qcnt ? slot : 0;
+  };
+  float px, py, pz, pf, cx, cy, cz;  // the gathered row: neighbour point, its label, its query's centre
+  auto gather = [&](int ql, int k) __attribute__((always_inline)) {
+    const int64_t q = q0 + ql, b = q / npoint;
+    const float *pp = xyz + (b * N + k) * (int64_t)stride;
+    if (row16) {  // (x, y, z, label) is one aligned 16-byte row of the caller's slab
+      const float4 v = *reinterpret_cast<const float4 *>(pp);
+      px = v.x, py = v.y, pz = v.z, pf = v.w;
+    } else {
+      px = pp[0], py = pp[1], pz = pp[2];
+      pf = feat[(b * N + k) * (int64_t)feat_stride];
+    }
+    const float *cp = new_xyz + q * new_stride;
+    cx = cp[0], cy = cp[1], cz = cp[2];
+  };
+
+  float run[Cfg::OT3];
+#pragma unroll
+  for (int ot = 0; ot < Cfg::OT3; ++ot) run[ot] = -__builtin_inff();
+  int cur = 0;  // local query being merged (wave-uniform)
+  auto flush = [&](int ot, int ql) __attribute__((always_inline)) {
+    float v = mpx_max_across_halves(run[ot]);
+    const int ch = ot * 32 + col;
+    v = fmaxf(v + b3_s[ch], 0.0f);
+    if (half == 0) out[(q0 + ql) * out_stride + ch] = v;
+    run[ot] = -__builtin_inff();
+  };
+
+  // row pipeline: neighbour index two tiles ahead, row data one tile ahead
+  int ql_cur, ql_next = 0, k_next = 0;
+  {
+    int off;
+    map_row(col, ql_cur, off);
+    gather(ql_cur, idx[(q0 + ql_cur) * nsample + off]);
+    map_row(32 + col, ql_next, off);
+    k_next = idx[(q0 + ql_next) * nsample + off];
+  }
+  int half_t = half;
+  for (int rt = 0; rt < n_rows; rt += 32) {
+    asm volatile("" : "+v"(w_off), "+v"(half_t));
+    // ---- layer-1 operand of this lane's row: (dx | dy), (dz | label) by lane-half, zero beyond -------------------
+    bf16x8 xh, xl;
+    {
+      float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      v[0] = half ? py - cy : px - cx;
+      v[1] = half ? pf : pz - cz;
+      split8(v, xh, xl);
+    }
+    const int ql_tile = ql_cur, ql_gather = ql_next, k_gather = k_next;
+    ql_cur = ql_next;
+    {
+      int off;
+      map_row(rt + 64 + col, ql_next, off);
+      k_next = idx[(q0 + ql_next) * nsample + off];
+    }
+    // ---- layer 1: H1t = W1 . Xt ------------------------------------------------------------------------------------
+    f32x16 a1[Cfg::OT1];
+#pragma unroll
+    for (int ot = 0; ot < Cfg::OT1; ++ot) a1[ot] = bias_tile_lds(b1_s, ot, half_t);
+    static_assert(Cfg::KS0 == 1, "one K16 step in layer 1");
+#pragma unroll
+    for (int ot = 0; ot < Cfg::OT1; ++ot) {
+      bf16x8 wh, wl;
+      operands(ot, wh, wl);
+      a1[ot] = mfma_bf16(wh, xh, a1[ot]);
+      a1[ot] = mfma_bf16(wl, xh, a1[ot]);
+      a1[ot] = mfma_bf16(wh, xl, a1[ot]);
+    }
+    gather(ql_gather, k_gather);  // the next tile's row (consumed at the top of the next iteration)
+    bf16x8 h1[Cfg::OT1][2], l1[Cfg::OT1][2];
+#pragma unroll
+    for (int ot = 0; ot < Cfg::OT1; ++ot) relu_split_tile(a1[ot], h1[ot], l1[ot]);
+    // ---- layer 2: H2t = W2 . H1t, the output tiles side by side (consecutive MFMAs on different accumulators) -------
+    f32x16 a2[Cfg::OT2];
+#pragma unroll
+    for (int ot = 0; ot < Cfg::OT2; ++ot) a2[ot] = bias_tile_lds(b2_s, ot, half_t);
+#pragma unroll
+    for (int s = 0; s < Cfg::KS1; ++s) {
+      bf16x8 wh[Cfg::OT2], wl[Cfg::OT2];
+#pragma unroll
+      for (int ot = 0; ot < Cfg::OT2; ++ot) operands(T2 + s * Cfg::OT2 + ot, wh[ot], wl[ot]);
+#pragma unroll
+      for (int pass = 0; pass < 3; ++pass)
+#pragma unroll
+        for (int ot = 0; ot < Cfg::OT2; ++ot)
+          a2[ot] = mfma_bf16(pass == 1 ? wl[ot] : wh[ot], pass == 2 ? l1[s >> 1][s & 1] : h1[s >> 1][s & 1], a2[ot]);
+    }
+    bf16x8 h2[Cfg::OT2][2], l2[Cfg::OT2][2];
+#pragma unroll
+    for (int ot = 0; ot < Cfg::OT2; ++ot) relu_split_tile(a2[ot], h2[ot], l2[ot]);
+    // ---- layer 3 (roles flipped: activations are A, weights B; rows on the register axis, channels on the lanes) ----
+    f32x16 a3[Cfg::OT3];
+#pragma unroll
+    for (int ot = 0; ot < Cfg::OT3; ++ot) a3[ot] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int s = 0; s < Cfg::KS2; ++s) {
+      bf16x8 wh[Cfg::OT3], wl[Cfg::OT3];
+#pragma unroll
+      for (int ot = 0; ot < Cfg::OT3; ++ot) operands(T3 + ot * Cfg::KS2 + s, wh[ot], wl[ot]);
+#pragma unroll
+      for (int pass = 0; pass < 3; ++pass)
+#pragma unroll
+        for (int ot = 0; ot < Cfg::OT3; ++ot)
+          a3[ot] = mfma_bf16(pass == 2 ? l2[s >> 1][s & 1] : h2[s >> 1][s & 1], pass == 1 ? wl[ot] : wh[ot], a3[ot]);
+    }
+    // ---- pooling: a lane holds, for its channel, four groups of 4 consecutive rows (group g = 2j + half = rows
+    // 4g .. 4g+3); groups never straddle queries: max inside each group, merge the 8 groups in row order, flush the
+    // running maximum whenever the (wave-uniform) query changes
+    int gq[8];
+#pragma unroll
+    for (int g = 0; g < 8; ++g) gq[g] = __builtin_amdgcn_readlane(ql_tile, 4 * g);
+#pragma unroll
+    for (int ot = 0; ot < Cfg::OT3; ++ot) {
+      float gm[4];
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj)
+        gm[jj] = fmaxf(fmaxf(a3[ot][4 * jj], a3[ot][4 * jj + 1]), fmaxf(a3[ot][4 * jj + 2], a3[ot][4 * jj + 3]));
+      int c = cur;
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        if (gq[g] != c) {
+          flush(ot, c);
+          c = gq[g];
+        }
+        run[ot] = fmaxf(run[ot], ((g & 1) == half) ? gm[g >> 1] : -__builtin_inff());
+      }
+    }
+    cur = gq[7];
+  }
+#pragma unroll
+  for (int ot = 0; ot < Cfg::OT3; ++ot) flush(ot, cur);
+}
+
 // ---- v2 of the factored (64+3, 128, 128, 256) module: persistent workgroups, ONE software-pipelined wave per SIMD ----
 // The lockstep kernel above keeps its matrix pipes ~40 % busy: its non-matrix work (forming relu(pre - ctr) and
 // splitting it into bf16 hi / lo, splitting the layer-2 accumulators, pooling, operand reads -- ~1000-1400 instructions
@@ -897,14 +1129,33 @@ __global__ void __launch_bounds__(64 * v2::WV) __attribute__((amdgpu_waves_per_e
     return 1;                                                                               \
   }
 
+// 1 (default): the weight-resident kernel for the modules whose pack fits LDS; 0: the lockstep kernel everywhere
+static int bf16_resident() {
+  static const int v = getenv("MPX_BF16_RESIDENT") ? atoi(getenv("MPX_BF16_RESIDENT")) : 1;
+  return v;
+}
+
 template <int CF, int C1, int C2, int C3>
 static int launch_sa_bf16(const float *xyz, int stride, const float *new_xyz, int new_stride, const float *feat,
                           int feat_stride, const int32_t *idx, const int32_t *cnt, const int32_t *order, int B, int N,
                           int npoint, int nsample,
-                          const void *wpack, float *out, int out_stride, mpx_stream_t stream) {
+                          const void *wpack, float *out, int out_stride, int append_centre, mpx_stream_t stream) {
   const int64_t nq = (int64_t)B * npoint;
   MPX_REQUIRE(nq < ((int64_t)1 << 31), "mpx_sa_mlp_bf16x3: too many query points");
   constexpr int Q = CF == 1 ? 16 : 4;  // queries per wave
+  if constexpr (CF == 1) {
+    if (bf16_resident()) {  // (walks the queries in their natural order: `order` is not needed)
+      const int64_t per_wg = (int64_t)res::WV * Q;
+      const int wpe = (npoint % per_wg == 0 && B % 8 == 0) ? (int)(npoint / per_wg) : 0;
+      const int row16 = (feat == xyz + 3 && stride == 4 && feat_stride == 4 && ((uintptr_t)xyz & 15) == 0) ? 1 : 0;
+      hipLaunchKernelGGL((sa_mlp_bf16_resident_kernel<CF, C1, C2, C3, Q>), dim3((unsigned)((nq + per_wg - 1) / per_wg)),
+                         dim3(64 * res::WV), 0, mpx_s(stream), xyz, stride, new_xyz, new_stride, feat, feat_stride, idx, cnt,
+                         nq, N, npoint, nsample, static_cast<const unsigned char *>(wpack), out, out_stride, wpe, row16,
+                         append_centre);
+      MPX_LAUNCH_CHECK("mpx_sa_mlp_bf16x3");
+    }
+  }
+  MPX_REQUIRE(!append_centre, "mpx_sa_mlp_bf16x3: append_centre is implemented by the weight-resident kernel only");
   const int64_t per_block = (int64_t)WAVES * Q;
   hipLaunchKernelGGL((sa_mlp_bf16_kernel<CF, C1, C2, C3, Q, false>), dim3((unsigned)((nq + per_block - 1) / per_block)),
                      dim3(64 * WAVES), 0, mpx_s(stream), xyz, stride, new_xyz, new_stride, feat, feat_stride, idx, cnt, order, nq, N, npoint, nsample,
@@ -963,8 +1214,9 @@ MPX_EXPORT int mpx_sa_mlp_bf16x3_factored(const float *pre, const float *ctr, co
 MPX_EXPORT int mpx_sa_mlp_bf16x3(const float *xyz, int stride, const float *new_xyz, int new_stride,
                                  const float *feat, int feat_stride, int C, const int32_t *idx, const int32_t *cnt,
                                  const int32_t *order, int B, int N, int npoint, int nsample, const void *wpack, int c1,
-                                 int c2, int c3, float *out, int out_stride, mpx_stream_t stream) {
+                                 int c2, int c3, float *out, int out_stride, int append_centre, mpx_stream_t stream) {
   MPX_REQUIRE(B >= 0 && N >= 1 && npoint >= 0, "mpx_sa_mlp_bf16x3: bad size");
+  MPX_REQUIRE(!append_centre || out_stride >= c3 + 4, "mpx_sa_mlp_bf16x3: append_centre needs out_stride >= c3 + 4");
   MPX_REQUIRE(nsample > 0 && nsample % 32 == 0, "mpx_sa_mlp_bf16x3: nsample must be a positive multiple of 32");
   MPX_REQUIRE(stride >= 3 && new_stride >= 3 && out_stride >= c3, "mpx_sa_mlp_bf16x3: bad stride");
   MPX_REQUIRE(C == 1 || (feat_stride % 4 == 0 && ((uintptr_t)feat & 15) == 0),
@@ -972,9 +1224,15 @@ MPX_EXPORT int mpx_sa_mlp_bf16x3(const float *xyz, int stride, const float *new_
   MPX_REQUIRE(((uintptr_t)wpack & 15) == 0, "mpx_sa_mlp_bf16x3: wpack must be 16-byte aligned");
   if (B == 0 || npoint == 0) return 0;
 #define CALL(a, b, c, d) \
-  return launch_sa_bf16<a, b, c, d>(xyz, stride, new_xyz, new_stride, feat, feat_stride, idx, cnt, order, B, N, npoint, nsample, wpack, out, out_stride, stream)
+  return launch_sa_bf16<a, b, c, d>(xyz, stride, new_xyz, new_stride, feat, feat_stride, idx, cnt, order, B, N, npoint, nsample, wpack, out, out_stride, append_centre, stream)
   SA_DISPATCH(CALL)
 #undef CALL
+}
+
+// 1: mpx_sa_mlp_bf16x3 walks the queries in the caller's `order` for this module (the lockstep kernel: balanced
+// workgroups); 0: it ignores `order` (the weight-resident kernel) -- and only then supports append_centre
+MPX_EXPORT int mpx_sa_mlp_bf16x3_wants_order(int C, int c1, int c2, int c3) {
+  return (C == 1 && c1 == 64 && c2 == 64 && c3 == 64 && bf16_resident()) ? 0 : 1;
 }
 
 MPX_EXPORT int64_t mpx_sa_pack_bf16x3_size(int C, int c1, int c2, int c3) {

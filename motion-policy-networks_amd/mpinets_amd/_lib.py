@@ -56,7 +56,8 @@ PROTOTYPES = {
     "mpx_sa_mlp_bf16x3_factored": [P, P, P, P, P, I, I, I, I, P, I, I, I, I, P, I, P],
     "mpx_sa_pack_size": [I, I, I, I],
     "mpx_sa_pack_weights": [P, P, P, P, P, P, I, I, I, I, P, P],
-    "mpx_sa_mlp_bf16x3": [P, I, P, I, P, I, I, P, P, P, I, I, I, I, P, I, I, I, P, I, P],
+    "mpx_sa_mlp_bf16x3": [P, I, P, I, P, I, I, P, P, P, I, I, I, I, P, I, I, I, P, I, I, P],
+    "mpx_sa_mlp_bf16x3_wants_order": [I, I, I, I],
     "mpx_sa_pack_bf16x3_size": [I, I, I, I],
     "mpx_sa_pack_bf16x3": [P, P, P, P, P, P, I, I, I, I, P, P],
     "mpx_linear": [P, I, P, P, I, I, I, I, P, I, P],

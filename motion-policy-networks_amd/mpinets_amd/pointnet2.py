@@ -204,8 +204,8 @@ def launch_sa(precision: str, xyz_ptr: int, stride: int, new_xyz_ptr: int, new_s
     """One fused group + MLP + max-pool launch in either precision (raw pointers: slab views welcome).
     ``cnt`` (from the ball query) lets the kernel skip neighbourhood tiles that hold only padding --
     bit-identical output; for the lockstep bf16x3 kernel the queries are first ordered by tile count.
-    ``append_centre``: also write [query xyz | 0] into columns [c3, c3+4) of the output rows (fp32 kernel with counts
-    only); returns whether that was done (False: the caller appends them with ``mpx_append_columns``)."""
+    ``append_centre``: also write [query xyz | 0] into columns [c3, c3+4) of the output rows (the fp32 kernel with
+    counts and the weight-resident bf16x3 kernel); returns whether that was done (False: the caller appends them with ``mpx_append_columns``)."""
     c1, c2, c3 = widths
     if precision == "fp32":
         fused = bool(append_centre and cnt is not None)
@@ -213,13 +213,16 @@ def launch_sa(precision: str, xyz_ptr: int, stride: int, new_xyz_ptr: int, new_s
                   _lib.ptr(cnt), B, N, npoint, nsample, _lib.ptr(wpack), c1, c2, c3, out_ptr, out_stride, int(fused))
         return fused
     order = None
-    if cnt is not None:
+    wants_order = bool(_lib.load().mpx_sa_mlp_bf16x3_wants_order(C, c1, c2, c3))
+    if cnt is not None and wants_order:
         order = torch.empty(B * npoint, dtype=torch.int32, device=idx.device)
         scratch = torch.empty(128, dtype=torch.int32, device=idx.device)
         _lib.call("mpx_sort_queries", _lib.ptr(cnt), B * npoint, nsample, _lib.ptr(order), _lib.ptr(scratch))
+    fused = bool(append_centre and not wants_order)  # (the weight-resident kernel completes the rows itself)
     _lib.call("mpx_sa_mlp_bf16x3", xyz_ptr, stride, new_xyz_ptr, new_stride, feat_ptr, feat_stride, C, _lib.ptr(idx),
-              _lib.ptr(cnt), _lib.ptr(order), B, N, npoint, nsample, _lib.ptr(wpack), c1, c2, c3, out_ptr, out_stride)
-    return False
+              _lib.ptr(cnt), _lib.ptr(order), B, N, npoint, nsample, _lib.ptr(wpack), c1, c2, c3, out_ptr, out_stride,
+              int(fused))
+    return fused
 
 
 def sa_mlp_fused(xyz: torch.Tensor, new_xyz: torch.Tensor, feat: torch.Tensor, feat_stride: int, C: int,

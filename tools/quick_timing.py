@@ -67,12 +67,12 @@ def main():
     r["sa2_mlp_elide"] = timeit(lambda: lib.call("mpx_sa_mlp", lib.ptr(xyz1), 3, lib.ptr(xyz2), 3, lib.ptr(f1), 64, 64, lib.ptr(nbr2), lib.ptr(cnt2), B, 512, 128, 128, lib.ptr(w2), 128, 128, 256, lib.ptr(f2), 256, 0))
     wb1 = sa1._packed.get(sa1.convs(), 1, "bf16x3")
     wb2 = sa2._packed.get(sa2.convs(), 64, "bf16x3")
-    r["sa1_bf16x3"] = timeit(lambda: lib.call("mpx_sa_mlp_bf16x3", lib.ptr(xyz), 4, lib.ptr(xyz1), 3, lib.ptr(xyz) + 12, 4, 1, lib.ptr(nbr1), None, None, B, N, 512, 128, lib.ptr(wb1), 64, 64, 64, lib.ptr(f1), 64))
+    r["sa1_bf16x3"] = timeit(lambda: lib.call("mpx_sa_mlp_bf16x3", lib.ptr(xyz), 4, lib.ptr(xyz1), 3, lib.ptr(xyz) + 12, 4, 1, lib.ptr(nbr1), None, None, B, N, 512, 128, lib.ptr(wb1), 64, 64, 64, lib.ptr(f1), 64, 0))
     r["sort1"] = timeit(lambda: lib.call("mpx_sort_queries", lib.ptr(cnt1), B * 512, 128, lib.ptr(ord1), lib.ptr(scr)))
-    r["sa1_bf16x3_elide"] = timeit(lambda: lib.call("mpx_sa_mlp_bf16x3", lib.ptr(xyz), 4, lib.ptr(xyz1), 3, lib.ptr(xyz) + 12, 4, 1, lib.ptr(nbr1), lib.ptr(cnt1), lib.ptr(ord1), B, N, 512, 128, lib.ptr(wb1), 64, 64, 64, lib.ptr(f1), 64))
-    r["sa2_bf16x3"] = timeit(lambda: lib.call("mpx_sa_mlp_bf16x3", lib.ptr(xyz1), 3, lib.ptr(xyz2), 3, lib.ptr(f1), 64, 64, lib.ptr(nbr2), None, None, B, 512, 128, 128, lib.ptr(wb2), 128, 128, 256, lib.ptr(f2), 256))
+    r["sa1_bf16x3_elide"] = timeit(lambda: lib.call("mpx_sa_mlp_bf16x3", lib.ptr(xyz), 4, lib.ptr(xyz1), 3, lib.ptr(xyz) + 12, 4, 1, lib.ptr(nbr1), lib.ptr(cnt1), lib.ptr(ord1), B, N, 512, 128, lib.ptr(wb1), 64, 64, 64, lib.ptr(f1), 64, 0))
+    r["sa2_bf16x3"] = timeit(lambda: lib.call("mpx_sa_mlp_bf16x3", lib.ptr(xyz1), 3, lib.ptr(xyz2), 3, lib.ptr(f1), 64, 64, lib.ptr(nbr2), None, None, B, 512, 128, 128, lib.ptr(wb2), 128, 128, 256, lib.ptr(f2), 256, 0))
     lib.call("mpx_sort_queries", lib.ptr(cnt2), B * 128, 128, lib.ptr(ord2), lib.ptr(scr))
-    r["sa2_bf16x3_elide"] = timeit(lambda: lib.call("mpx_sa_mlp_bf16x3", lib.ptr(xyz1), 3, lib.ptr(xyz2), 3, lib.ptr(f1), 64, 64, lib.ptr(nbr2), lib.ptr(cnt2), lib.ptr(ord2), B, 512, 128, 128, lib.ptr(wb2), 128, 128, 256, lib.ptr(f2), 256))
+    r["sa2_bf16x3_elide"] = timeit(lambda: lib.call("mpx_sa_mlp_bf16x3", lib.ptr(xyz1), 3, lib.ptr(xyz2), 3, lib.ptr(f1), 64, 64, lib.ptr(nbr2), lib.ptr(cnt2), lib.ptr(ord2), B, 512, 128, 128, lib.ptr(wb2), 128, 128, 256, lib.ptr(f2), 256, 0))
     with torch.no_grad():
         r["forward"] = timeit(lambda: mdl(xyz, qn), n=3, warm=1)
         mdl.set_precision("bf16x3")
