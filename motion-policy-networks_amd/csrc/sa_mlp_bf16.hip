@@ -576,7 +576,7 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
 namespace res {
 constexpr int WV = 4;
 }
-template <int CF, int C1, int C2, int C3, int Q>
+template <int CF, int C1, int C2, int C3, int Q, bool ONE_ENV>
 __global__ void __launch_bounds__(64 * res::WV) __attribute__((amdgpu_waves_per_eu(MPX_RES_OCC, MPX_RES_OCC)))
     sa_mlp_bf16_resident_kernel(const float *__restrict__ xyz, int stride, const float *__restrict__ new_xyz,
                                 int new_stride, const float *__restrict__ feat, int feat_stride,
@@ -587,8 +587,10 @@ __global__ void __launch_bounds__(64 * res::WV) __attribute__((amdgpu_waves_per_
   static_assert(CF == 1, "written for the one-feature first module (layer-1 operand forming)");
   constexpr int NT = Cfg::ST1 + Cfg::ST2 + Cfg::ST3;  // real step-tiles
   constexpr int T2 = Cfg::ST1, T3 = Cfg::ST1 + Cfg::ST2;  // first LDS tile of layers 2, 3
-  __shared__ __attribute__((aligned(16))) unsigned char wlds[NT * TILE_BYTES + 4 * (C1 + C2 + C3)];
+  constexpr int ROWQ = (Q * 128 + 64) / 4 + 16;  // 4-row groups of a wave's rows (nsample <= 128) + the prefetch overhang
+  __shared__ __attribute__((aligned(16))) unsigned char wlds[NT * TILE_BYTES + 4 * (C1 + C2 + C3) + res::WV * ROWQ];
   static_assert(sizeof(wlds) <= 40960, "four workgroups per CU");
+  unsigned char *rowq_all = wlds + NT * TILE_BYTES + 4 * (C1 + C2 + C3);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int half = lane >> 5, col = lane & 31;
@@ -616,7 +618,9 @@ __global__ void __launch_bounds__(64 * res::WV) __attribute__((amdgpu_waves_per_
   };
 
   // XCD-aware order (hardware dispatches workgroup h to XCD h % 8): all workgroups of an environment on one XCD, so its
-  // cloud is fetched into one L2 (wpe = workgroups per environment; 0: natural order)
+  // cloud is fetched into one L2 (wpe = workgroups per environment; 0: natural order).  (A persistent form with a
+  // device-side unit queue, as in the second module's kernel below, was measured 7 % slower here: the SIMDs' issue
+  // ports, not their wave slots, are what is full.)
   int64_t wg = blockIdx.x;
   if (wpe > 0) {
     const int64_t xcd = wg & 7, slot = wg >> 3;
@@ -641,21 +645,42 @@ __global__ void __launch_bounds__(64 * res::WV) __attribute__((amdgpu_waves_per_
   }
   const int total = __builtin_amdgcn_readlane(pre, Q - 1);
   pre -= my_rows;
-  int s_pre[Q];
-#pragma unroll
-  for (int i = 0; i < Q; ++i) s_pre[i] = __builtin_amdgcn_readlane(pre, i);
   const int n_rows = total <= 32 ? 32 : ((total + 31) & ~31);
+  // group of 4 rows -> local query, one byte per group in this wave's LDS strip (a query's rows are whole groups; the
+  // groups past the end -- the index prefetch runs two tiles ahead -- belong to the last query): each query's lane
+  // writes its own groups, so a tile's row -> query map is one LDS read instead of a compare chain over the Q queries
+  unsigned char *rowq = rowq_all + wave * ROWQ;
+  {
+    const int g0 = pre >> 2, ng = my_rows >> 2;
+    for (int j = 0; j < ng; ++j) rowq[g0 + j] = (unsigned char)lane;
+    const int gt = total >> 2, ge = (n_rows + 64) >> 2;  // ge - gt <= 24
+    if (gt + lane < ge) rowq[gt + lane] = (unsigned char)(nq - 1);
+  }
+  __builtin_amdgcn_wave_barrier();
+  // uniform bases: everything a row needs is a 32-bit offset from one of these (ONE_ENV: npoint is a multiple of Q, the
+  // wave's queries share their environment's cloud; the rows are then fetched with buffer loads: one address VGPR)
+  const int64_t b0 = q0 / npoint;
+  const float *ctr_w = new_xyz + q0 * new_stride;
+  float *out_w = out + q0 * out_stride;
+  const __amdgpu_buffer_rsrc_t r_idx =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t *>(idx + q0 * nsample), 0, Q * nsample * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_ctr =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(ctr_w), 0, 0x7ffffff0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_xyz = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(xyz + b0 * N * (int64_t)stride), 0, 0x7ffffff0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t r_feat = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float *>(feat + b0 * N * (int64_t)feat_stride), 0, 0x7ffffff0, 0x00020000);
+  auto load_idx = [&](int ql, int off) __attribute__((always_inline)) {
+    return (int)__builtin_amdgcn_raw_buffer_load_b32(r_idx, (ql * nsample + off) * 4, 0, 0);
+  };
   if (append_centre && lane < 4 * nq) {  // [centre xyz | 0] behind the pooled features: the next module's operand row
     const int qi = lane >> 2, c = lane & 3;
-    out[(q0 + qi) * out_stride + C3 + c] = c < 3 ? new_xyz[(q0 + qi) * new_stride + c] : 0.0f;
+    out_w[qi * out_stride + C3 + c] = c < 3 ? ctr_w[qi * new_stride + c] : 0.0f;
   }
 
-  // row -> (local query, neighbour slot): the query is counted (one compare + add per query), its row offset and hit
-  // count come from the lanes that hold them; rows past the end repeat the last query's first slot
+  // row -> (local query, neighbour slot); rows past the end repeat the last query's first slot
   auto map_row = [&](int p, int &ql, int &off) __attribute__((always_inline)) {
-    int n = 0;
-#pragma unroll
-    for (int i = 1; i < Q; ++i) n += (i < nq && p >= s_pre[i]) ? 1 : 0;
+    const int n = rowq[p >> 2];
     ql = n;
     const int qpre = __builtin_amdgcn_ds_bpermute(4 * n, pre), qcnt = __builtin_amdgcn_ds_bpermute(4 * n, my_cnt);
     const int slot = p - qpre;
@@ -663,29 +688,44 @@ __global__ void __launch_bounds__(64 * res::WV) __attribute__((amdgpu_waves_per_
   };
   float px, py, pz, pf, cx, cy, cz;  // the gathered row: neighbour point, its label, its query's centre
   auto gather = [&](int ql, int k) __attribute__((always_inline)) {
-    const int64_t q = q0 + ql, b = q / npoint;
-    const float *pp = xyz + (b * N + k) * (int64_t)stride;
-    if (row16) {  // (x, y, z, label) is one aligned 16-byte row of the caller's slab
-      const float4 v = *reinterpret_cast<const float4 *>(pp);
-      px = v.x, py = v.y, pz = v.z, pf = v.w;
+    if constexpr (ONE_ENV) {
+      if (row16) {  // (x, y, z, label) is one aligned 16-byte row of the caller's slab
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r_xyz, k * 16, 0, 0);
+        px = __uint_as_float(v.x), py = __uint_as_float(v.y), pz = __uint_as_float(v.z), pf = __uint_as_float(v.w);
+      } else {
+        const int o = k * stride * 4;
+        px = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_xyz, o, 0, 0));
+        py = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_xyz, o, 4, 0));
+        pz = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_xyz, o, 8, 0));
+        pf = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_feat, k * feat_stride * 4, 0, 0));
+      }
     } else {
+      const int64_t b = (q0 + ql) / npoint;
+      const float *pp = xyz + (b * N + k) * (int64_t)stride;
       px = pp[0], py = pp[1], pz = pp[2];
       pf = feat[(b * N + k) * (int64_t)feat_stride];
     }
-    const float *cp = new_xyz + q * new_stride;
-    cx = cp[0], cy = cp[1], cz = cp[2];
+    const int o = ql * new_stride * 4;
+    cx = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_ctr, o, 0, 0));
+    cy = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_ctr, o, 4, 0));
+    cz = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_ctr, o, 8, 0));
   };
 
-  float run[Cfg::OT3];
+  float run[Cfg::OT3], b3v[Cfg::OT3];
 #pragma unroll
-  for (int ot = 0; ot < Cfg::OT3; ++ot) run[ot] = -__builtin_inff();
-  int cur = 0;  // local query being merged (wave-uniform)
-  auto flush = [&](int ot, int ql) __attribute__((always_inline)) {
-    float v = mpx_max_across_halves(run[ot]);
-    const int ch = ot * 32 + col;
-    v = fmaxf(v + b3_s[ch], 0.0f);
-    if (half == 0) out[(q0 + ql) * out_stride + ch] = v;
+  for (int ot = 0; ot < Cfg::OT3; ++ot) {
     run[ot] = -__builtin_inff();
+    b3v[ot] = b3_s[ot * 32 + col];
+  }
+  int cur = 0;  // local query being merged (wave-uniform)
+  const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(out_w, 0, 0x7ffffff0, 0x00020000);
+  auto flush = [&](int ql) __attribute__((always_inline)) {  // every output tile of query ql (scalar row offset)
+#pragma unroll
+    for (int ot = 0; ot < Cfg::OT3; ++ot) {
+      const float v = fmaxf(mpx_max_across_halves(run[ot]) + b3v[ot], 0.0f);
+      if (half == 0) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r_out, (ot * 32 + col) * 4, ql * out_stride * 4, 0);
+      run[ot] = -__builtin_inff();
+    }
   };
 
   // row pipeline: neighbour index two tiles ahead, row data one tile ahead
@@ -693,9 +733,9 @@ __global__ void __launch_bounds__(64 * res::WV) __attribute__((amdgpu_waves_per_
   {
     int off;
     map_row(col, ql_cur, off);
-    gather(ql_cur, idx[(q0 + ql_cur) * nsample + off]);
+    gather(ql_cur, load_idx(ql_cur, off));
     map_row(32 + col, ql_next, off);
-    k_next = idx[(q0 + ql_next) * nsample + off];
+    k_next = load_idx(ql_next, off);
   }
   int half_t = half;
   for (int rt = 0; rt < n_rows; rt += 32) {
@@ -713,7 +753,7 @@ __global__ void __launch_bounds__(64 * res::WV) __attribute__((amdgpu_waves_per_
     {
       int off;
       map_row(rt + 64 + col, ql_next, off);
-      k_next = idx[(q0 + ql_next) * nsample + off];
+      k_next = load_idx(ql_next, off);
     }
     // ---- layer 1: H1t = W1 . Xt ------------------------------------------------------------------------------------
     f32x16 a1[Cfg::OT1];
@@ -771,26 +811,30 @@ __global__ void __launch_bounds__(64 * res::WV) __attribute__((amdgpu_waves_per_
     int gq[8];
 #pragma unroll
     for (int g = 0; g < 8; ++g) gq[g] = __builtin_amdgcn_readlane(ql_tile, 4 * g);
+    float gm[Cfg::OT3][4];
 #pragma unroll
-    for (int ot = 0; ot < Cfg::OT3; ++ot) {
-      float gm[4];
+    for (int ot = 0; ot < Cfg::OT3; ++ot)
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj)
-        gm[jj] = fmaxf(fmaxf(a3[ot][4 * jj], a3[ot][4 * jj + 1]), fmaxf(a3[ot][4 * jj + 2], a3[ot][4 * jj + 3]));
-      int c = cur;
+        gm[ot][jj] = fmaxf(fmaxf(a3[ot][4 * jj], a3[ot][4 * jj + 1]), fmaxf(a3[ot][4 * jj + 2], a3[ot][4 * jj + 3]));
+    if (gq[7] == cur) {  // the whole tile belongs to the query being merged
+#pragma unroll
+      for (int ot = 0; ot < Cfg::OT3; ++ot)
+        run[ot] = fmaxf(run[ot], fmaxf(fmaxf(gm[ot][0], gm[ot][1]), fmaxf(gm[ot][2], gm[ot][3])));
+    } else {
 #pragma unroll
       for (int g = 0; g < 8; ++g) {
-        if (gq[g] != c) {
-          flush(ot, c);
-          c = gq[g];
+        if (gq[g] != cur) {
+          flush(cur);
+          cur = gq[g];
         }
-        run[ot] = fmaxf(run[ot], ((g & 1) == half) ? gm[g >> 1] : -__builtin_inff());
+#pragma unroll
+        for (int ot = 0; ot < Cfg::OT3; ++ot)
+          run[ot] = fmaxf(run[ot], ((g & 1) == half) ? gm[ot][g >> 1] : -__builtin_inff());
       }
     }
-    cur = gq[7];
   }
-#pragma unroll
-  for (int ot = 0; ot < Cfg::OT3; ++ot) flush(ot, cur);
+  flush(cur);
 }
 
 // ---- v2 of the factored (64+3, 128, 128, 256) module: persistent workgroups, ONE software-pipelined wave per SIMD ----
@@ -1144,14 +1188,20 @@ static int launch_sa_bf16(const float *xyz, int stride, const float *new_xyz, in
   MPX_REQUIRE(nq < ((int64_t)1 << 31), "mpx_sa_mlp_bf16x3: too many query points");
   constexpr int Q = CF == 1 ? 16 : 4;  // queries per wave
   if constexpr (CF == 1) {
-    if (bf16_resident()) {  // (walks the queries in their natural order: `order` is not needed)
+    if (bf16_resident() && nsample <= 128) {  // (walks the queries in their natural order: `order` is not needed)
       const int64_t per_wg = (int64_t)res::WV * Q;
       const int wpe = (npoint % per_wg == 0 && B % 8 == 0) ? (int)(npoint / per_wg) : 0;
       const int row16 = (feat == xyz + 3 && stride == 4 && feat_stride == 4 && ((uintptr_t)xyz & 15) == 0) ? 1 : 0;
-      hipLaunchKernelGGL((sa_mlp_bf16_resident_kernel<CF, C1, C2, C3, Q>), dim3((unsigned)((nq + per_wg - 1) / per_wg)),
-                         dim3(64 * res::WV), 0, mpx_s(stream), xyz, stride, new_xyz, new_stride, feat, feat_stride, idx, cnt,
-                         nq, N, npoint, nsample, static_cast<const unsigned char *>(wpack), out, out_stride, wpe, row16,
-                         append_centre);
+      const dim3 grid((unsigned)((nq + per_wg - 1) / per_wg));
+      const unsigned char *wp = static_cast<const unsigned char *>(wpack);
+      if (npoint % Q == 0)  // a wave's queries share their environment
+        hipLaunchKernelGGL((sa_mlp_bf16_resident_kernel<CF, C1, C2, C3, Q, true>), grid, dim3(64 * res::WV), 0, mpx_s(stream),
+                           xyz, stride, new_xyz, new_stride, feat, feat_stride, idx, cnt, nq, N, npoint, nsample, wp, out,
+                           out_stride, wpe, row16, append_centre);
+      else
+        hipLaunchKernelGGL((sa_mlp_bf16_resident_kernel<CF, C1, C2, C3, Q, false>), grid, dim3(64 * res::WV), 0, mpx_s(stream),
+                           xyz, stride, new_xyz, new_stride, feat, feat_stride, idx, cnt, nq, N, npoint, nsample, wp, out,
+                           out_stride, wpe, row16, append_centre);
       MPX_LAUNCH_CHECK("mpx_sa_mlp_bf16x3");
     }
   }
