@@ -122,30 +122,31 @@ int mpx_trajectory_metrics(const float *traj, const int32_t *lengths, const floa
 
 /* ---- split-bf16 ("bf16x3") dense layers: the opt-in fast mode of mpx_linear / mpx_linear_rowmax ------
  * Every fp32 product is evaluated as x_hi*w_hi + x_hi*w_lo + x_lo*w_hi on the bf16 matrix cores (fp32
- * accumulate).  mpx_split_bf16 splits a weight matrix [N,K] once into two bf16 planes [N,Kp], Kp = K rounded up
- * to 16 (zero padded); activations stay fp32 in HBM and are split while staged.  Same argument meaning as the
- * fp32 entry points otherwise.                                                                          */
-int mpx_split_bf16(const float *w, int N, int K, void *w_hi, void *w_lo, mpx_stream_t stream);
-int mpx_linear_bf16x3(const float *x, int ldx, const void *w_hi, const void *w_lo, const float *bias, int M,
-                      int N, int K, int act, float *y, int ldy, mpx_stream_t stream);
-int mpx_linear_rowmax_bf16x3(const float *x, int ldx, const void *w_hi, const void *w_lo, const float *bias,
-                             int M, int N, int K, int rows, float *y, int ldy, mpx_stream_t stream);
-/* Chains of such layers (the group-all module's 259 -> 512 -> 512 -> 1024 MLP, model.py:383) keep their
- * intermediate activations as the two bf16 planes the next layer multiplies with, [M, ldp] each (same bytes as the fp32
- * rows): mpx_linear_bf16x3_to_planes is mpx_linear_bf16x3 writing planes (y_hi / y_lo, N and ldp multiples of 4)
- * instead of fp32 rows; mpx_linear_bf16x3_planes reads planes (a_hi / a_lo [M, lda], K a multiple of 32, lda of 8, each
- * plane under 4 GB) and writes EITHER fp32 rows (y, y_hi = y_lo = NULL) OR planes (y = NULL);
- * mpx_linear_rowmax_bf16x3_planes is mpx_linear_rowmax_bf16x3 on plane input.  A value's planes are
- * hi = bf16(v), lo = bf16(v - hi) wherever they are made, and the products are accumulated in the same order, so a chain
- * through planes equals the chain through fp32 rows bit for bit.                                             */
-int mpx_linear_bf16x3_to_planes(const float *x, int ldx, const void *w_hi, const void *w_lo, const float *bias,
-                                int M, int N, int K, int act, void *y_hi, void *y_lo, int ldp, mpx_stream_t stream);
-int mpx_linear_bf16x3_planes(const void *a_hi, const void *a_lo, int lda, const void *w_hi, const void *w_lo,
-                             const float *bias, int M, int N, int K, int act, float *y, int ldy, void *y_hi,
-                             void *y_lo, int ldp, mpx_stream_t stream);
-int mpx_linear_rowmax_bf16x3_planes(const void *a_hi, const void *a_lo, int lda, const void *w_hi, const void *w_lo,
-                                    const float *bias, int M, int N, int K, int rows, float *y, int ldy,
-                                    mpx_stream_t stream);
+ * accumulate).  Split operands are held in the PAIRS form: a row holds, per group of 16 k-values,
+ * [hi x 16 | lo x 16] bf16 (hi = bf16(v), lo = bf16(v - hi)), K padded with zeros to Kp = roundup(K, 16):
+ * [rows, ld >= 2 Kp] bf16 -- the same bytes as the fp32 rows.  mpx_split_bf16 converts fp32 rows [R, K]
+ * (weights [N, K], once; or activations) into pairs.  Same argument meaning as the fp32 entry points otherwise;
+ * weights are always passed as pairs with ld = 2 Kp.
+ *   mpx_linear_bf16x3 / mpx_linear_rowmax_bf16x3: fp32 activations (split while staged), fp32 result.
+ *   mpx_linear_bf16x3_to_pairs: the same, result written as pairs (N and ldp multiples of 4, ldp >= 2 Np).
+ *   mpx_linear_bf16x3_pairs: activations already in pairs (a_pairs [M, lda], K a multiple of 16, lda of 8; under
+ *     4 GB), result EITHER fp32 rows (y) OR pairs (y_pairs); the other pointer NULL.
+ *   mpx_linear_rowmax_bf16x3_pairs: ReLU + max over each group of rows = 128 rows, as fp32 (y) or pairs (y_pairs).
+ * Chains of layers (the group-all module's 259 -> 512 -> 512 -> 1024 MLP, model.py:383) keep their activations in
+ * pairs: a value is split once, by the epilogue that produces it, and every form accumulates in the same order, so a
+ * chain through pairs equals the chain through fp32 rows bit for bit.                                            */
+int mpx_split_bf16(const float *x, int ldx, int64_t R, int K, void *pairs, int ldp, mpx_stream_t stream);
+int mpx_linear_bf16x3(const float *x, int ldx, const void *w_pairs, const float *bias, int M, int N, int K,
+                      int act, float *y, int ldy, mpx_stream_t stream);
+int mpx_linear_rowmax_bf16x3(const float *x, int ldx, const void *w_pairs, const float *bias, int M, int N,
+                             int K, int rows, float *y, int ldy, mpx_stream_t stream);
+int mpx_linear_bf16x3_to_pairs(const float *x, int ldx, const void *w_pairs, const float *bias, int M, int N,
+                               int K, int act, void *y_pairs, int ldp, mpx_stream_t stream);
+int mpx_linear_bf16x3_pairs(const void *a_pairs, int lda, const void *w_pairs, const float *bias, int M, int N,
+                            int K, int act, float *y, int ldy, void *y_pairs, int ldp, mpx_stream_t stream);
+int mpx_linear_rowmax_bf16x3_pairs(const void *a_pairs, int lda, const void *w_pairs, const float *bias, int M,
+                                   int N, int K, int rows, float *y, int ldy, void *y_pairs, int ldp,
+                                   mpx_stream_t stream);
 
 /* ---- training losses with analytic gradients (row N1; mpinets/loss.py:31-166) -------------------- */
 

@@ -64,12 +64,12 @@ PROTOTYPES = {
     "mpx_linear_workspace": [I, I, I],
     "mpx_linear_ws": [P, I, P, P, I, I, I, I, P, I, P, L, P],
     "mpx_linear_rowmax": [P, I, P, P, I, I, I, I, P, I, P],
-    "mpx_split_bf16": [P, I, I, P, P, P],
-    "mpx_linear_bf16x3": [P, I, P, P, P, I, I, I, I, P, I, P],
-    "mpx_linear_rowmax_bf16x3": [P, I, P, P, P, I, I, I, I, P, I, P],
-    "mpx_linear_bf16x3_to_planes": [P, I, P, P, P, I, I, I, I, P, P, I, P],
-    "mpx_linear_bf16x3_planes": [P, P, I, P, P, P, I, I, I, I, P, I, P, P, I, P],
-    "mpx_linear_rowmax_bf16x3_planes": [P, P, I, P, P, P, I, I, I, I, P, I, P],
+    "mpx_split_bf16": [P, I, L, I, P, I, P],
+    "mpx_linear_bf16x3": [P, I, P, P, I, I, I, I, P, I, P],
+    "mpx_linear_rowmax_bf16x3": [P, I, P, P, I, I, I, I, P, I, P],
+    "mpx_linear_bf16x3_to_pairs": [P, I, P, P, I, I, I, I, P, I, P],
+    "mpx_linear_bf16x3_pairs": [P, I, P, P, I, I, I, I, P, I, P, I, P],
+    "mpx_linear_rowmax_bf16x3_pairs": [P, I, P, P, I, I, I, I, P, I, P, I, P],
     "mpx_groupnorm_leaky_grad": [P, P, P, P, I, I, I, F, P, P, P, P, P],
     "mpx_act_backward": [P, P, L, I, P, P],
     "mpx_linear_wgrad_scratch": [I, I, I],

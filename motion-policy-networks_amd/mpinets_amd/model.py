@@ -75,30 +75,30 @@ class MPiNetsPointNet(nn.Module):
             return linear_x3(x, weight, bias, act, self._split, out=out, source=source)
         return linear(x, weight, bias, act, out=out)
 
-    def _sa3_through_planes(self, h: torch.Tensor, c3, B: int) -> torch.Tensor:
-        """The group-all MLP in ``bf16x3`` with its intermediate activations kept as hi / lo bf16 planes (the operand
-        form of the next layer: nothing is split on the way in, all four operand planes are staged by DMA) instead of
-        fp32 rows.  Bit-identical to the fp32-row chain (same split, same accumulation order).  Rows go in chunks that
-        keep a plane under the 4 GB a buffer descriptor spans."""
+    def _sa3_through_pairs(self, h: torch.Tensor, c3, B: int) -> torch.Tensor:
+        """The group-all MLP in ``bf16x3`` with its intermediate activations kept in the kernels' pairs form (hi / lo
+        bf16 per 16 k-values: the operand of the next layer, staged by DMA and split once, by the epilogue that makes
+        them) instead of fp32 rows.  Bit-identical to the fp32-row chain (same split, same accumulation order).  Rows
+        go in chunks that keep an operand under the 4 GB a buffer descriptor spans."""
         lib, dev = _lib, h.device
         w = [self._sa3_first_weight(), c3[1].weight.view(c3[1].out_channels, -1), c3[2].weight.view(c3[2].out_channels, -1)]
-        planes = [self._split.get(w[0], c3[0].weight), self._split.get(w[1]), self._split.get(w[2])]
+        wp = [self._split.get(w[0], c3[0].weight), self._split.get(w[1]), self._split.get(w[2])]
         n1, n2, n3 = (x.size(0) for x in w)
         pooled = torch.empty((B, n3), dtype=torch.float32, device=dev)
-        step = max(1, min(65535, ((1 << 32) - 4096) // (128 * 2 * max(n1, n2))))  # environments per call
+        step = max(1, min(65535, ((1 << 32) - 4096) // (128 * 4 * max(n1, n2))))  # environments per call
         nb0 = min(step, B)
-        p1 = torch.empty((2, nb0 * 128, n1), dtype=torch.bfloat16, device=dev)
-        p2 = torch.empty((2, nb0 * 128, n2), dtype=torch.bfloat16, device=dev)
+        p1 = torch.empty((nb0 * 128, 2 * n1), dtype=torch.bfloat16, device=dev)
+        p2 = torch.empty((nb0 * 128, 2 * n2), dtype=torch.bfloat16, device=dev)
         for b0 in range(0, B, step):
             nb = min(step, B - b0)
             M = nb * 128
             x = h[b0 * 128:]
-            lib.call("mpx_linear_bf16x3_to_planes", lib.ptr(x), h.stride(0), lib.ptr(planes[0][0]), lib.ptr(planes[0][1]),
-                     lib.ptr(c3[0].bias), M, n1, w[0].size(1), ACT_RELU, lib.ptr(p1[0]), lib.ptr(p1[1]), n1)
-            lib.call("mpx_linear_bf16x3_planes", lib.ptr(p1[0]), lib.ptr(p1[1]), n1, lib.ptr(planes[1][0]),
-                     lib.ptr(planes[1][1]), lib.ptr(c3[1].bias), M, n2, n1, ACT_RELU, None, 0, lib.ptr(p2[0]), lib.ptr(p2[1]), n2)
-            lib.call("mpx_linear_rowmax_bf16x3_planes", lib.ptr(p2[0]), lib.ptr(p2[1]), n2, lib.ptr(planes[2][0]),
-                     lib.ptr(planes[2][1]), lib.ptr(c3[2].bias), M, n3, n2, 128, lib.ptr(pooled[b0:]), pooled.stride(0))
+            lib.call("mpx_linear_bf16x3_to_pairs", lib.ptr(x), h.stride(0), lib.ptr(wp[0]), lib.ptr(c3[0].bias), M, n1,
+                     w[0].size(1), ACT_RELU, lib.ptr(p1), 2 * n1)
+            lib.call("mpx_linear_bf16x3_pairs", lib.ptr(p1), 2 * n1, lib.ptr(wp[1]), lib.ptr(c3[1].bias), M, n2, n1, ACT_RELU,
+                     None, 0, lib.ptr(p2), 2 * n2)
+            lib.call("mpx_linear_rowmax_bf16x3_pairs", lib.ptr(p2), 2 * n2, lib.ptr(wp[2]), lib.ptr(c3[2].bias), M, n3, n2,
+                     128, lib.ptr(pooled[b0:]), pooled.stride(0), None, 0)
         return pooled
 
     @staticmethod
@@ -271,9 +271,9 @@ class MPiNetsPointNet(nn.Module):
         # ---- SA3 (group-all): three GEMMs over B*128 rows + max over each environment's rows ------------
         c3 = sa3.convs()
         h = sa3_in.view(B * sa2.npoint, K3)
-        if (self.dense_precision == "bf16x3" and sa2.npoint == 128 and os.environ.get("MPX_BF16_PLANES", "1") != "0"
-                and all(c.out_channels % 32 == 0 for c in c3)):
-            pooled = self._sa3_through_planes(h, c3, B)
+        if (self.dense_precision == "bf16x3" and sa2.npoint == 128 and os.environ.get("MPX_BF16_PAIRS", "1") != "0"
+                and all(c.out_channels % 16 == 0 for c in c3)):
+            pooled = self._sa3_through_pairs(h, c3, B)
             self.last_counts = (cnt1, cnt2)
             if aux is not None:
                 aux.update(fps_idx1=idx1, xyz1=xyz1, ball_idx1=nbr1, ball_cnt1=cnt1, f1=f1, fps_idx2=idx2, ball_idx2=nbr2,
@@ -290,8 +290,7 @@ class MPiNetsPointNet(nn.Module):
             for b0 in range(0, B, 65535):
                 nb = min(65535, B - b0)
                 if self.dense_precision == "bf16x3":
-                    w3h, w3l = self._split.get(w3)
-                    lib.call("mpx_linear_rowmax_bf16x3", lib.ptr(h[b0 * 128:]), h.stride(0), lib.ptr(w3h), lib.ptr(w3l),
+                    lib.call("mpx_linear_rowmax_bf16x3", lib.ptr(h[b0 * 128:]), h.stride(0), lib.ptr(self._split.get(w3)),
                              lib.ptr(c3[2].bias), nb * 128, w3.size(0), w3.size(1), 128, lib.ptr(pooled[b0:]),
                              pooled.stride(0))
                 else:

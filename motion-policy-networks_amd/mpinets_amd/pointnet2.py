@@ -94,29 +94,37 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], 
 _WORKSPACE = {}
 
 
+def split_pairs(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """fp32 rows [R, K] -> the ``bf16x3`` kernels' PAIRS form [R, 2 * roundup(K, 16)] bf16: per group of 16 k-values
+    [hi x 16 | lo x 16], hi = bf16(v), lo = bf16(v - hi), zero padded."""
+    assert x.ndim == 2 and x.stride(1) == 1 and x.dtype == torch.float32
+    R, K = x.shape
+    Kp = (K + 15) // 16 * 16
+    if out is None:
+        out = torch.empty((R, 2 * Kp), dtype=torch.bfloat16, device=x.device)
+    assert out.shape == (R, 2 * Kp) and out.stride(1) == 1
+    _lib.call("mpx_split_bf16", _lib.ptr(x), x.stride(0), R, K, _lib.ptr(out), out.stride(0))
+    return out
+
+
 class SplitWeights:
-    """bf16 hi/lo planes of dense weight matrices for the ``bf16x3`` mode, refreshed when a parameter changes."""
+    """Dense weight matrices in the pairs form for the ``bf16x3`` mode, refreshed when a parameter changes."""
 
     def __init__(self):
         self.cache = {}
 
-    def get(self, weight: torch.Tensor, source: Optional[torch.Tensor] = None):
+    def get(self, weight: torch.Tensor, source: Optional[torch.Tensor] = None) -> torch.Tensor:
         """``source``: the parameter a derived matrix (padded / transposed copy) was made from -- its version
-        decides when the planes are stale."""
+        decides when the pairs are stale."""
         src = weight if source is None else source
         key = (src.data_ptr(), tuple(weight.shape))
         ver = (src._version, tuple(weight.shape))
         hit = self.cache.get(key)
         if hit is None or hit[0] != ver:
             w = _lib.f32c(weight.detach())
-            N, K = w.shape
-            Kp = (K + 15) // 16 * 16
-            hi = torch.empty((N, Kp), dtype=torch.bfloat16, device=w.device)
-            lo = torch.empty((N, Kp), dtype=torch.bfloat16, device=w.device)
-            _lib.call("mpx_split_bf16", _lib.ptr(w), N, K, _lib.ptr(hi), _lib.ptr(lo))
-            hit = (ver, hi, lo, w)  # w kept alive: its data_ptr is the key
+            hit = (ver, split_pairs(w), w)  # w kept alive: its data_ptr is the key
             self.cache[key] = hit
-        return hit[1], hit[2]
+        return hit[1]
 
 
 def linear_x3(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], act: int, split: SplitWeights,
@@ -125,12 +133,12 @@ def linear_x3(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor
     assert x.ndim == 2 and weight.ndim == 2 and x.size(1) == weight.size(1) and x.stride(1) == 1
     M, K = x.shape
     N = weight.size(0)
-    hi, lo = split.get(weight, source)
+    wp = split.get(weight, source)
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=x.device)
     assert out.shape == (M, N) and out.stride(1) == 1
-    _lib.call("mpx_linear_bf16x3", _lib.ptr(x), x.stride(0), _lib.ptr(hi), _lib.ptr(lo), _lib.ptr(bias), M, N, K, act,
-              _lib.ptr(out), out.stride(0))
+    _lib.call("mpx_linear_bf16x3", _lib.ptr(x), x.stride(0), _lib.ptr(wp), _lib.ptr(bias), M, N, K, act, _lib.ptr(out),
+              out.stride(0))
     return out
 
 

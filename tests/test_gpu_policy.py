@@ -417,9 +417,8 @@ def test_linear_bf16x3_matches_fp32_layer():
     x = T(rng.normal(size=(5 * 128, 512)).astype(np.float32))
     w = T((rng.normal(size=(1024, 512)) * 0.05).astype(np.float32))
     b = T(rng.normal(size=1024).astype(np.float32))
-    hi, lo = split.get(w)
     out = torch.full((5, 1024), -1.0, device=dev())
-    _lib.call("mpx_linear_rowmax_bf16x3", _lib.ptr(x), 512, _lib.ptr(hi), _lib.ptr(lo), _lib.ptr(b), 640, 1024, 512, 128,
+    _lib.call("mpx_linear_rowmax_bf16x3", _lib.ptr(x), 512, _lib.ptr(split.get(w)), _lib.ptr(b), 640, 1024, 512, 128,
               _lib.ptr(out), 1024)
     ref = linear_x3(x, w, b, 1, split).reshape(5, 128, 1024).max(dim=1).values
     assert torch.equal(out, ref)
@@ -429,83 +428,94 @@ def test_linear_bf16x3_matches_fp32_layer():
     np.testing.assert_allclose(y2.cpu().numpy(), (x.double() @ w.double().T + b.double()).cpu().numpy(), atol=3e-4)
 
 
-def _planes_of(x):
-    hi = x.to(torch.bfloat16)
-    return hi.contiguous(), (x - hi.float()).to(torch.bfloat16).contiguous()
+def _pairs_of(x):
+    """torch restatement of the pairs form: per 16 k-values [hi x 16 | lo x 16], hi = bf16(v), lo = bf16(v - hi)."""
+    R, K = x.shape
+    Kp = (K + 15) // 16 * 16
+    xp = torch.nn.functional.pad(x, (0, Kp - K))
+    hi = xp.to(torch.bfloat16)
+    lo = (xp - hi.float()).to(torch.bfloat16)
+    return torch.cat([hi.view(R, Kp // 16, 16), lo.view(R, Kp // 16, 16)], dim=2).reshape(R, 2 * Kp).contiguous()
 
 
-def test_linear_bf16x3_plane_chain_is_bit_identical_to_the_row_chain():
-    """The plane-input / plane-output forms of the bf16x3 dense layer (operands already split by the layer before,
-    staged by DMA) == the fp32-row form bit for bit: fp32 rows out, planes out, and the pooled variant; ragged M / N,
-    every activation; and the three-layer group-all chain through planes == the chain through fp32 rows."""
+def test_linear_bf16x3_pairs_chain_is_bit_identical_to_the_row_chain():
+    """The pairs-input / pairs-output forms of the bf16x3 dense layer (operands already split by the layer before,
+    staged by DMA) == the fp32-row form bit for bit: fp32 rows out, pairs out, and the pooled variants; ragged M / N,
+    every activation; and the three-layer group-all chain through pairs == the chain through fp32 rows."""
     from mpinets_amd import _lib
-    from mpinets_amd.pointnet2 import SplitWeights, linear_x3
+    from mpinets_amd.pointnet2 import SplitWeights, linear_x3, split_pairs
 
     rng = np.random.default_rng(23)
     split = SplitWeights()
-    for (M, N, K) in [(128, 128, 32), (257, 200, 64), (5, 4096, 1024), (1000, 64, 2112), (640, 1024, 512), (1, 4, 32)]:
+    for (M, N, K) in [(128, 128, 16), (257, 200, 48), (5, 4096, 1024), (1000, 64, 2112), (640, 1024, 512), (1, 4, 32),
+                      (300, 36, 20)]:
         x = T(rng.normal(size=(M, K)).astype(np.float32))
         w = T((rng.normal(size=(N, K)) / np.sqrt(K)).astype(np.float32))
         b = T(rng.normal(size=N).astype(np.float32))
-        wh, wl = split.get(w)
-        xh, xl = _planes_of(x)
+        wp = split.get(w)
+        assert torch.equal(wp, _pairs_of(w)) and torch.equal(split_pairs(x), _pairs_of(x))  # mpx_split_bf16 itself
+        Np = (N + 15) // 16 * 16
         for act in (0, 1, 2):
             ref = linear_x3(x, w, b, act, split)
+            rp = _pairs_of(ref)
+            # fp32 rows in -> pairs out (the pad columns of the last 16-group are left to the caller: pre-zeroed here)
+            yp = torch.zeros((M, 2 * Np), dtype=torch.bfloat16, device=dev())
+            _lib.call("mpx_linear_bf16x3_to_pairs", _lib.ptr(x), K, _lib.ptr(wp), _lib.ptr(b), M, N, K, act, _lib.ptr(yp), 2 * Np)
+            assert torch.equal(yp, rp), ("to_pairs", M, N, K, act)
+            if K % 16:
+                continue
+            xp = split_pairs(x)
             y = torch.full((M, N), 7.0, device=dev())
-            _lib.call("mpx_linear_bf16x3_planes", _lib.ptr(xh), _lib.ptr(xl), K, _lib.ptr(wh), _lib.ptr(wl), _lib.ptr(b), M, N,
-                      K, act, _lib.ptr(y), N, None, None, 0)
-            assert torch.equal(y, ref), (M, N, K, act)
-            rh, rl = _planes_of(ref)
-            for fn, args in (("mpx_linear_bf16x3_planes", (_lib.ptr(xh), _lib.ptr(xl), K)), ("mpx_linear_bf16x3_to_planes", (_lib.ptr(x), K))):
-                ph = torch.zeros((M, N), dtype=torch.bfloat16, device=dev())
-                pl = torch.zeros((M, N), dtype=torch.bfloat16, device=dev())
-                tail = (None, 0, _lib.ptr(ph), _lib.ptr(pl), N) if fn.endswith("_planes") and "to_" not in fn else (
-                    _lib.ptr(ph), _lib.ptr(pl), N)
-                _lib.call(fn, *args, _lib.ptr(wh), _lib.ptr(wl), _lib.ptr(b), M, N, K, act, *tail)
-                assert torch.equal(ph, rh) and torch.equal(pl, rl), (fn, M, N, K, act)
-    # padded leading dimensions (planes with lda > K, output planes with ldp > N: the columns beyond stay untouched)
+            _lib.call("mpx_linear_bf16x3_pairs", _lib.ptr(xp), 2 * K, _lib.ptr(wp), _lib.ptr(b), M, N, K, act, _lib.ptr(y), N,
+                      None, 0)
+            assert torch.equal(y, ref), ("pairs", M, N, K, act)
+            yp.zero_()
+            _lib.call("mpx_linear_bf16x3_pairs", _lib.ptr(xp), 2 * K, _lib.ptr(wp), _lib.ptr(b), M, N, K, act, None, 0,
+                      _lib.ptr(yp), 2 * Np)
+            assert torch.equal(yp, rp), ("pairs->pairs", M, N, K, act)
+    # padded leading dimensions: activation pairs with lda > 2 K, output pairs with ldp > 2 Np (columns beyond untouched)
     M, N, K = 300, 96, 64
     x = T(rng.normal(size=(M, K)).astype(np.float32))
     w = T(rng.normal(size=(N, K)).astype(np.float32))
-    wh, wl = split.get(w)
-    xh, xl = (torch.nn.functional.pad(p, (0, 8)).contiguous() for p in _planes_of(x))
-    ph = torch.full((M, N + 4), 3.0, dtype=torch.bfloat16, device=dev())
-    pl = torch.full((M, N + 4), 3.0, dtype=torch.bfloat16, device=dev())
-    _lib.call("mpx_linear_bf16x3_planes", _lib.ptr(xh), _lib.ptr(xl), K + 8, _lib.ptr(wh), _lib.ptr(wl), None, M, N, K, 0, None,
-              0, _lib.ptr(ph), _lib.ptr(pl), N + 4)
-    rh, rl = _planes_of(linear_x3(x, w, None, 0, split))
-    assert torch.equal(ph[:, :N], rh) and torch.equal(pl[:, :N], rl) and bool((ph[:, N:] == 3).all() and (pl[:, N:] == 3).all())
-    # the group-all chain: 272 -> 512 -> 512 -> 1024 + max over 128 rows, 5 environments
+    xp = torch.nn.functional.pad(split_pairs(x), (0, 8)).contiguous()
+    yp = torch.full((M, 2 * N + 4), 3.0, dtype=torch.bfloat16, device=dev())
+    _lib.call("mpx_linear_bf16x3_pairs", _lib.ptr(xp), 2 * K + 8, _lib.ptr(split.get(w)), None, M, N, K, 0, None, 0, _lib.ptr(yp),
+              2 * N + 4)
+    assert torch.equal(yp[:, :2 * N], _pairs_of(linear_x3(x, w, None, 0, split))) and bool((yp[:, 2 * N:] == 3).all())
+    # the group-all chain: 272 -> 512 -> 512 -> 1024 + max over 128 rows, 5 environments (an odd number of 128-row
+    # groups: the last 256-row tile is half empty), pooled as fp32 and as pairs
     x = T(np.maximum(rng.normal(size=(640, 272)), 0).astype(np.float32))
     ws = [T((rng.normal(size=s) * 0.05).astype(np.float32)) for s in ((512, 272), (512, 512), (1024, 512))]
     bs = [T(rng.normal(size=n).astype(np.float32)) for n in (512, 512, 1024)]
     h = linear_x3(linear_x3(x, ws[0], bs[0], 1, split), ws[1], bs[1], 1, split)
-    hi, lo = split.get(ws[2])
     ref = torch.empty((5, 1024), device=dev())
-    _lib.call("mpx_linear_rowmax_bf16x3", _lib.ptr(h), 512, _lib.ptr(hi), _lib.ptr(lo), _lib.ptr(bs[2]), 640, 1024, 512, 128,
+    _lib.call("mpx_linear_rowmax_bf16x3", _lib.ptr(h), 512, _lib.ptr(split.get(ws[2])), _lib.ptr(bs[2]), 640, 1024, 512, 128,
               _lib.ptr(ref), 1024)
-    p1 = torch.empty((2, 640, 512), dtype=torch.bfloat16, device=dev())
+    p1 = torch.empty((640, 1024), dtype=torch.bfloat16, device=dev())
     p2 = torch.empty_like(p1)
-    s0, s1 = split.get(ws[0]), split.get(ws[1])
-    _lib.call("mpx_linear_bf16x3_to_planes", _lib.ptr(x), 272, _lib.ptr(s0[0]), _lib.ptr(s0[1]), _lib.ptr(bs[0]), 640, 512, 272, 1,
-              _lib.ptr(p1[0]), _lib.ptr(p1[1]), 512)
-    _lib.call("mpx_linear_bf16x3_planes", _lib.ptr(p1[0]), _lib.ptr(p1[1]), 512, _lib.ptr(s1[0]), _lib.ptr(s1[1]), _lib.ptr(bs[1]),
-              640, 512, 512, 1, None, 0, _lib.ptr(p2[0]), _lib.ptr(p2[1]), 512)
+    _lib.call("mpx_linear_bf16x3_to_pairs", _lib.ptr(x), 272, _lib.ptr(split.get(ws[0])), _lib.ptr(bs[0]), 640, 512, 272, 1,
+              _lib.ptr(p1), 1024)
+    _lib.call("mpx_linear_bf16x3_pairs", _lib.ptr(p1), 1024, _lib.ptr(split.get(ws[1])), _lib.ptr(bs[1]), 640, 512, 512, 1, None,
+              0, _lib.ptr(p2), 1024)
     out = torch.full((5, 1024), -1.0, device=dev())
-    _lib.call("mpx_linear_rowmax_bf16x3_planes", _lib.ptr(p2[0]), _lib.ptr(p2[1]), 512, _lib.ptr(hi), _lib.ptr(lo),
-              _lib.ptr(bs[2]), 640, 1024, 512, 128, _lib.ptr(out), 1024)
+    _lib.call("mpx_linear_rowmax_bf16x3_pairs", _lib.ptr(p2), 1024, _lib.ptr(split.get(ws[2])), _lib.ptr(bs[2]), 640, 1024, 512,
+              128, _lib.ptr(out), 1024, None, 0)
     assert torch.equal(out, ref)
-    # argument checks: K must be whole 32-k slabs, exactly one output form
+    outp = torch.zeros((5, 2048), dtype=torch.bfloat16, device=dev())
+    _lib.call("mpx_linear_rowmax_bf16x3_pairs", _lib.ptr(p2), 1024, _lib.ptr(split.get(ws[2])), _lib.ptr(bs[2]), 640, 1024, 512,
+              128, None, 0, _lib.ptr(outp), 2048)
+    assert torch.equal(outp, _pairs_of(ref))
+    # argument checks: K must be whole 16-k groups, exactly one output form
     with pytest.raises(_lib.MpxError):
-        _lib.call("mpx_linear_bf16x3_planes", _lib.ptr(p1[0]), _lib.ptr(p1[1]), 512, _lib.ptr(s1[0]), _lib.ptr(s1[1]), None, 640,
-                  512, 48, 0, None, 0, _lib.ptr(p2[0]), _lib.ptr(p2[1]), 512)
+        _lib.call("mpx_linear_bf16x3_pairs", _lib.ptr(p1), 1024, _lib.ptr(split.get(ws[1])), None, 640, 512, 40, 0, None, 0,
+                  _lib.ptr(p2), 1024)
     with pytest.raises(_lib.MpxError):
-        _lib.call("mpx_linear_bf16x3_planes", _lib.ptr(p1[0]), _lib.ptr(p1[1]), 512, _lib.ptr(s1[0]), _lib.ptr(s1[1]), None, 640,
-                  512, 512, 0, _lib.ptr(out), 512, _lib.ptr(p2[0]), _lib.ptr(p2[1]), 512)
+        _lib.call("mpx_linear_bf16x3_pairs", _lib.ptr(p1), 1024, _lib.ptr(split.get(ws[1])), None, 640, 512, 512, 0,
+                  _lib.ptr(out), 512, _lib.ptr(p2), 1024)
 
 
-def test_policy_forward_bf16x3_planes_on_and_off_agree(monkeypatch):
-    """The policy forward in bf16x3 with the group-all MLP through planes (default) == with fp32 rows, bit for bit."""
+def test_policy_forward_bf16x3_pairs_on_and_off_agree(monkeypatch):
+    """The policy forward in bf16x3 with the group-all MLP through pairs (default) == with fp32 rows, bit for bit."""
     from mpinets_amd.model import MotionPolicyNetwork
     from mpinets_amd.scenes import make_problem_batch
 
@@ -514,7 +524,7 @@ def test_policy_forward_bf16x3_planes_on_and_off_agree(monkeypatch):
     prob = make_problem_batch(6, seed=31, device=dev())
     with torch.no_grad():
         a = mdl(prob["xyz"], prob["q_norm"]).clone()
-        monkeypatch.setenv("MPX_BF16_PLANES", "0")
+        monkeypatch.setenv("MPX_BF16_PAIRS", "0")
         b = mdl(prob["xyz"], prob["q_norm"]).clone()
     assert torch.equal(a, b)
 
