@@ -393,6 +393,10 @@ int mpx_linear_rowmax(const float *x, int ldx, const float *w, const float *bias
  * allowed.  x,y [M,C].                                                                       */
 int mpx_groupnorm_leaky(const float *x, const float *gamma, const float *beta, int M, int C,
                         int groups, float eps, float *y, mpx_stream_t stream);
+/* the same, with the result written in the bf16x3 dense layers' pairs form (see mpx_split_bf16; C a multiple of
+ * 16, ldp >= 2 C bf16 elements) instead of fp32 rows: the operand of the dense layer that follows.  */
+int mpx_groupnorm_leaky_to_pairs(const float *x, const float *gamma, const float *beta, int M, int C,
+                                 int groups, float eps, void *y_pairs, int ldp, mpx_stream_t stream);
 
 /* max over `rows` consecutive rows: x [G*rows, C] -> y [G, C]  (max_pool2d of the group-all
  * SA module, model.py:383)                                                                   */

@@ -449,7 +449,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 __global__ void __launch_bounds__(256)
     groupnorm_leaky_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
                            const float *__restrict__ beta, int64_t n_rg, int C, int groups, float eps,
-                           float *__restrict__ y) {
+                           float *__restrict__ y, __bf16 *__restrict__ pairs, int ldp) {
   const int lane = threadIdx.x & 63;
   const int64_t rg = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (rg >= n_rg) return;
@@ -481,8 +481,17 @@ __global__ void __launch_bounds__(256)
   for (int i = 0; i < MAXV; ++i) {
     const int c = lane + 64 * i;
     if (c < gs) {
-      const float o = (v[i] - mean) * rstd * gamma[g * gs + c] + beta[g * gs + c];
-      yp[c] = o >= 0.0f ? o : o * 0.01f;
+      float o = (v[i] - mean) * rstd * gamma[g * gs + c] + beta[g * gs + c];
+      o = o >= 0.0f ? o : o * 0.01f;
+      if (pairs) {  // the bf16x3 dense kernels' operand form: per 16 channels [hi x 16 | lo x 16] (dense_bf16.hip)
+        const int cc = g * gs + c;
+        __bf16 *d = pairs + row * (int64_t)ldp + (cc >> 4) * 32 + (cc & 15);
+        const __bf16 h = (__bf16)o;
+        d[0] = h;
+        d[16] = (__bf16)(o - (float)h);
+      } else {
+        yp[c] = o;
+      }
     }
   }
 }
@@ -494,8 +503,21 @@ MPX_EXPORT int mpx_groupnorm_leaky(const float *x, const float *gamma, const flo
   if (M == 0) return 0;
   const int64_t n = (int64_t)M * groups;
   hipLaunchKernelGGL(groupnorm_leaky_kernel, dim3(cdiv(n, 4)), dim3(256), 0, mpx_s(stream), x, gamma, beta, n, C,
-                     groups, eps, y);
+                     groups, eps, y, (__bf16 *)nullptr, 0);
   MPX_LAUNCH_CHECK("mpx_groupnorm_leaky");
+}
+
+// the same, with the result written in the bf16x3 dense kernels' pairs form (mpx_split_bf16) instead of fp32 rows
+MPX_EXPORT int mpx_groupnorm_leaky_to_pairs(const float *x, const float *gamma, const float *beta, int M, int C, int groups,
+                                            float eps, void *y_pairs, int ldp, mpx_stream_t stream) {
+  MPX_REQUIRE(M >= 0 && C >= 1 && groups >= 1 && C % groups == 0, "mpx_groupnorm_leaky_to_pairs: bad size");
+  MPX_REQUIRE(C / groups <= 512, "mpx_groupnorm_leaky_to_pairs: group size %d > 512 unsupported", C / groups);
+  MPX_REQUIRE(y_pairs && C % 16 == 0 && ldp >= 2 * C, "mpx_groupnorm_leaky_to_pairs: C must be a multiple of 16, ldp >= 2 C");
+  if (M == 0) return 0;
+  const int64_t n = (int64_t)M * groups;
+  hipLaunchKernelGGL(groupnorm_leaky_kernel, dim3(cdiv(n, 4)), dim3(256), 0, mpx_s(stream), x, gamma, beta, n, C,
+                     groups, eps, (float *)nullptr, reinterpret_cast<__bf16 *>(y_pairs), ldp);
+  MPX_LAUNCH_CHECK("mpx_groupnorm_leaky_to_pairs");
 }
 
 // ---- max over groups of consecutive rows -------------------------------------------------------------

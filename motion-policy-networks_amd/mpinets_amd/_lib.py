@@ -75,6 +75,7 @@ PROTOTYPES = {
     "mpx_linear_wgrad_scratch": [I, I, I],
     "mpx_linear_wgrad": [P, I, P, I, I, I, I, P, P, P, P],
     "mpx_groupnorm_leaky": [P, P, P, I, I, I, F, P, P],
+    "mpx_groupnorm_leaky_to_pairs": [P, P, P, I, I, I, F, P, I, P],
     "mpx_rowmax": [P, I, I, I, I, P, I, P],
     "mpx_append_columns": [P, I, I, I, L, P, I, I, P],
     "mpx_policy_workspace": [I, I],

@@ -75,7 +75,7 @@ class MPiNetsPointNet(nn.Module):
             return linear_x3(x, weight, bias, act, self._split, out=out, source=source)
         return linear(x, weight, bias, act, out=out)
 
-    def _sa3_through_pairs(self, h: torch.Tensor, c3, B: int) -> torch.Tensor:
+    def _sa3_through_pairs(self, h: torch.Tensor, c3, B: int, pooled_pairs: bool = False) -> torch.Tensor:
         """The group-all MLP in ``bf16x3`` with its intermediate activations kept in the kernels' pairs form (hi / lo
         bf16 per 16 k-values: the operand of the next layer, staged by DMA and split once, by the epilogue that makes
         them) instead of fp32 rows.  Bit-identical to the fp32-row chain (same split, same accumulation order).  Rows
@@ -84,7 +84,8 @@ class MPiNetsPointNet(nn.Module):
         w = [self._sa3_first_weight(), c3[1].weight.view(c3[1].out_channels, -1), c3[2].weight.view(c3[2].out_channels, -1)]
         wp = [self._split.get(w[0], c3[0].weight), self._split.get(w[1]), self._split.get(w[2])]
         n1, n2, n3 = (x.size(0) for x in w)
-        pooled = torch.empty((B, n3), dtype=torch.float32, device=dev)
+        pooled = (torch.empty((B, 2 * n3), dtype=torch.bfloat16, device=dev) if pooled_pairs else
+                  torch.empty((B, n3), dtype=torch.float32, device=dev))
         step = max(1, min(65535, ((1 << 32) - 4096) // (128 * 4 * max(n1, n2))))  # environments per call
         nb0 = min(step, B)
         p1 = torch.empty((nb0 * 128, 2 * n1), dtype=torch.bfloat16, device=dev)
@@ -97,8 +98,12 @@ class MPiNetsPointNet(nn.Module):
                      w[0].size(1), ACT_RELU, lib.ptr(p1), 2 * n1)
             lib.call("mpx_linear_bf16x3_pairs", lib.ptr(p1), 2 * n1, lib.ptr(wp[1]), lib.ptr(c3[1].bias), M, n2, n1, ACT_RELU,
                      None, 0, lib.ptr(p2), 2 * n2)
-            lib.call("mpx_linear_rowmax_bf16x3_pairs", lib.ptr(p2), 2 * n2, lib.ptr(wp[2]), lib.ptr(c3[2].bias), M, n3, n2,
-                     128, lib.ptr(pooled[b0:]), pooled.stride(0), None, 0)
+            if pooled_pairs:
+                lib.call("mpx_linear_rowmax_bf16x3_pairs", lib.ptr(p2), 2 * n2, lib.ptr(wp[2]), lib.ptr(c3[2].bias), M, n3,
+                         n2, 128, None, 0, lib.ptr(pooled[b0:]), pooled.stride(0))
+            else:
+                lib.call("mpx_linear_rowmax_bf16x3_pairs", lib.ptr(p2), 2 * n2, lib.ptr(wp[2]), lib.ptr(c3[2].bias), M, n3,
+                         n2, 128, lib.ptr(pooled[b0:]), pooled.stride(0), None, 0)
         return pooled
 
     @staticmethod
@@ -115,6 +120,26 @@ class MPiNetsPointNet(nn.Module):
         for module in self.SA_modules:
             xyz, features = module(xyz, features)
         return self._fc(features.squeeze(-1))
+
+    def _fc_through_pairs(self, xp: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """The fc head in ``bf16x3`` on an input already in the pairs form [B, 2 * 1024]: every Linear reads pairs (its
+        operands go to LDS by DMA), GroupNorm + LeakyReLU writes the next layer's pairs.  Bit-identical to ``_fc``."""
+        lib, fc = _lib, self.fc_layer
+        B, dev = xp.size(0), xp.device
+        h = xp
+        for li, gi in ((0, 1), (3, 4), (6, None)):
+            lin = fc[li]
+            N, K = lin.weight.shape
+            last = gi is None
+            y = out if (last and out is not None) else torch.empty((B, N), dtype=torch.float32, device=dev)
+            lib.call("mpx_linear_bf16x3_pairs", lib.ptr(h), h.stride(0), lib.ptr(self._split.get(lin.weight)), lib.ptr(lin.bias),
+                     B, N, K, ACT_NONE, lib.ptr(y), y.stride(0), None, 0)
+            if last:
+                return y
+            gn = fc[gi]
+            h = torch.empty((B, 2 * N), dtype=torch.bfloat16, device=dev)
+            lib.call("mpx_groupnorm_leaky_to_pairs", lib.ptr(y), lib.ptr(gn.weight), lib.ptr(gn.bias), B, N, gn.num_groups,
+                     float(gn.eps), lib.ptr(h), 2 * N)
 
     def _fc(self, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         fc = self.fc_layer
@@ -273,8 +298,10 @@ class MPiNetsPointNet(nn.Module):
         h = sa3_in.view(B * sa2.npoint, K3)
         if (self.dense_precision == "bf16x3" and sa2.npoint == 128 and os.environ.get("MPX_BF16_PAIRS", "1") != "0"
                 and all(c.out_channels % 16 == 0 for c in c3)):
-            pooled = self._sa3_through_pairs(h, c3, B)
             self.last_counts = (cnt1, cnt2)
+            if aux is None and c3[2].out_channels % 16 == 0:  # (aux wants the pooled features as fp32)
+                return self._fc_through_pairs(self._sa3_through_pairs(h, c3, B, pooled_pairs=True), out=out)
+            pooled = self._sa3_through_pairs(h, c3, B)
             if aux is not None:
                 aux.update(fps_idx1=idx1, xyz1=xyz1, ball_idx1=nbr1, ball_cnt1=cnt1, f1=f1, fps_idx2=idx2, ball_idx2=nbr2,
                            ball_cnt2=cnt2, sa3_in=sa3_in, f3=pooled)

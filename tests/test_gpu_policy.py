@@ -505,6 +505,13 @@ def test_linear_bf16x3_pairs_chain_is_bit_identical_to_the_row_chain():
     _lib.call("mpx_linear_rowmax_bf16x3_pairs", _lib.ptr(p2), 1024, _lib.ptr(split.get(ws[2])), _lib.ptr(bs[2]), 640, 1024, 512,
               128, None, 0, _lib.ptr(outp), 2048)
     assert torch.equal(outp, _pairs_of(ref))
+    # GroupNorm + LeakyReLU writing the next layer's pairs == its fp32 result, split
+    from mpinets_amd.pointnet2 import groupnorm_leaky
+    xg = T(rng.normal(size=(37, 4096)).astype(np.float32))
+    gam, bet = T(rng.normal(size=4096).astype(np.float32)), T(rng.normal(size=4096).astype(np.float32))
+    gp = torch.zeros((37, 8192), dtype=torch.bfloat16, device=dev())
+    _lib.call("mpx_groupnorm_leaky_to_pairs", _lib.ptr(xg), _lib.ptr(gam), _lib.ptr(bet), 37, 4096, 16, 1e-5, _lib.ptr(gp), 8192)
+    assert torch.equal(gp, _pairs_of(groupnorm_leaky(xg, gam, bet, 16)))
     # argument checks: K must be whole 16-k groups, exactly one output form
     with pytest.raises(_lib.MpxError):
         _lib.call("mpx_linear_bf16x3_pairs", _lib.ptr(p1), 1024, _lib.ptr(split.get(ws[1])), None, 640, 512, 40, 0, None, 0,
