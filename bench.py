@@ -228,8 +228,9 @@ def main():
         eng.step()  # packs the bf16 operand blocks + warm-up
         torch.cuda.synchronize()
         shard.barrier()
-        _lib.profile_start("mpx_sa_mlp_bf16x3", "mpx_sa_mlp_bf16x3_factored", "mpx_linear_bf16x3", "mpx_linear_rowmax_bf16x3",
-                            "mpx_linear", "mpx_linear_ws")
+        dense_calls = ("mpx_linear_bf16x3", "mpx_linear_rowmax_bf16x3", "mpx_linear_bf16x3_to_pairs", "mpx_linear_bf16x3_pairs",
+                       "mpx_linear_rowmax_bf16x3_pairs", "mpx_linear", "mpx_linear_ws")
+        _lib.profile_start("mpx_sa_mlp_bf16x3", "mpx_sa_mlp_bf16x3_factored", *dense_calls)
         tf0 = time.perf_counter()
         for _ in range(args.fast_steps):
             eng.step()
@@ -238,8 +239,7 @@ def main():
         fel = shard.max_over_ranks(time.perf_counter() - tf0, dev)
         fall = _lib.profile_stop()
         model.set_precision("fp32")
-        fdense = float(np.sum(fall["mpx_linear_bf16x3"]) + np.sum(fall["mpx_linear_rowmax_bf16x3"])
-                       + np.sum(fall["mpx_linear"]) + np.sum(fall["mpx_linear_ws"])) / args.fast_steps
+        fdense = float(sum(np.sum(fall[k]) for k in dense_calls)) / args.fast_steps
         fast = (fel, float(np.mean(fall["mpx_sa_mlp_bf16x3"])), float(np.mean(fall["mpx_sa_mlp_bf16x3_factored"])), fdense)
 
     # final host gather (the only cross-rank data movement): joint angles + collision flags
