@@ -22,6 +22,7 @@
 #include "common.h"
 
 #include <stdlib.h>
+#include <type_traits>
 
 typedef unsigned long long u64;
 
@@ -255,6 +256,315 @@ __global__ void __launch_bounds__(64)
   }
 }
 
+// ---- farthest point sampling with exact culling (512 < N <= 8192) ---------------------------------------------------
+// fps_kernel above is bound by its VALU stream: every pick re-evaluates all N running distances (7 instructions per
+// point) although, after the first few dozen picks, a new pick lowers the running distance of only the points near it.
+// Here the cloud is first ordered along a Morton curve (16^3 cells over its bounding box, counting sort in LDS) and cut
+// into chunks of 64 consecutive points -- one register slot of one wave, dealt round-robin to the 8 waves so that the
+// chunks around a pick belong to different waves.  Per chunk a wave keeps, in lane `slot` of a few registers, the
+// bounding box and an UPPER bound `cub` of the chunk's largest running distance.  A pick costs a wave one VALU pass
+// over those <= 16 lanes: the smallest and the largest squared distance from the pick to the box; the chunk's points
+// are re-evaluated only if the smallest is below `cub` (28 of 98 chunks on the bench scenes), and `cub` drops to the
+// largest (every running distance of the chunk is now <= its distance to the pick <= that).  Skipping is exact: the
+// lower bound is evaluated with the same fp32 operations in the same order as a point's distance (x - x1 is monotone
+// in x; a*a and fma(a,a,c) are monotone in |a| and c), so bound <= distance(p) for every p in the box IN fp32, and
+// bound >= cub >= running(p) means min(distance, running) == running.  (`cub` is padded by 1e-6 relative: it only has to
+// be an upper bound.)  The arg-max over all keys, the tie order and the outputs are those of fps_kernel bit for bit:
+// the key's low word carries the same tie rank (bit-reversed k mod 512, then k / 512) in its upper bits; the point's
+// position in the sorted order rides in the 13 bits below, which can never decide a comparison (the rank bits above
+// identify the point) and gives the picked point's coordinates with one LDS lookup.
+// A first form kept each chunk's exact (distance, rank) maximum by a wave reduction per re-evaluated chunk (9.7 chunks
+// per pick instead of 28): bit-exact too, and no faster than fps_kernel -- the serial reductions made the pick a
+// 1.7 k-cycle latency chain, two of which fit a CU.
+template <int CTRL>
+__device__ __forceinline__ float dpp_movf(float v) {
+  return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), CTRL, 0xf, 0xf, true));
+}
+template <bool MAX>
+__device__ __forceinline__ float wave_red_f32(float v) {  // min / max over the wave, in every lane's return value
+  auto op = [](float a, float b) { return MAX ? fmaxf(a, b) : fminf(a, b); };
+  v = op(v, dpp_movf<0xB1>(v));
+  v = op(v, dpp_movf<0x4E>(v));
+  v = op(v, dpp_movf<0x141>(v));
+  v = op(v, dpp_movf<0x140>(v));
+  auto rl = [&](int l) { return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v), l)); };
+  return op(op(rl(0), rl(16)), op(rl(32), rl(48)));
+}
+// v with lane `lane` replaced by the wave-uniform value s.  (v_writelane takes one SGPR: the lane select must be an
+// inline constant -- the switch folds away where `lane` is an unrolled loop index.)
+__device__ __forceinline__ unsigned writelane_u32(unsigned s, int lane, unsigned v) {
+  const unsigned su = (unsigned)__builtin_amdgcn_readfirstlane((int)s);
+#define MPX_WL(L) case L: asm("v_writelane_b32 %0, %1, " #L : "+v"(v) : "s"(su)); break;
+  switch (lane) {
+    MPX_WL(0) MPX_WL(1) MPX_WL(2) MPX_WL(3) MPX_WL(4) MPX_WL(5) MPX_WL(6) MPX_WL(7)
+    MPX_WL(8) MPX_WL(9) MPX_WL(10) MPX_WL(11) MPX_WL(12) MPX_WL(13) MPX_WL(14) MPX_WL(15)
+    default: break;
+  }
+#undef MPX_WL
+  return v;
+}
+__device__ __forceinline__ float writelane_f32(float s, int lane, float v) {
+  return __uint_as_float(writelane_u32(__float_as_uint(s), lane, __float_as_uint(v)));
+}
+__device__ __forceinline__ u64 writelane64(u64 s, int lane, u64 v) {
+  return pack64(writelane_u32((unsigned)s, lane, (unsigned)v), writelane_u32((unsigned)(s >> 32), lane, (unsigned)(v >> 32)));
+}
+__device__ __forceinline__ unsigned morton4(unsigned v) {  // 4 bits -> bits 0, 3, 6, 9
+  v &= 0xFu;
+  v = (v | (v << 4)) & 0xC3u;
+  v = (v | (v << 2)) & 0x249u;
+  return v;
+}
+
+// loop with compile-time indices (arrays indexed this way are split into registers before any control flow is built
+// around their elements; with `#pragma unroll` loops the 26-dword key array of fps_cull_kernel stayed ONE vector value
+// that was copied and spilled whole at every conditional update)
+template <int I, int E, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+  if constexpr (I < E) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, E>(f);
+  }
+}
+
+constexpr int FPSC_CELLS = 4096, FPSC_THREADS = 512, FPSC_WAVES = 8;
+// dynamic LDS: [0,256) reduction slots, [256,512) scalars (position of point 0, cloud bounding box exchange), then the
+// cloud in sorted order sx | sy | sz (3 N floats); the prologue's histogram (16 KB) and position -> index map (2 N bytes)
+// live in the same area before the coordinates are written
+__host__ __device__ constexpr size_t fpsc_lds_bytes(int N) {
+  const size_t cloud = (size_t)3 * N * 4, pro = (size_t)FPSC_CELLS * 4 + (((size_t)N * 2 + 15) & ~(size_t)15);
+  return 512 + (cloud > pro ? cloud : pro);
+}
+template <int PTS>
+__global__ void __launch_bounds__(FPSC_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
+    fps_cull_kernel(const float *__restrict__ xyz, int N, int stride, int npoint, int32_t *__restrict__ idx,
+                    float *__restrict__ new_xyz, int new_stride) {
+  static_assert(PTS >= 2 && PTS <= 16, "slots per lane");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  u64 *slots = reinterpret_cast<u64 *>(smem);                    // [2][16]
+  int *scal = reinterpret_cast<int *>(smem + 256);               // [0]: sorted position of point 0
+  float *bbx = reinterpret_cast<float *>(smem + 256 + 16);       // [8 waves][6]
+  unsigned *hist = reinterpret_cast<unsigned *>(smem + 512);     // [4096]   (prologue)
+  unsigned short *pmap = reinterpret_cast<unsigned short *>(smem + 512 + FPSC_CELLS * 4);  // [N] (prologue)
+  float *sx = reinterpret_cast<float *>(smem + 512), *sy = sx + N, *sz = sy + N;           // (after the prologue)
+
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const float *pts = xyz + (size_t)b * N * stride;
+  int32_t *out = idx + (size_t)b * npoint;
+  float *nxyz = new_xyz ? new_xyz + (size_t)b * npoint * new_stride : nullptr;
+  const float INF = __builtin_inff();
+
+  // ---- prologue 1: cells of the points in index order (thread t owns k = t + 512 i), histogram, positions ----------
+  unsigned code[PTS], rnk[PTS];
+  {
+    float x[PTS], y[PTS], z[PTS];
+    float mn[3] = {INF, INF, INF}, mx[3] = {-INF, -INF, -INF};
+#pragma unroll
+    for (int i = 0; i < PTS; ++i) {
+      const int k = tid + i * FPSC_THREADS;
+      x[i] = y[i] = z[i] = 0.0f;
+      if (k < N) {
+        x[i] = pts[(size_t)k * stride + 0];
+        y[i] = pts[(size_t)k * stride + 1];
+        z[i] = pts[(size_t)k * stride + 2];
+        mn[0] = fminf(mn[0], x[i]), mn[1] = fminf(mn[1], y[i]), mn[2] = fminf(mn[2], z[i]);
+        mx[0] = fmaxf(mx[0], x[i]), mx[1] = fmaxf(mx[1], y[i]), mx[2] = fmaxf(mx[2], z[i]);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      mn[c] = wave_red_f32<false>(mn[c]);
+      mx[c] = wave_red_f32<true>(mx[c]);
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) bbx[wave * 6 + c] = mn[c], bbx[wave * 6 + 3 + c] = mx[c];
+    }
+    for (int i = tid; i < FPSC_CELLS; i += FPSC_THREADS) hist[i] = 0;
+    if (tid < 32) slots[tid] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < FPSC_WAVES; ++w)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) mn[c] = fminf(mn[c], bbx[w * 6 + c]), mx[c] = fmaxf(mx[c], bbx[w * 6 + 3 + c]);
+    float sc[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) sc[c] = mx[c] > mn[c] ? 16.0f * __builtin_amdgcn_rcpf(mx[c] - mn[c]) : 0.0f;  // (cell choice only affects speed)
+#pragma unroll
+    for (int i = 0; i < PTS; ++i) {
+      const int k = tid + i * FPSC_THREADS;
+      code[i] = rnk[i] = 0;
+      if (k < N) {
+        const int cx = min(15, max(0, (int)((x[i] - mn[0]) * sc[0]))), cy = min(15, max(0, (int)((y[i] - mn[1]) * sc[1]))),
+                  cz = min(15, max(0, (int)((z[i] - mn[2]) * sc[2])));
+        code[i] = morton4(cx) | (morton4(cy) << 1) | (morton4(cz) << 2);
+        rnk[i] = atomicAdd(&hist[code[i]], 1u);
+      }
+    }
+    __syncthreads();
+  }
+  {  // exclusive scan of the 4096 cell counts: thread t owns cells 8 t .. 8 t + 7
+    unsigned c8[8], tot = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      c8[e] = hist[tid * 8 + e];
+      tot += c8[e];
+    }
+    unsigned inc = tot;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned t = __shfl_up(inc, o);
+      if (lane >= o) inc += t;
+    }
+    unsigned *wtot = reinterpret_cast<unsigned *>(bbx);  // (the box exchange is over)
+    __syncthreads();
+    if (lane == 63) wtot[wave] = inc;
+    __syncthreads();
+    unsigned base = inc - tot;
+#pragma unroll
+    for (int w = 0; w < FPSC_WAVES; ++w)
+      if (w < wave) base += wtot[w];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      hist[tid * 8 + e] = base;
+      base += c8[e];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < PTS; ++i) {
+    const int k = tid + i * FPSC_THREADS;
+    if (k < N) {
+      const unsigned pos = hist[code[i]] + rnk[i];
+      pmap[pos] = (unsigned short)k;
+      if (k == 0) scal[0] = (int)pos;
+    }
+  }
+  __syncthreads();
+
+  // ---- prologue 2: the points in sorted order; chunk c = positions [64 c, 64 c + 64) belongs to wave c % 8, slot c / 8 --
+  float x[PTS], y[PTS], z[PTS];
+  u64 key[PTS];
+  int kk[PTS];
+  static_for<0, PTS>([&](auto I) {
+    constexpr int i = decltype(I)::value;
+    const int pos = (wave + FPSC_WAVES * i) * 64 + lane;
+    kk[i] = pos < N ? (int)pmap[pos] : -1;
+  });
+  const int pos0 = scal[0];
+  __syncthreads();  // (the map and the histogram are dead: their bytes become the sorted cloud)
+  static_for<0, PTS>([&](auto I) {
+    constexpr int i = decltype(I)::value;
+    const int pos = (wave + FPSC_WAVES * i) * 64 + lane;
+    x[i] = y[i] = z[i] = 0.0f;
+    key[i] = 0;  // a point that may never be picked keeps key == 0 (distance +0, rank 0)
+    if (kk[i] >= 0) {
+      const int k = kk[i];
+      x[i] = pts[(size_t)k * stride + 0];
+      y[i] = pts[(size_t)k * stride + 1];
+      z[i] = pts[(size_t)k * stride + 2];
+      sx[pos] = x[i];
+      sy[pos] = y[i];
+      sz[pos] = z[i];
+      const float mag = mpx_fma(z[i], z[i], mpx_fma(y[i], y[i], x[i] * x[i]));
+      if (!((double)mag <= 1e-3)) {  // (see fps_kernel)
+        // tie order of the reference: smaller (bitrev(k mod 512), k / 512) wins -> larger key wins
+        const unsigned rank = (__brev((unsigned)k & 511u) & 0xFF800000u) | (((unsigned)k >> 9) << 18) | (unsigned)pos;
+        key[i] = pack64(0xFFFFFFFFu - rank, __float_as_uint(1e10f));
+      }
+    }
+  });
+  // chunk records, slot i in lane i: bounding box of the chunk's points, upper bound of their running distances
+  // (an empty or candidate-free chunk: 0, never re-evaluated)
+  float bnx = INF, bny = INF, bnz = INF, bxx = -INF, bxy = -INF, bxz = -INF, cub = 0.0f;
+  __syncthreads();  // sorted cloud visible
+  // lane i < PTS walks ITS chunk's 64 points in LDS: no cross-lane traffic (positions past the end of the cloud are
+  // clamped to its last point: a repeated point changes neither the box nor `any`; a chunk wholly past the end keeps
+  // the inverted box and cub = 0)
+  if (lane < PTS) {
+    const int p0 = (wave + FPSC_WAVES * lane) * 64;
+    if (p0 < N) {
+      bool any = false;
+#pragma unroll 8
+      for (int q = 0; q < 64; ++q) {
+        const int pos = min(p0 + ((q + 5 * lane) & 63), N - 1);  // (staggered: the lanes' chunks are 2 KB apart = one bank)
+        const float px = sx[pos], py = sy[pos], pz = sz[pos];
+        bnx = fminf(bnx, px), bny = fminf(bny, py), bnz = fminf(bnz, pz);
+        bxx = fmaxf(bxx, px), bxy = fmaxf(bxy, py), bxz = fmaxf(bxz, pz);
+        const float mag = mpx_fma(pz, pz, mpx_fma(py, py, px * px));
+        any = any || !((double)mag <= 1e-3);
+      }
+      cub = any ? 1e10f : 0.0f;
+    }
+  }
+
+  int old = 0, pos_old = pos0;
+  for (int j = 1; j < npoint; ++j) {
+    const float x1 = sx[pos_old], y1 = sy[pos_old], z1 = sz[pos_old];
+    if (tid == 0) {
+      out[j - 1] = old;
+      if (nxyz) {
+        nxyz[(size_t)(j - 1) * new_stride + 0] = x1;
+        nxyz[(size_t)(j - 1) * new_stride + 1] = y1;
+        nxyz[(size_t)(j - 1) * new_stride + 2] = z1;
+      }
+    }
+    // smallest / largest squared distance from the pick to chunk `lane`'s box, in a point's own operation order
+    const float ax = bnx - x1, bx_ = x1 - bxx, ay = bny - y1, by_ = y1 - bxy, az = bnz - z1, bz_ = z1 - bxz;
+    const float ex = fmaxf(fmaxf(ax, bx_), 0.0f), ey = fmaxf(fmaxf(ay, by_), 0.0f), ez = fmaxf(fmaxf(az, bz_), 0.0f);
+    const float bound = mpx_fma(ez, ez, mpx_fma(ey, ey, ex * ex));
+    const unsigned tmask = (unsigned)__builtin_amdgcn_ballot_w64(lane < PTS && bound < cub);
+    {  // |p - x1| <= max(x1 - bmin, bmax - x1) per axis
+      const float fx = fmaxf(-ax, -bx_), fy = fmaxf(-ay, -by_), fz = fmaxf(-az, -bz_);
+      const float far = mpx_fma(fz, fz, mpx_fma(fy, fy, fx * fx)) * 1.000001f;
+      cub = fminf(cub, far);  // (an empty chunk's box is inverted: far = +inf, cub stays 0)
+    }
+    static_for<0, PTS>([&](auto I) {
+      constexpr int i = decltype(I)::value;
+      if (tmask & (1u << i)) {  // (wave-uniform)
+        const float dx = x[i] - x1, dy = y[i] - y1, dz = z[i] - z1;
+        const float d = mpx_fma(dz, dz, mpx_fma(dy, dy, dx * dx));
+        float d2;  // min(d, temp[k]) as one v_min_f32 (fminf() adds a canonicalising v_max per call)
+        asm("v_min_f32 %0, %1, %2" : "=v"(d2) : "v"(d), "v"(__uint_as_float((unsigned)(key[i] >> 32))));
+        key[i] = pack64((unsigned)key[i], __float_as_uint(d2));
+      }
+    });
+    u64 best;
+    {  // this lane's largest key: two interleaved chains of v_max_f64
+      u64 b0 = key[0], b1 = key[1];
+      static_for<1, (PTS + 1) / 2>([&](auto I) {
+        constexpr int i = 2 * decltype(I)::value;
+        b0 = umax64(b0, key[i]);
+        if constexpr (i + 1 < PTS) b1 = umax64(b1, key[i + 1]);
+      });
+      best = umax64(b0, b1);
+    }
+    best = wave_max64(best);
+    u64 *slot = slots + (j & 1) * 16;
+    if (lane == 0) slot[wave] = best;
+    __syncthreads();
+    u64 m = row_max64(slot[lane & 15]);
+    m = readlane64(m, 0);
+    if (m == 0) {
+      old = 0;  // nothing was a candidate: the reference's besti stays 0
+      pos_old = pos0;
+    } else {
+      const unsigned rank = 0xFFFFFFFFu - (unsigned)m;
+      old = (int)((((rank >> 18) & 0x1Fu) << 9) | __brev(rank & 0xFF800000u));
+      pos_old = (int)(rank & 0x1FFFu);
+    }
+  }
+  if (tid == 0 && npoint > 0) {
+    out[npoint - 1] = old;
+    if (nxyz) {
+      nxyz[(size_t)(npoint - 1) * new_stride + 0] = sx[pos_old];
+      nxyz[(size_t)(npoint - 1) * new_stride + 1] = sy[pos_old];
+      nxyz[(size_t)(npoint - 1) * new_stride + 2] = sz[pos_old];
+    }
+  }
+}
+
 constexpr int FPS_MAX_N = 8192;                         // 512 threads x 16 points (include/mpinets_hip.h says the same)
 constexpr int FPS_MAX_LDS = 256 + 3 * FPS_MAX_N * 4;    // the cloud copy of the largest supported launch
 
@@ -282,6 +592,27 @@ MPX_EXPORT int mpx_fps(const float *xyz, int B, int N, int stride, int npoint, i
       default: FPS_WAVE(8); break;
     }
 #undef FPS_WAVE
+    MPX_LAUNCH_CHECK("mpx_fps");
+  }
+  static const int use_cull = getenv("MPX_FPS_CULL") ? atoi(getenv("MPX_FPS_CULL")) : 1;
+  if (use_cull && N > 512) {  // (log2bs == 9 here: the key layout of fps_cull_kernel assumes it)
+    const size_t lds_c = fpsc_lds_bytes(N);
+    dim3 gc(B), tc(FPSC_THREADS);
+#define FPS_CULL(P)                                                                                              \
+  do {                                                                                                           \
+    if (lds_c > 64 * 1024) MPX_LDS_LIMIT_ONCE(fps_cull_kernel<P>, fpsc_lds_bytes(FPS_MAX_N), "mpx_fps");          \
+    hipLaunchKernelGGL(fps_cull_kernel<P>, gc, tc, lds_c, mpx_s(stream), xyz, N, stride, npoint, idx, new_xyz,   \
+                       new_stride);                                                                              \
+  } while (0)
+    const int pts_c = (N + FPSC_THREADS - 1) / FPSC_THREADS;
+    if (pts_c <= 2) FPS_CULL(2);
+    else if (pts_c <= 4) FPS_CULL(4);
+    else if (pts_c <= 6) FPS_CULL(6);
+    else if (pts_c <= 8) FPS_CULL(8);
+    else if (pts_c <= 10) FPS_CULL(10);
+    else if (pts_c <= 13) FPS_CULL(13);
+    else FPS_CULL(16);
+#undef FPS_CULL
     MPX_LAUNCH_CHECK("mpx_fps");
   }
   int block = ((N + 63) / 64) * 64;

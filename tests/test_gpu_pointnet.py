@@ -21,7 +21,8 @@ def clouds(B, N, seed, stride=3):
 
 
 @pytest.mark.parametrize("B,N,npoint,stride", [(3, 6272, 512, 4), (4, 512, 128, 3), (2, 1000, 64, 3),
-                                               (2, 63, 17, 3), (1, 8192, 300, 4), (2, 2500, 100, 3)])
+                                               (2, 63, 17, 3), (1, 8192, 300, 4), (2, 2500, 100, 3),
+                                               (2, 513, 40, 3), (2, 4097, 77, 3), (1, 7000, 7000, 3)])
 def test_fps_bit_exact(oracle, B, N, npoint, stride):
     from mpinets_amd.pointnet2 import furthest_point_sample
 
@@ -52,6 +53,27 @@ def test_fps_ties_duplicates_and_skipped_points(oracle):
     z[1] = 0.01
     np.testing.assert_array_equal(furthest_point_sample(T(z), 9).cpu().numpy(), oracle.fps(z, 9))
     assert (oracle.fps(z, 9) == 0).all()
+
+
+def test_fps_degenerate_clouds_through_the_culled_kernel(oracle):
+    """Clouds whose bounding box has no extent along one, two or all axes (the Morton cells of the culled kernel
+    collapse), clouds of a few distinct points repeated thousands of times, and one far outlier."""
+    from mpinets_amd.pointnet2 import furthest_point_sample
+
+    rng = np.random.default_rng(12)
+    N = 3000
+    plane = clouds(1, N, 3)[0]
+    plane[:, 2] = 0.25
+    line = np.zeros((N, 3), np.float32)
+    line[:, 0] = rng.uniform(-1, 1, N)
+    line[:, 1] = 0.5
+    same = np.full((N, 3), 0.3, np.float32)
+    few = clouds(1, 7, 4)[0][rng.integers(0, 7, N)]
+    outlier = clouds(1, N, 5)[0] * 0.05 + 0.5
+    outlier[1234] = [90.0, -80.0, 70.0]
+    x = np.stack([plane, line, same, few, outlier])
+    idx = furthest_point_sample(T(x), 200)
+    np.testing.assert_array_equal(idx.cpu().numpy(), oracle.fps(x, 200))
 
 
 def test_fps_on_real_slab(oracle):

@@ -1,4 +1,4 @@
-"""FPS timing at the model's sizes (development aid). usage: fps_timing.py [B]"""
+"""FPS timing at the model's sizes (development aid). usage: fps_timing.py [B] [npoint]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "motion-policy-networks_amd")]
@@ -6,17 +6,18 @@ import torch
 from mpinets_amd import _lib
 from mpinets_amd.scenes import make_problem_batch
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+NP = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 dev = torch.device("cuda:0")
 prob = make_problem_batch(B, seed=0, device=dev, scene_pool=64, device_clouds=True)
 xyz = prob["xyz"]
-idx = torch.empty((B, 512), dtype=torch.int32, device=dev)
-nx = torch.empty((B, 512, 3), device=dev)
+idx = torch.empty((B, NP), dtype=torch.int32, device=dev)
+nx = torch.empty((B, NP, 3), device=dev)
 def run():
-    _lib.call("mpx_fps", _lib.ptr(xyz), B, 6272, 4, 512, _lib.ptr(idx), _lib.ptr(nx), 3)
+    _lib.call("mpx_fps", _lib.ptr(xyz), B, 6272, 4, NP, _lib.ptr(idx), _lib.ptr(nx), 3)
 for _ in range(2): run()
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(5): run()
 e1.record(); torch.cuda.synchronize()
-print(f"MPX_FPS_BLOCK={os.environ.get('MPX_FPS_BLOCK','512')}: fps 6272->512, B={B}: {e0.elapsed_time(e1)/5:.3f} ms  checksum {int(idx.sum())}")
+print(f"MPX_FPS_CULL={os.environ.get('MPX_FPS_CULL','1')}: fps 6272->{NP}, B={B}: {e0.elapsed_time(e1)/5:.3f} ms  checksum {int(idx.sum())}")
