@@ -327,6 +327,31 @@ __device__ __forceinline__ void static_for(F &&f) {
   }
 }
 
+// max of an unsigned over the wave as six in-place DPP-fused v_max_u32 (row steps, then row_bcast:15 / :31 carry the row
+// results upwards: lane 63 holds the maximum) + one v_readlane -- against 12 DPP moves, 7 v_max_f64, 8 v_readlane and 8
+// moves for the 64-bit key maximum of wave_max64.  (Inline asm: the two wait states a DPP read needs after the VALU
+// write of its source are written out.)
+__device__ __forceinline__ unsigned wave_max_u32_dpp(unsigned v) {
+  asm volatile(
+      "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "s_nop 1"
+      : "+v"(v));
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+// arg-max of 64-bit keys {low: tie word, high: bits of a non-negative float} over the wave, in two 32-bit stages: the
+// largest high word, then the largest low word among the lanes that hold it (the same total order as the 64-bit max)
+__device__ __forceinline__ u64 wave_max64_staged(u64 k) {
+  const unsigned hi = (unsigned)(k >> 32), lo = (unsigned)k;
+  const unsigned mhi = wave_max_u32_dpp(hi);
+  const unsigned mlo = wave_max_u32_dpp(hi == mhi ? lo : 0u);
+  return pack64(mlo, mhi);
+}
+
 constexpr int FPSC_CELLS = 4096, FPSC_THREADS = 512, FPSC_WAVES = 8;
 // dynamic LDS: [0,256) reduction slots, [256,512) scalars (position of point 0, cloud bounding box exchange), then the
 // cloud in sorted order sx | sy | sz (3 N floats); the prologue's histogram (16 KB) and position -> index map (2 N bytes)
@@ -540,7 +565,7 @@ __global__ void __launch_bounds__(FPSC_THREADS) __attribute__((amdgpu_waves_per_
       });
       best = umax64(b0, b1);
     }
-    best = wave_max64(best);
+    best = wave_max64_staged(best);
     u64 *slot = slots + (j & 1) * 16;
     if (lane == 0) slot[wave] = best;
     __syncthreads();
