@@ -4,4 +4,4 @@ tag=$1; ctr=$2; shift 2
 REPO=$(pwd); mkdir -p gpurun_out
 ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/pmc_$tag && timeout 600 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/pmc_$tag -o run -- python $REPO/"$@" > $REPO/gpurun_out/pmc_${tag}.log 2>&1
   for f in $(find /tmp/pmc_$tag -name "*counter_collection.csv"); do python $REPO/tools/pmc_summary.py $f > $REPO/gpurun_out/pmc_${tag}.csv; done )
-grep -E "bf16_kernel|packed_kernel|resident_kernel|planes_kernel" gpurun_out/pmc_${tag}.csv | cut -c1-40,90- | head -40
+grep -E "bf16_kernel|packed_kernel|resident_kernel|pairs_kernel|fps_" gpurun_out/pmc_${tag}.csv | cut -c1-40,90- | head -40
