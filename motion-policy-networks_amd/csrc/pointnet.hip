@@ -754,6 +754,61 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// ---- ball query of a SMALL cloud (N <= 512: the second set-abstraction module, 128 queries x 512 points, many hits) ----
+// The kernel above gives a query to a lane, which appends its hits with scattered 4-byte stores: with ~60 hits per row
+// that is store-issue bound (0.56 ms per step at 8192 environments).  Here a WAVE owns a query at a time and the cloud
+// sits in its registers (lane l holds points l, l + 64, ...: 64 consecutive indices per register slot): a slot is one
+// distance pass + one ballot; a hit's output position is the running count plus the hits in the lanes below it
+// (v_mbcnt), so the row is written in index order with contiguous stores, and the padding by the same wave.
+// Same arithmetic (fma chain of centre - point) and the same idx / cnt as ball_query_kernel.
+template <int PTS>
+__global__ void __launch_bounds__(256)
+    ball_query_wave_kernel(const float *__restrict__ new_xyz, int new_stride, const float *__restrict__ xyz, int stride,
+                           int N, int npoint, float radius2, int nsample, int32_t *__restrict__ idx,
+                           int32_t *__restrict__ cnt_out, int qpw) {
+  const int b = blockIdx.y, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j0 = (blockIdx.x * 4 + wave) * qpw;
+  if (j0 >= npoint) return;
+  const float *pts = xyz + (size_t)b * N * stride;
+  float px[PTS], py[PTS], pz[PTS];
+#pragma unroll
+  for (int i = 0; i < PTS; ++i) {
+    const int k = lane + 64 * i;
+    px[i] = py[i] = pz[i] = 0.0f;
+    if (k < N) {
+      px[i] = pts[(size_t)k * stride + 0];
+      py[i] = pts[(size_t)k * stride + 1];
+      pz[i] = pts[(size_t)k * stride + 2];
+    }
+  }
+  const int j1 = min(j0 + qpw, npoint);
+  for (int j = j0; j < j1; ++j) {  // (wave-uniform)
+    const float *c = new_xyz + ((size_t)b * npoint + j) * new_stride;
+    const float cx = c[0], cy = c[1], cz = c[2];
+    int32_t *row = idx + ((size_t)b * npoint + j) * nsample;
+    int base = 0, first = 0;
+#pragma unroll
+    for (int i = 0; i < PTS; ++i) {
+      if (64 * i < N && base < nsample) {  // (uniform)
+        const float dx = cx - px[i], dy = cy - py[i], dz = cz - pz[i];
+        const float d2 = mpx_fma(dz, dz, mpx_fma(dy, dy, dx * dx));
+        const bool hit = lane + 64 * i < N && d2 < radius2;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
+        if (m) {
+          const int pos = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+          if (hit && pos < nsample) row[pos] = lane + 64 * i;
+          if (base == 0) first = 64 * i + (int)__builtin_ctzll(m);
+          base += (int)__builtin_popcountll(m);
+        }
+      }
+    }
+    const int cnt = base < nsample ? base : nsample;
+    for (int l = cnt + lane; l < nsample; l += 64) row[l] = first;  // padding: the first hit (zeros when there is none)
+    if (cnt_out && lane == 0) cnt_out[(size_t)b * npoint + j] = cnt;
+  }
+}
+
 // ---- ball query through a column grid (exact; the large-cloud / small-radius case) ---------------------------
 // The brute-force kernel above tests every (query, point) pair: 512 x 6272 for the first set-abstraction module,
 // of which ~10 per query are hits (radius 5 cm).  Here one workgroup owns one environment: the cloud is bucketed
@@ -1072,6 +1127,19 @@ MPX_EXPORT int mpx_ball_query(const float *new_xyz, int new_stride, const float 
                          stride, N, npoint, r2, inv_h, nsample, idx, cnt);
       MPX_LAUNCH_CHECK("mpx_ball_query");
     }
+  }
+  static const int use_wave_bq = getenv("MPX_BQ_WAVE") ? atoi(getenv("MPX_BQ_WAVE")) : 1;
+  if (use_wave_bq && N >= 1 && N <= 512) {  // small cloud: a wave per query, cloud in registers, rows written in order
+    const int qpw = npoint >= 64 ? 16 : 4;  // queries per wave (the cloud load is amortised over them)
+    dim3 gw(cdiv(npoint, 4 * qpw), B), tw(256);
+#define BQ_WAVE(P)                                                                                                   \
+  hipLaunchKernelGGL(ball_query_wave_kernel<P>, gw, tw, 0, mpx_s(stream), new_xyz, new_stride, xyz, stride, N, npoint, r2, \
+                     nsample, idx, cnt, qpw)
+    if (N <= 128) BQ_WAVE(2);
+    else if (N <= 256) BQ_WAVE(4);
+    else BQ_WAVE(8);
+#undef BQ_WAVE
+    MPX_LAUNCH_CHECK("mpx_ball_query");
   }
   dim3 g(cdiv(npoint, 256), B), t(256);
   const bool al64 = stride == 4 && ((uintptr_t)xyz & 63) == 0 && N % 4 == 0;

@@ -88,7 +88,9 @@ def test_fps_on_real_slab(oracle):
 
 
 @pytest.mark.parametrize("B,N,npoint,radius,nsample,stride", [(2, 6272, 512, 0.05, 128, 4), (3, 512, 128, 0.3, 128, 3),
-                                                              (2, 700, 50, 0.4, 32, 3), (1, 100, 10, 5.0, 64, 3)])
+                                                              (2, 700, 50, 0.4, 32, 3), (1, 100, 10, 5.0, 64, 3),
+                                                              (2, 300, 70, 0.5, 16, 4), (1, 512, 129, 0.9, 128, 3),
+                                                              (3, 65, 65, 0.2, 128, 3)])
 def test_ball_query_bit_exact(oracle, B, N, npoint, radius, nsample, stride):
     from mpinets_amd.pointnet2 import ball_query
 
