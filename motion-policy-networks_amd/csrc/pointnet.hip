@@ -824,7 +824,7 @@ constexpr int BQG = 48;            // columns per side
 #define MPX_BQG_THREADS 1024
 #endif
 constexpr int BQG_THREADS = MPX_BQG_THREADS;  // 16 waves: the query walk is LDS-latency bound, two lanes share a query
-constexpr int BQ_HC = 48;          // hits of a query kept in LDS (the rest of a long row goes through its global row)
+constexpr int BQ_HC = 40;          // hits of a query kept in LDS (the rest of a long row goes through its global row)
 
 __device__ __forceinline__ int bq_cell(float v, float origin, float inv_h) {
   const int c = (int)floorf((v - origin) * inv_h);
@@ -872,11 +872,10 @@ __global__ void __launch_bounds__(BQG_THREADS)
                            int N, int npoint, float radius2, float inv_h, int nsample, int32_t *__restrict__ idx,
                            int32_t *__restrict__ cnt_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float *sx = reinterpret_cast<float *>(smem), *sy = sx + N, *sz = sy + N;
-  int *ccount = reinterpret_cast<int *>(sz + N);                                    // [G*G] counts, then cursors
+  float4 *sp = reinterpret_cast<float4 *>(smem);                                    // [N] (x, y, z, point id) by column
+  int *ccount = reinterpret_cast<int *>(sp + N);                                    // [G*G] counts, then cursors
   unsigned short *cstart = reinterpret_cast<unsigned short *>(ccount + BQG * BQG);  // [G*G + 1]
-  unsigned short *order = cstart + BQG * BQG + 2;                                   // [N] point ids by column
-  unsigned short *qcnt = order + ((N + 1) & ~1);                                    // [npoint] hits per query
+  unsigned short *qcnt = cstart + BQG * BQG + 2;                                    // [npoint] hits per query
   unsigned short *ovf = qcnt + ((npoint + 1) & ~1);                                 // [npoint] overflowing queries
   unsigned short *hbuf = ovf + ((npoint + 1) & ~1);                                 // [npoint][BQ_HC] first hits of a row
   int *cnt_s = reinterpret_cast<int *>(hbuf + (size_t)npoint * BQ_HC);              // [npoint] hits found so far (atomic)
@@ -912,9 +911,10 @@ __global__ void __launch_bounds__(BQG_THREADS)
 #pragma unroll
   for (int w = 1; w < BQG_THREADS / 64; ++w) ox = fminf(ox, red[2 * w]), oy = fminf(oy, red[2 * w + 1]);
 
-  // ---- counting sort by column: LDS receives the coordinates IN BUCKET ORDER (sx/sy/sz[e]) next to the point ids
-  // (order[e]), so a candidate costs three independent LDS reads instead of an id read followed by three
-  // dependent ones
+  // ---- counting sort by column: LDS receives (x, y, z, point id) IN BUCKET ORDER as one 16-byte record, so a candidate
+  // costs ONE ds_read_b128.  (The walk below reads per-lane random bucket slots: as three ds_read_b32 + a 16-bit id read
+  // it serialised on LDS bank conflicts -- 67-96 k of the kernel's 165 k cycles per environment by s_memtime, and not an
+  // imbalance: the same candidates dealt evenly over the threads took as long.)
   int cell[PT];
 #pragma unroll
   for (int i = 0; i < PT; ++i) {
@@ -958,8 +958,7 @@ __global__ void __launch_bounds__(BQG_THREADS)
     const int k = tid + i * BQG_THREADS;
     if (k < N) {
       const int at = atomicAdd(&ccount[cell[i]], 1);
-      order[at] = (unsigned short)k;
-      sx[at] = px[i], sy[at] = py[i], sz[at] = pz[i];
+      sp[at] = make_float4(px[i], py[i], pz[i], __int_as_float(k));
     }
   }
   __syncthreads();
@@ -992,18 +991,22 @@ __global__ void __launch_bounds__(BQG_THREADS)
       int e = e0;
       for (; e + 4 <= e1; e += 4) {  // four candidates in flight
         float d2[4];
+        int kk[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const float dx = cx - sx[e + u], dy = cy - sy[e + u], dz = cz - sz[e + u];
+          const float4 p = sp[e + u];
+          const float dx = cx - p.x, dy = cy - p.y, dz = cz - p.z;
           d2[u] = mpx_fma(dz, dz, mpx_fma(dy, dy, dx * dx));
+          kk[u] = __float_as_int(p.w);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-          if (d2[u] < radius2) hit(order[e + u]);
+          if (d2[u] < radius2) hit(kk[u]);
       }
       for (; e < e1; ++e) {
-        const float dx = cx - sx[e], dy = cy - sy[e], dz = cz - sz[e];
-        if (mpx_fma(dz, dz, mpx_fma(dy, dy, dx * dx)) < radius2) hit(order[e]);
+        const float4 p = sp[e];
+        const float dx = cx - p.x, dy = cy - p.y, dz = cz - p.z;
+        if (mpx_fma(dz, dz, mpx_fma(dy, dy, dx * dx)) < radius2) hit(__float_as_int(p.w));
       }
     }
   }
@@ -1117,9 +1120,8 @@ MPX_EXPORT int mpx_ball_query(const float *new_xyz, int new_stride, const float 
   static const int use_grid = getenv("MPX_BQ_GRID") ? atoi(getenv("MPX_BQ_GRID")) : 1;
   if (use_grid && N >= 2048 && N <= 8192 && nsample <= 128 && nsample > BQ_HC && npoint <= 4096 && radius > 0.0f &&
       radius * BQG < 4.0f) {  // columns of side ~radius must still resolve the scene (48 x radius < 4 m)
-    const size_t lds = (size_t)3 * N * 4 + (size_t)BQG * BQG * 4 + (size_t)(BQG * BQG + 2) * 2 +
-                       (size_t)((N + 1) & ~1) * 2 + (size_t)((npoint + 1) & ~1) * 2 * 2 + (size_t)npoint * BQ_HC * 2 +
-                       (size_t)npoint * 4;
+    const size_t lds = (size_t)4 * N * 4 + (size_t)BQG * BQG * 4 + (size_t)(BQG * BQG + 2) * 2 +
+                       (size_t)((npoint + 1) & ~1) * 2 * 2 + (size_t)npoint * BQ_HC * 2 + (size_t)npoint * 4;
     if (lds <= 158 * 1024) {
       MPX_LDS_LIMIT_ONCE(ball_query_grid_kernel, 158 * 1024, "mpx_ball_query");
       const float inv_h = 1.0f / (radius * 1.0001f);
