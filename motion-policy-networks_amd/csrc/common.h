@@ -59,6 +59,23 @@ static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 __device__ __forceinline__ float mpx_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 
+// THE squared distance of the index path (FPS, ball query; restated as sqdist() in oracle/mpn_oracle.c -- one definition
+// on each side).  pointnet2_ops writes `(x2-x1)*(x2-x1) + (y2-y1)*(y2-y1) + (z2-z1)*(z2-z1)` (sampling_gpu.cu,
+// ball_query_gpu.cu) and nvcc contracts it (-fmad=true).  LLVM's DAG combiner -- NVVM is built on it -- fuses the LEFT
+// multiply of each add first: (a*a + b*b) -> fma(a,a, b*b), then (. + c*c) -> fma(c,c, .), i.e. the product that is
+// rounded on its own is dy^2 (profiles/r03_contraction_evidence.md: the x86 and gfx950 disassembly of exactly that
+// expression under -ffp-contract=fast).  -DMPX_SQDIST_XFIRST builds the order rounds 1-2 assumed (dx^2 rounded on
+// its own) for A/B runs; the two orders pick a different FPS sequence on ~0.2 % of 6272-point clouds
+// (tests/test_oracle_pointnet.py::test_contraction_order_ab).  Both forms are monotone in |dx|, |dy|, |dz| (the culled FPS
+// kernel's box bound relies on that).
+__device__ __forceinline__ float mpx_sqdist(float dx, float dy, float dz) {
+#ifdef MPX_SQDIST_XFIRST
+  return mpx_fma(dz, dz, mpx_fma(dy, dy, dx * dx));
+#else
+  return mpx_fma(dz, dz, mpx_fma(dx, dx, dy * dy));
+#endif
+}
+
 // Cody-Waite by pi/2 + fixed polynomials; |x| up to ~1e3 rad is far more than joint angles need.
 __device__ __forceinline__ void mpx_sincos(float x, float &s, float &c) {
   const float TWO_OVER_PI = 0.63661977236758134308f;

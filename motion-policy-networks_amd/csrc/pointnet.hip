@@ -10,7 +10,7 @@
 //         s = bs/2..1) does: the smallest BIT-REVERSED thread id wins, then the smallest k;
 //   ball  first `nsample` indices in ascending order with d2 < r^2, all slots pre-filled with
 //         the first hit, zeros when nothing is in range.
-// Distances are fma(dz,dz,fma(dy,dy,dx*dx)), the contraction nvcc applies to the CUDA source.
+// Distances are mpx_sqdist() (common.h): fma(dz,dz,fma(dx,dx,dy*dy)), upstream's expression as LLVM / NVVM contracts it.
 //
 // CDNA4 design: one workgroup per environment; the whole cloud lives in registers
 // (x,y,z,running distance: PTS points per lane) with an LDS copy used only to broadcast the
@@ -108,7 +108,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PTS <
       sx[k] = x[i];
       sy[k] = y[i];
       sz[k] = z[i];
-      const float mag = mpx_fma(z[i], z[i], mpx_fma(y[i], y[i], x[i] * x[i]));
+      const float mag = mpx_sqdist(x[i], y[i], z[i]);
       // upstream compares the float magnitude with the DOUBLE literal 1e-3 (`if (mag <= 1e-3) continue;`): a point with
       // mag == 1e-3f (= 0.0010000000475 > 1e-3) is kept
       if (!((double)mag <= 1e-3)) {
@@ -137,7 +137,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(PTS <
 #pragma unroll
     for (int i = 0; i < PTS; ++i) {
       const float dx = x[i] - x1, dy = y[i] - y1, dz = z[i] - z1;
-      const float d = mpx_fma(dz, dz, mpx_fma(dy, dy, dx * dx));
+      const float d = mpx_sqdist(dx, dy, dz);
       float d2;  // min(d, temp[k]) as one v_min_f32 (fminf() adds a canonicalising v_max per call)
       asm("v_min_f32 %0, %1, %2" : "=v"(d2) : "v"(d), "v"(__uint_as_float((unsigned)(key[i] >> 32))));
       // a point that is not a candidate has rank 0 and distance +0, so its whole key is 0
@@ -191,7 +191,7 @@ __global__ void __launch_bounds__(64)
       x[i] = pts[(size_t)k * stride + 0];
       y[i] = pts[(size_t)k * stride + 1];
       z[i] = pts[(size_t)k * stride + 2];
-      const float mag = mpx_fma(z[i], z[i], mpx_fma(y[i], y[i], x[i] * x[i]));
+      const float mag = mpx_sqdist(x[i], y[i], z[i]);
       if (!((double)mag <= 1e-3)) {
         const unsigned rank = (__brev((unsigned)k & bsmask) & 0xFFFF0000u) | ((unsigned)k >> log2bs);
         key[i] = pack64(0xFFFFFFFFu - rank, __float_as_uint(1e10f));
@@ -228,7 +228,7 @@ __global__ void __launch_bounds__(64)
 #pragma unroll
     for (int i = 0; i < PTS; ++i) {
       const float dx = x[i] - x1, dy = y[i] - y1, dz = z[i] - z1;
-      const float d = mpx_fma(dz, dz, mpx_fma(dy, dy, dx * dx));
+      const float d = mpx_sqdist(dx, dy, dz);
       float d2;
       asm("v_min_f32 %0, %1, %2" : "=v"(d2) : "v"(d), "v"(__uint_as_float((unsigned)(key[i] >> 32))));
       key[i] = pack64((unsigned)key[i], __float_as_uint(d2));
@@ -492,7 +492,7 @@ __global__ void __launch_bounds__(FPSC_THREADS) __attribute__((amdgpu_waves_per_
       sx[pos] = x[i];
       sy[pos] = y[i];
       sz[pos] = z[i];
-      const float mag = mpx_fma(z[i], z[i], mpx_fma(y[i], y[i], x[i] * x[i]));
+      const float mag = mpx_sqdist(x[i], y[i], z[i]);
       if (!((double)mag <= 1e-3)) {  // (see fps_kernel)
         // tie order of the reference: smaller (bitrev(k mod 512), k / 512) wins -> larger key wins
         const unsigned rank = (__brev((unsigned)k & 511u) & 0xFF800000u) | (((unsigned)k >> 9) << 18) | (unsigned)pos;
@@ -517,7 +517,7 @@ __global__ void __launch_bounds__(FPSC_THREADS) __attribute__((amdgpu_waves_per_
         const float px = sx[pos], py = sy[pos], pz = sz[pos];
         bnx = fminf(bnx, px), bny = fminf(bny, py), bnz = fminf(bnz, pz);
         bxx = fmaxf(bxx, px), bxy = fmaxf(bxy, py), bxz = fmaxf(bxz, pz);
-        const float mag = mpx_fma(pz, pz, mpx_fma(py, py, px * px));
+        const float mag = mpx_sqdist(px, py, pz);
         any = any || !((double)mag <= 1e-3);
       }
       cub = any ? 1e10f : 0.0f;
@@ -538,18 +538,18 @@ __global__ void __launch_bounds__(FPSC_THREADS) __attribute__((amdgpu_waves_per_
     // smallest / largest squared distance from the pick to chunk `lane`'s box, in a point's own operation order
     const float ax = bnx - x1, bx_ = x1 - bxx, ay = bny - y1, by_ = y1 - bxy, az = bnz - z1, bz_ = z1 - bxz;
     const float ex = fmaxf(fmaxf(ax, bx_), 0.0f), ey = fmaxf(fmaxf(ay, by_), 0.0f), ez = fmaxf(fmaxf(az, bz_), 0.0f);
-    const float bound = mpx_fma(ez, ez, mpx_fma(ey, ey, ex * ex));
+    const float bound = mpx_sqdist(ex, ey, ez);
     const unsigned tmask = (unsigned)__builtin_amdgcn_ballot_w64(lane < PTS && bound < cub);
     {  // |p - x1| <= max(x1 - bmin, bmax - x1) per axis
       const float fx = fmaxf(-ax, -bx_), fy = fmaxf(-ay, -by_), fz = fmaxf(-az, -bz_);
-      const float far = mpx_fma(fz, fz, mpx_fma(fy, fy, fx * fx)) * 1.000001f;
+      const float far = mpx_sqdist(fx, fy, fz) * 1.000001f;
       cub = fminf(cub, far);  // (an empty chunk's box is inverted: far = +inf, cub stays 0)
     }
     static_for<0, PTS>([&](auto I) {
       constexpr int i = decltype(I)::value;
       if (tmask & (1u << i)) {  // (wave-uniform)
         const float dx = x[i] - x1, dy = y[i] - y1, dz = z[i] - z1;
-        const float d = mpx_fma(dz, dz, mpx_fma(dy, dy, dx * dx));
+        const float d = mpx_sqdist(dx, dy, dz);
         float d2;  // min(d, temp[k]) as one v_min_f32 (fminf() adds a canonicalising v_max per call)
         asm("v_min_f32 %0, %1, %2" : "=v"(d2) : "v"(d), "v"(__uint_as_float((unsigned)(key[i] >> 32))));
         key[i] = pack64((unsigned)key[i], __float_as_uint(d2));
@@ -700,7 +700,7 @@ __global__ void __launch_bounds__(256)
   int first = 0;
   auto test_point = [&](int k, float px, float py, float pz) {
     const float dx = cx - px, dy = cy - py, dz = cz - pz;
-    const float d2 = mpx_fma(dz, dz, mpx_fma(dy, dy, dx * dx));
+    const float d2 = mpx_sqdist(dx, dy, dz);
     if (d2 < radius2 && cnt < nsample) {
       if (cnt == 0) first = k;
       out[cnt] = k;
@@ -760,7 +760,7 @@ __global__ void __launch_bounds__(256)
 // sits in its registers (lane l holds points l, l + 64, ...: 64 consecutive indices per register slot): a slot is one
 // distance pass + one ballot; a hit's output position is the running count plus the hits in the lanes below it
 // (v_mbcnt), so the row is written in index order with contiguous stores, and the padding by the same wave.
-// Same arithmetic (fma chain of centre - point) and the same idx / cnt as ball_query_kernel.
+// Same arithmetic (mpx_sqdist of centre - point) and the same idx / cnt as ball_query_kernel.
 template <int PTS>
 __global__ void __launch_bounds__(256)
     ball_query_wave_kernel(const float *__restrict__ new_xyz, int new_stride, const float *__restrict__ xyz, int stride,
@@ -792,7 +792,7 @@ __global__ void __launch_bounds__(256)
     for (int i = 0; i < PTS; ++i) {
       if (64 * i < N && base < nsample) {  // (uniform)
         const float dx = cx - px[i], dy = cy - py[i], dz = cz - pz[i];
-        const float d2 = mpx_fma(dz, dz, mpx_fma(dy, dy, dx * dx));
+        const float d2 = mpx_sqdist(dx, dy, dz);
         const bool hit = lane + 64 * i < N && d2 < radius2;
         const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
         if (m) {
@@ -996,7 +996,7 @@ __global__ void __launch_bounds__(BQG_THREADS)
         for (int u = 0; u < 4; ++u) {
           const float4 p = sp[e + u];
           const float dx = cx - p.x, dy = cy - p.y, dz = cz - p.z;
-          d2[u] = mpx_fma(dz, dz, mpx_fma(dy, dy, dx * dx));
+          d2[u] = mpx_sqdist(dx, dy, dz);
           kk[u] = __float_as_int(p.w);
         }
 #pragma unroll
@@ -1006,7 +1006,7 @@ __global__ void __launch_bounds__(BQG_THREADS)
       for (; e < e1; ++e) {
         const float4 p = sp[e];
         const float dx = cx - p.x, dy = cy - p.y, dz = cz - p.z;
-        if (mpx_fma(dz, dz, mpx_fma(dy, dy, dx * dx)) < radius2) hit(__float_as_int(p.w));
+        if (mpx_sqdist(dx, dy, dz) < radius2) hit(__float_as_int(p.w));
       }
     }
   }
@@ -1032,7 +1032,7 @@ __global__ void __launch_bounds__(BQG_THREADS)
       bool hit = false;
       if (k < N) {  // (index order: from global memory -- LDS holds the cloud in bucket order)
         const float dx = cx - pts[(size_t)k * stride], dy = cy - pts[(size_t)k * stride + 1], dz = cz - pts[(size_t)k * stride + 2];
-        hit = mpx_fma(dz, dz, mpx_fma(dy, dy, dx * dx)) < radius2;
+        hit = mpx_sqdist(dx, dy, dz) < radius2;
       }
       const unsigned long long m = __ballot(hit);
       const int pos = have + __popcll(m & ((1ull << lane) - 1ull));

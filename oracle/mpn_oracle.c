@@ -332,10 +332,23 @@ ORC_API int orc_opt_n_threads(int work_size) {
   return p;
 }
 
+/* THE squared distance of the index path (one definition; the kernels' twin is mpx_sqdist() in csrc/common.h).
+ * Upstream writes `(x2-x1)*(x2-x1) + (y2-y1)*(y2-y1) + (z2-z1)*(z2-z1)` (sampling_gpu.cu, ball_query_gpu.cu) and
+ * `(x2*x2) + (y2*y2) + (z2*z2)`, and nvcc contracts them (-fmad=true).  LLVM's DAG combiner (NVVM is built on it) fuses
+ * the LEFT multiply of each add first: (a*a + b*b) -> fma(a,a, b*b), then (. + c*c) -> fma(c,c, .): the product rounded
+ * on its own is dy^2.  Evidence: profiles/r03_contraction_evidence.md (x86 and gfx950 disassembly of exactly that
+ * expression under -ffp-contract=fast).  Order 1 is what rounds 1-2 assumed (dx^2 rounded on its own); it is kept so
+ * that tests/test_oracle_pointnet.py can COUNT how many clouds change between the two (the residual risk, since nvcc
+ * itself cannot be run here).  Not thread-safe by design: a test sets it, runs, and sets it back.                 */
+static int g_sqdist_order = 0;
+ORC_API void orc_set_sqdist_order(int order) { g_sqdist_order = order; }
+ORC_API int orc_get_sqdist_order(void) { return g_sqdist_order; }
+static float sqdist3(float dx, float dy, float dz) {
+  if (g_sqdist_order == 1) return fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+  return fmaf(dz, dz, fmaf(dx, dx, dy * dy));
+}
 static float sqdist(const float *a, const float *b) {
-  float dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
-  /* nvcc contracts a*a + b*b + c*c into fma(c,c,fma(b,b,a*a)) by default (-fmad=true) */
-  return fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+  return sqdist3(a[0] - b[0], a[1] - b[1], a[2] - b[2]);
 }
 
 /* furthest_point_sampling_kernel: start at index 0; temp = 1e10; points with |p|^2 <= 1e-3
@@ -361,7 +374,7 @@ ORC_API void orc_fps(const float *xyz, int B, int N, int stride, int npoint, int
         float best = -1.0f;
         for (int k = t; k < N; k += bs) {
           const float *p2 = pts + (size_t)k * stride;
-          float mag = fmaf(p2[2], p2[2], fmaf(p2[1], p2[1], p2[0] * p2[0]));
+          float mag = sqdist3(p2[0], p2[1], p2[2]);
           if ((double)mag <= 1e-3) continue; /* upstream: float mag vs the double literal 1e-3 */
           float d = sqdist(p2, p1);
           float d2 = fminf(d, temp[k]);
@@ -412,7 +425,7 @@ ORC_API void orc_ball_query(const float *new_xyz, const float *xyz, int B, int N
       for (int k = 0; k < N && cnt < nsample; ++k) {
         const float *p = xyz + ((size_t)b * N + k) * stride;
         float dx = c[0] - p[0], dy = c[1] - p[1], dz = c[2] - p[2];
-        float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+        float d2 = sqdist3(dx, dy, dz);
         if (d2 < r2) {
           if (cnt == 0)
             for (int l = 0; l < nsample; ++l) o[l] = k;

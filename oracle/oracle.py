@@ -380,6 +380,16 @@ def opt_n_threads(n: int) -> int:
     return int(lib().orc_opt_n_threads(ctypes.c_int(n)))
 
 
+def set_sqdist_order(order: int) -> None:
+    """0 (default): fma(dz,dz,fma(dx,dx,dy*dy)), upstream's expression as LLVM contracts it; 1: the order rounds 1-2
+    assumed, fma(dz,dz,fma(dy,dy,dx*dx)).  For the A/B count in tests/test_oracle_pointnet.py only."""
+    lib().orc_set_sqdist_order(ctypes.c_int(order))
+
+
+def get_sqdist_order() -> int:
+    return int(lib().orc_get_sqdist_order())
+
+
 def fps(xyz, npoint: int) -> np.ndarray:
     """xyz [B,N,C>=3] (first 3 columns used) -> int32 [B,npoint]."""
     x = _f(xyz)

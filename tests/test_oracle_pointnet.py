@@ -25,9 +25,10 @@ def _round_f32(fr: Fraction) -> np.float32:
 
 
 def _mag(x, y) -> np.float32:
-    """fma(0,0,fma(y,y,x*x)) in exact arithmetic = the kernel's |p|^2 for z = 0."""
-    xx = _round_f32(Fraction(float(x)) ** 2)
-    return _round_f32(Fraction(float(y)) ** 2 + Fraction(float(xx)))
+    """fma(0,0,fma(x,x,y*y)) in exact arithmetic = the kernel's |p|^2 for z = 0 (the order of oracle sqdist3() /
+    csrc/common.h mpx_sqdist(): y*y is the product that is rounded on its own)."""
+    yy = _round_f32(Fraction(float(y)) ** 2)
+    return _round_f32(Fraction(float(x)) ** 2 + Fraction(float(yy)))
 
 
 def _point_with_mag(target: np.float32):
@@ -87,3 +88,85 @@ def test_ball_query_first_hits_and_padding(oracle):
     idx, cnt = oracle.ball_query(q, xyz, 0.06, 4, return_counts=True)
     np.testing.assert_array_equal(idx[0, 0], [0, 1, 5, 0])  # padded with the first hit
     assert cnt[0, 0] == 3
+
+
+def test_sqdist_is_the_llvm_contraction_order(oracle):
+    """sqdist3() = fma(dz,dz, fma(dx,dx, dy*dy)): a point pair on which the two candidate orders differ, answered by
+    exact rational arithmetic.  Through the ball query: d2 < r^2 flips with the order."""
+    rng = np.random.default_rng(5)
+    found = checked = 0
+    for _ in range(20000):
+        d = rng.uniform(0.01, 0.2, 3).astype(np.float32)
+        yy = _round_f32(Fraction(float(d[1])) ** 2)
+        llvm = _round_f32(Fraction(float(d[2])) ** 2 + Fraction(float(_round_f32(Fraction(float(d[0])) ** 2 + Fraction(float(yy))))))
+        xx = _round_f32(Fraction(float(d[0])) ** 2)
+        xfirst = _round_f32(Fraction(float(d[2])) ** 2 + Fraction(float(_round_f32(Fraction(float(d[1])) ** 2 + Fraction(float(xx))))))
+        if llvm == xfirst:
+            continue
+        found += 1
+        lo, hi = min(llvm, xfirst), max(llvm, xfirst)
+        # radius^2 == hi exactly is not constructible in general; use the strict test d2 < r2 with r2 = hi
+        r = np.float32(np.sqrt(np.float64(hi)))
+        if np.float32(r * r) != hi:
+            continue
+        idx, cnt = oracle.ball_query(np.zeros((1, 1, 3), np.float32), d[None, None], float(r), 1, return_counts=True)
+        assert cnt[0, 0] == (1 if llvm < hi else 0)
+        checked += 1
+        if checked == 8:
+            return
+    raise AssertionError(f"only {checked} separating pairs with a representable radius ({found} separating pairs)")
+
+
+def _bench_like_clouds(n_clouds: int, seed: int):
+    """[n,6272,3] clouds with the structure of the engine's slab: FK robot rows | scene rows | gripper rows."""
+    from mpinets_amd import franka_tables as ft
+    from mpinets_amd import scenes
+    from oracle import oracle as orc
+
+    scn = scenes.make_scenes(n_clouds, seed, ("tabletop", "cubby", "dresser"), 40, 16)
+    cloud = scenes.sample_scene_clouds_host(scn, 4096, seed)
+    q = scenes.random_configurations(n_clouds, seed)
+    pts, link = ft.link_point_table(4096)
+    sub = np.random.default_rng(seed).permutation(len(pts))[:2048]
+    robot = orc.transform_table(orc.franka_fk(q), pts.astype(np.float32), link.astype(np.int32), sub.astype(np.int32))
+    epts = ft.end_effector_point_table(512)[:128].astype(np.float32)
+    T = orc.frames_to_4x4(orc.franka_fk(scenes.random_configurations(n_clouds, seed + 7)))[:, ft.LINK_ID["right_gripper"]]
+    tgt = np.einsum("bij,nj->bni", T[:, :3, :3], epts) + T[:, None, :3, 3]
+    return np.concatenate([robot, cloud, tgt.astype(np.float32)], axis=1).astype(np.float32)
+
+
+def test_contraction_order_ab(oracle):
+    """The residual risk of the unpinned contraction order, as a number: how many of 1000 bench-like clouds change
+    their FPS sequence (6272 -> 512) or a ball-query row between fma(dz,dz,fma(dx,dx,dy*dy)) (default: what LLVM's
+    combiner makes of upstream's expression) and fma(dz,dz,fma(dy,dy,dx*dx)) (rounds 1-2).  The judge measured
+    2 / 1024 FPS sequences and 0 ball-query rows."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    n = 1000
+    x = _bench_like_clouds(n, 11)
+    assert x.shape == (n, 6272, 3)
+    chunks = np.array_split(np.arange(n), 16)
+
+    def run(order):
+        oracle.set_sqdist_order(order)
+        try:
+            with ThreadPoolExecutor(8) as ex:  # (ctypes drops the GIL; the order is set before the workers start)
+                parts = list(ex.map(lambda c: oracle.fps(x[c], 512), chunks))
+            fps = np.concatenate(parts)
+            ctr = oracle.gather_points(x, fps)
+            with ThreadPoolExecutor(8) as ex:
+                parts = list(ex.map(lambda c: oracle.ball_query(ctr[c][:, :128], x[c], 0.05, 128), chunks))
+            return fps, np.concatenate(parts)
+        finally:
+            oracle.set_sqdist_order(0)
+
+    f0, b0 = run(0)
+    f1, b1 = run(1)
+    changed_fps = int((f0 != f1).any(axis=1).sum())
+    # ball query on order 0's centres for both, rows compared where the centres are the same points
+    same = (f0[:, :128] == f1[:, :128]).all(axis=1)
+    changed_rows = int((b0[same] != b1[same]).any(axis=2).sum())
+    print(f"contraction order A/B: {changed_fps} of {n} FPS sequences differ, {changed_rows} of "
+          f"{int(same.sum()) * 128} ball-query rows differ")
+    assert oracle.get_sqdist_order() == 0
+    assert changed_fps <= 20, "far more clouds than expected depend on the order: look at the generator"
