@@ -74,8 +74,12 @@ def cpu_baseline(prob, model, n_env: int):
                          prim["cylinder_quats"]))
     dt = time.perf_counter() - t0
     del cloud
-    return {"value": n_env / dt, "unit": "env-steps/s", "cores": int(cores), "kind": "port",
-            "sample": f"{n_env} env-steps of the same step (oracle/: C FPS+ball-query+FK+SDF single-thread, "
+    # `cores`: the port is NOT parallel throughout -- the C parts (FPS, ball query, grouping, FK, SDF) run on ONE thread,
+    # only the numpy float64 matrix products use the BLAS pool.  Both numbers are stated; `cores` is the BLAS pool
+    # (where most of the sample's time goes), `host_cores` what the box has.
+    return {"value": n_env / dt, "unit": "env-steps/s", "cores": int(cores), "blas_threads": int(cores),
+            "scalar_threads": 1, "host_cores": int(os.cpu_count() or 1), "kind": "port",
+            "sample": f"{n_env} env-steps of the same step (oracle/: C FPS+ball-query+FK+SDF on ONE thread, "
                       f"numpy float64 MLPs on {cores} BLAS threads), {dt:.1f} s"}
 
 
@@ -167,6 +171,7 @@ def main():
     ap.add_argument("--fast-steps", type=int, default=3, help="steps of the secondary bf16x3 measurement (0 = skip)")
     ap.add_argument("--extra", type=int, default=1, help="also time BASELINE configs 2 and 4 (collision validation only)")
     ap.add_argument("--static-steps", type=int, default=2, help="steps of the extra without scene re-render on tabletop-only scenes (BASELINE config 3 shape at this batch size); 0 = skip")
+    ap.add_argument("--all-slots-steps", type=int, default=2, help="steps of the worst-case extra: padding elision off, all 128 slots per neighbourhood (0 = skip)")
     ap.add_argument("--pipeline-steps", type=int, default=3, help="steps of the two-stream pipelined measurement of the headline workload (0 = skip)")
     ap.add_argument("--cpu-envs", type=int, default=64, help="env-steps in the CPU baseline sample (0 = skip)")
     ap.add_argument("--scene-pool", type=int, default=1024, help="distinct host-generated primitive sets tiled over the batch (clouds are drawn per env on the device)")
@@ -217,7 +222,15 @@ def main():
     shard.barrier()
     elapsed = time.perf_counter() - t0
     prof = _lib.profile_stop()
+    elapsed_local = elapsed
     elapsed = shard.max_over_ranks(elapsed, dev)
+    # self-check record of an N-rank run: which communicator, which device every rank ran on, every rank's own time
+    props = torch.cuda.get_device_properties(dev)
+    rank_records = shard.gather_objects({
+        "rank": rank, "local_rank": local, "device": str(dev), "device_name": props.name,
+        "gcn_arch": getattr(props, "gcnArchName", ""), "pci_bus_id": getattr(props, "pci_bus_id", None),
+        "env_ids": [envs.start, envs.stop], "ms_per_step": elapsed_local / args.steps * 1e3})
+    dist_backend = shard.backend_name()
     cnt1, cnt2 = (c.clone() for c in model.point_cloud_encoder.last_counts)  # ball-query hit counts of the last timed step
 
     # ---- secondary measurement: the opt-in split-bf16 mode of the two grouped MLPs (same step, same
@@ -390,6 +403,27 @@ def main():
             extra = extra if extra is not None else {}
             extra["tabletop_static_scene"] = static
 
+    # ---- extra: the worst case of the headline -- the SAME workload with the padding elision switched off: every
+    # neighbourhood walks its nominal 128 slots like the reference does (model.set_elide_padding(False))
+    all_slots = None
+    if args.extra and args.all_slots_steps > 0:
+        model.set_elide_padding(False)
+        eng.step()
+        torch.cuda.synchronize()
+        shard.barrier()
+        ta0 = time.perf_counter()
+        for _ in range(args.all_slots_steps):
+            eng.step()
+        torch.cuda.synchronize()
+        shard.barrier()
+        el_a = shard.max_over_ranks(time.perf_counter() - ta0, dev)
+        model.set_elide_padding(True)
+        all_slots = {"steps": args.all_slots_steps, "ms_per_step": el_a / args.all_slots_steps * 1e3,
+                     "env_steps_per_s": B * n_gpus * args.all_slots_steps / el_a, "dtype": "f32",
+                     "what": "the headline workload with padding elision OFF: the grouped MLPs evaluate all 128 slots of every "
+                             "neighbourhood (what the reference computes; same result bit for bit) -- the density-independent "
+                             "floor of the headline number"}
+
     if rank == 0:
         # SA1 = mpx_sa_mlp; SA2 = mpx_sa_mlp_factored (first layer evaluated per point / per query by two
         # mpx_linear calls, which are timed under linear_all)
@@ -468,11 +502,18 @@ def main():
             # per-stage achieved / peak with the ALGORITHMIC work of SURVEY.md section 8(d) (per env-step, x B envs)
             "stages": stage_table(prof, args.steps, B, sa1_ms, sa1_exec, sa2_ms, sa2_exec),
             "result_check": {"gathered_q": list(q_all.shape), "collision_rate": float((f_all != 0).float().mean())},
+            # N-rank self-check: the communicator the barrier / MAX / gather ran on ("nccl" = RCCL; null = a plain single
+            # process, no group), the number of ranks on it, and every rank's device + own ms_per_step (`ms_per_step`
+            # above is their maximum)
+            "dist_backend": dist_backend, "rccl_ranks": n_gpus if dist_backend == "nccl" else 0,
+            "ranks": rank_records,
         }
         if extra is not None:
             out["extra_configs"] = extra
         if pipelined is not None:
             out["pipelined_two_streams"] = pipelined
+        if all_slots is not None:
+            out["all_slots"] = all_slots
         if fast is not None:
             fel, f1_ms, f2_ms, fdense_ms = fast
             out["fast_mode"] = {

@@ -29,7 +29,7 @@ typedef void *mpx_stream_t;
 
 #define MPX_NUM_FRAMES 15 /* link0..8, hand, leftfinger, rightfinger, l/r fingertip, right_gripper */
 
-int mpx_version(void);
+int mpx_version(void); /* 300: mpx_set_variant / mpx_get_variant, mpx_sa_mlp_bf16x3_wants_order takes nsample */
 const char *mpx_last_error(void);
 /* host-side query of the device the library will launch on (name buffer may be NULL) */
 int mpx_device_info(char *name, int name_len, int *cu_count, int *lds_bytes);
@@ -279,6 +279,16 @@ int mpx_scene_cloud(const float *cub_centers, const float *cub_dims, const float
 int mpx_fps(const float *xyz, int B, int N, int stride, int npoint, int32_t *idx, float *new_xyz,
             int new_stride, mpx_stream_t stream);
 
+/* Verification hook (host call, process-wide): which kernel family serves mpx_fps / mpx_ball_query.  value 1 (default) =
+ * the fast kernels (one wave per small cloud / Morton-culled FPS; wave-per-query / bucketed ball query); value 0 = the
+ * plain kernels they are proven against.  Indices are identical bit for bit either way; the switch lets a test run
+ * both on the same clouds in one process (tests/test_gpu_soak.py).  Returns non-zero on a bad selector / value.      */
+#define MPX_VARIANT_FPS 0
+#define MPX_VARIANT_BALL_QUERY 1
+#define MPX_VARIANT_COUNT_ 2
+int mpx_set_variant(int what, int value);
+int mpx_get_variant(int what); /* -1: unknown selector */
+
 /* ball_query: first `nsample` indices (ascending) with d2 < radius^2, padded with the first
  * hit, zero when there is none.  idx int32 [B,npoint,nsample].  cnt (optional, int32
  * [B,npoint]) receives the number of real hits (<= nsample): slots [cnt, nsample) are padding. */
@@ -327,8 +337,11 @@ int mpx_sa_mlp_factored(const float *pre, const float *ctr, const int32_t *idx, 
                         float *out, int out_stride, mpx_stream_t stream);
 /* mpx_sa_mlp_factored on the bf16 matrix cores (split products, see mpx_sa_mlp_bf16x3): wpack from
  * mpx_sa_pack_bf16x3 (its layer-1 blocks are not read); order (optional) from mpx_sort_queries.          */
-/* host query: does mpx_sa_mlp_bf16x3_factored use `order` (1: the lockstep variant, pass mpx_sort_queries' output for
- * balanced workgroups) or ignore it (0: the persistent variant takes queries in a static XCD-aware stride)?         */
+/* host query: does mpx_sa_mlp_bf16x3_factored use `order`?  Always 0 since version 300: its one kernel is persistent
+ * and takes units of 8 queries from a device-side queue (`order` is ignored; pass NULL).  The queue is 32 bytes of
+ * library-image memory per (device, stream), zeroed on the launch stream in front of the kernel: concurrent calls on
+ * DIFFERENT streams never share counters (up to 256 streams per process).  hipGraph: a captured call bakes its capture
+ * stream's queue in -- do not replay two graphs that were captured on the same stream concurrently on two streams.   */
 int mpx_sa_mlp_bf16x3_factored_wants_order(void);
 int mpx_sa_mlp_bf16x3_factored(const float *pre, const float *ctr, const int32_t *idx, const int32_t *cnt,
                                const int32_t *order, int B, int N, int npoint, int nsample, const void *wpack,
@@ -349,9 +362,10 @@ int mpx_sa_pack_weights(const float *w1, const float *b1, const float *w2, const
  * mpx_sort_queries) is the order in which waves take the queries: the 8 waves of a workgroup walk
  * the weight stream in lockstep and run max(tiles) of their row counts.  A module whose whole pack fits
  * LDS (the first one, 1+3 -> 64 -> 64 -> 64) runs a weight-resident kernel instead that takes the queries
- * in their natural order: mpx_sa_mlp_bf16x3_wants_order (host query) says whether `order` is used for a
- * module.  append_centre as in mpx_sa_mlp (only where `order` is not used).                              */
-int mpx_sa_mlp_bf16x3_wants_order(int C, int c1, int c2, int c3);
+ * in their natural order (up to nsample = 128): mpx_sa_mlp_bf16x3_wants_order (host query; the launcher uses the
+ * same predicate) says whether `order` is used for a module and neighbourhood size.  append_centre as in mpx_sa_mlp
+ * (only where `order` is not used).                                                                        */
+int mpx_sa_mlp_bf16x3_wants_order(int C, int c1, int c2, int c3, int nsample);
 int mpx_sa_mlp_bf16x3(const float *xyz, int stride, const float *new_xyz, int new_stride,
                       const float *feat, int feat_stride, int C, const int32_t *idx,
                       const int32_t *cnt, const int32_t *order, int B, int N, int npoint,

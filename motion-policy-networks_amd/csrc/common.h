@@ -12,8 +12,6 @@
 
 // ---- error plumbing -------------------------------------------------------------------------
 void mpx_set_error(const char *fmt, ...);
-// a zeroed slot of 8 unit counters (one per XCD) for a persistent kernel's device-side work queue (sa_mlp.hip)
-unsigned int *mpx_next_unit_queue(hipStream_t stream);
 
 #define MPX_REQUIRE(cond, ...)        \
   do {                                \

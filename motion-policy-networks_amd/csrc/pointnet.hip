@@ -599,6 +599,22 @@ static int opt_n_threads_log2(int n) {
   return l;
 }
 
+// ---- verification hook: which kernel family serves mpx_fps / mpx_ball_query ---------------------------------------
+// Variant 1 (default) = the fast kernels (wave-per-environment / Morton-culled FPS; wave-per-query / bucketed ball
+// query), variant 0 = the plain kernels they are proven against (fps_kernel, ball_query_kernel).  Both produce the same
+// indices bit for bit; the switch exists so that a test can run BOTH in one process on the same clouds
+// (tests/test_gpu_soak.py).  Process-wide, read at every launch.
+static std::atomic<int> g_variant[MPX_VARIANT_COUNT_] = {{1}, {1}};
+MPX_EXPORT int mpx_set_variant(int what, int value) {
+  MPX_REQUIRE(what >= 0 && what < MPX_VARIANT_COUNT_, "mpx_set_variant: unknown selector %d", what);
+  MPX_REQUIRE(value == 0 || value == 1, "mpx_set_variant: value must be 0 (plain kernels) or 1 (default)");
+  g_variant[what].store(value, std::memory_order_relaxed);
+  return 0;
+}
+MPX_EXPORT int mpx_get_variant(int what) {
+  return (what >= 0 && what < MPX_VARIANT_COUNT_) ? g_variant[what].load(std::memory_order_relaxed) : -1;
+}
+
 MPX_EXPORT int mpx_fps(const float *xyz, int B, int N, int stride, int npoint, int32_t *idx, float *new_xyz,
                        int new_stride, mpx_stream_t stream) {
   MPX_REQUIRE(B >= 0 && N >= 1 && npoint >= 0 && stride >= 3, "mpx_fps: bad size");
@@ -606,8 +622,8 @@ MPX_EXPORT int mpx_fps(const float *xyz, int B, int N, int stride, int npoint, i
   MPX_REQUIRE(new_xyz == nullptr || new_stride >= 3, "mpx_fps: new_stride < 3");
   if (B == 0 || npoint == 0) return 0;
   const int log2bs = opt_n_threads_log2(N);
-  static const int use_wave = getenv("MPX_FPS_WAVE") ? atoi(getenv("MPX_FPS_WAVE")) : 1;
-  if (use_wave && N <= 512) {  // small cloud: one wave per environment, no LDS, no barrier
+  const int fast = g_variant[MPX_VARIANT_FPS].load(std::memory_order_relaxed);
+  if (fast && N <= 512) {  // small cloud: one wave per environment, no LDS, no barrier
     dim3 g1(B), t1(64);
 #define FPS_WAVE(P) hipLaunchKernelGGL(fps_wave_kernel<P>, g1, t1, 0, mpx_s(stream), xyz, N, stride, npoint, log2bs, idx, new_xyz, new_stride)
     switch ((N + 63) / 64) {
@@ -619,8 +635,7 @@ MPX_EXPORT int mpx_fps(const float *xyz, int B, int N, int stride, int npoint, i
 #undef FPS_WAVE
     MPX_LAUNCH_CHECK("mpx_fps");
   }
-  static const int use_cull = getenv("MPX_FPS_CULL") ? atoi(getenv("MPX_FPS_CULL")) : 1;
-  if (use_cull && N > 512) {  // (log2bs == 9 here: the key layout of fps_cull_kernel assumes it)
+  if (fast && N > 512) {  // (log2bs == 9 here: the key layout of fps_cull_kernel assumes it)
     const size_t lds_c = fpsc_lds_bytes(N);
     dim3 gc(B), tc(FPSC_THREADS);
 #define FPS_CULL(P)                                                                                              \
@@ -641,8 +656,7 @@ MPX_EXPORT int mpx_fps(const float *xyz, int B, int N, int stride, int npoint, i
     MPX_LAUNCH_CHECK("mpx_fps");
   }
   int block = ((N + 63) / 64) * 64;
-  static const int block_cap = getenv("MPX_FPS_BLOCK") ? atoi(getenv("MPX_FPS_BLOCK")) : 512;  // measured: 512 x 13 pts beats 1024 x 7
-  if (block > block_cap) block = block_cap;
+  if (block > 512) block = 512;  // measured: 512 threads x 13 points beat 1024 x 7
   const int pts = (N + block - 1) / block;
   const size_t lds = 256 + (size_t)3 * N * sizeof(float);
   dim3 g(B), t(block);
@@ -1117,8 +1131,8 @@ MPX_EXPORT int mpx_ball_query(const float *new_xyz, int new_stride, const float 
   if (B == 0 || npoint == 0 || nsample == 0) return 0;
   const float r2 = radius * radius;  // float product, like the reference kernel
   // large cloud, small radius (the first set-abstraction module): bucketed search, bit-identical output
-  static const int use_grid = getenv("MPX_BQ_GRID") ? atoi(getenv("MPX_BQ_GRID")) : 1;
-  if (use_grid && N >= 2048 && N <= 8192 && nsample <= 128 && nsample > BQ_HC && npoint <= 4096 && radius > 0.0f &&
+  const int fast = g_variant[MPX_VARIANT_BALL_QUERY].load(std::memory_order_relaxed);
+  if (fast && N >= 2048 && N <= 8192 && nsample <= 128 && nsample > BQ_HC && npoint <= 4096 && radius > 0.0f &&
       radius * BQG < 4.0f) {  // columns of side ~radius must still resolve the scene (48 x radius < 4 m)
     const size_t lds = (size_t)4 * N * 4 + (size_t)BQG * BQG * 4 + (size_t)(BQG * BQG + 2) * 2 +
                        (size_t)((npoint + 1) & ~1) * 2 * 2 + (size_t)npoint * BQ_HC * 2 + (size_t)npoint * 4;
@@ -1130,8 +1144,7 @@ MPX_EXPORT int mpx_ball_query(const float *new_xyz, int new_stride, const float 
       MPX_LAUNCH_CHECK("mpx_ball_query");
     }
   }
-  static const int use_wave_bq = getenv("MPX_BQ_WAVE") ? atoi(getenv("MPX_BQ_WAVE")) : 1;
-  if (use_wave_bq && N >= 1 && N <= 512) {  // small cloud: a wave per query, cloud in registers, rows written in order
+  if (fast && N >= 1 && N <= 512) {  // small cloud: a wave per query, cloud in registers, rows written in order
     const int qpw = npoint >= 64 ? 16 : 4;  // queries per wave (the cloud load is amortised over them)
     dim3 gw(cdiv(npoint, 4 * qpw), B), tw(256);
 #define BQ_WAVE(P)                                                                                                   \

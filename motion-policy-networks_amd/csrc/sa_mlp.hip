@@ -618,364 +618,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CF == 1
   for (int ot = 0; ot < Cfg::OT3; ++ot) flush(ot, cur);
 }
 
-// ---- persistent variant of the factored (64+3, 128, 128, 256) module: ONE software-pipelined wave per SIMD ----------
-// sa_mlp_packed_kernel<64,128,128,256,8,true> keeps the matrix pipes 85 % busy with two 240-register waves per SIMD:
-// each wave alternates matrix phases with phases of its own (forming relu(pre - ctr), ReLU of the layer-2 tiles,
-// pooling, the per-unit prologue of index -> row loads), and the two waves of a SIMD cover each other only when
-// their phases happen to differ.  This variant removes the phases instead of covering them:
-//   * one persistent workgroup of 4 waves per CU (grid = CU count), one 512-register wave per SIMD; a wave takes units
-//     of Q = 8 consecutive queries in a static XCD-aware stride (an environment's queries stay on one XCD: its
-//     512 x 128 first-layer rows are read through one L2);
-//   * the layer-3 weights (512 MFMA steps x 256 B = 128 KB) are copied into LDS once per workgroup and read from
-//     there (one ds_read_b128 per 4 MFMAs); the layer-2 weights (64 KB per tile) stream from L2 through an 8-group
-//     register ring, 7 groups (1792 matrix cycles) ahead;
-//   * layer 3 walks two output tiles at a time on two accumulators -- each tile's k order is unchanged, so every
-//     pooled value is BIT-IDENTICAL to the two-wave kernel's -- and the tile loop is a software pipeline written in
-//     issue order: behind the MFMAs of layer 3 ride the ReLU of layer 2's tiles, the pooling of the output pair before,
-//     and the NEXT tile's relu(pre - ctr) (its rows are requested when layer 2 ends: the only slow loads of the loop sit
-//     in front of 512 MFMAs that wait for nothing but LDS).  A v_mfma_f32_32x32x2_f32 occupies the pipe for 64 cycles:
-//     ~15 issue slots per gap, of which this stream needs ~3.
-// Same pack (mpx_sa_pack_weights), same inputs and outputs as the kernel above.
-namespace sa2p {
-using Cfg = SaCfg<64, 128, 128, 256>;
-constexpr int Q = 8, WV = 4;
-constexpr int C1 = 128, C2 = 128, C3 = 256;
-constexpr int G2 = Cfg::S2 / 4, G3 = Cfg::S3 / 4, GPT = Cfg::KS2 / 4;  // 64 layer-2 groups, 128 layer-3 groups, 16 per output tile
-constexpr int W2_BYTES_OFF = (int)Cfg::W2_OFF * 4, W3_BYTES_OFF = (int)Cfg::W3_OFF * 4, W3_BYTES = G3 * 1024;  // 131072
-constexpr int LDS_B2 = W3_BYTES, LDS_B3 = LDS_B2 + 4 * C2, LDS_CTR = LDS_B3 + 4 * C3;
-constexpr int LDS_BYTES = LDS_CTR + WV * Q * C1 * 4;  // 148992
-constexpr int RS = 8, RD = 7;                          // layer-2 ring: stages (one float4 group each), prefetch distance
-static_assert(G2 == 64 && G3 == 128 && GPT == 16 && Cfg::OT2 == 4 && Cfg::OT3 == 8, "shape");
-}  // namespace sa2p
-
-#define SA2P_FENCE() __builtin_amdgcn_sched_barrier(0)
-
-// Unit queues of the persistent kernel: 64 slots of 8 counters (one per XCD) in device memory that belongs to the
-// library image (nothing is allocated); a launch takes the next slot round-robin and zeroes it on its stream first
-// (stream-ordered, hipGraph-capturable).  Launches on different streams use different slots unless more than 64 are in
-// flight on one device at once.
-__device__ unsigned int sa2p_queues[64 * 8];
-unsigned int *mpx_next_unit_queue(hipStream_t stream) {
-  static std::atomic<unsigned int> turn{0};
-  static unsigned int *base[64];
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-  unsigned int *&b = base[dev & 63];
-  if (!b) {
-    void *p = nullptr;
-    if (hipGetSymbolAddress(&p, HIP_SYMBOL(sa2p_queues)) != hipSuccess) return nullptr;
-    b = static_cast<unsigned int *>(p);
-  }
-  unsigned int *q = b + 8 * (turn.fetch_add(1) & 63);
-  if (hipMemsetAsync(q, 0, 8 * sizeof(unsigned int), stream) != hipSuccess) return nullptr;
-  return q;
-}
-
-__global__ void __launch_bounds__(64 * sa2p::WV) __attribute__((amdgpu_waves_per_eu(1, 1)))
-    sa2_fp32_persistent_kernel(const int32_t *__restrict__ idx, const int32_t *__restrict__ cnt, int64_t n_query, int N,
-                               int npoint, int nsample, const float *__restrict__ wpack, float *__restrict__ out,
-                               int out_stride, const float *__restrict__ pre_rows, const float *__restrict__ ctr,
-                               int xcd_aware, unsigned int *__restrict__ queue) {
-  using namespace sa2p;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int half = lane >> 5, col = lane & 31;
-  {  // layer-3 weights + b2 | b3 -> LDS, once
-    const uint4 *src = reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(wpack) + W3_BYTES_OFF);
-    uint4 *dst = reinterpret_cast<uint4 *>(smem);
-    for (int i = threadIdx.x; i < W3_BYTES / 16; i += 64 * WV) dst[i] = src[i];
-    float *b = reinterpret_cast<float *>(smem + LDS_B2);
-    for (int i = threadIdx.x; i < C2 + C3; i += 64 * WV) b[i] = wpack[Cfg::B2_OFF + i];  // b2 | b3 are contiguous
-  }
-  __syncthreads();  // the only barrier: from here on the waves are independent
-  const float *b2_s = reinterpret_cast<const float *>(smem + LDS_B2);
-  const float *b3_s = reinterpret_cast<const float *>(smem + LDS_B3);
-  float *ctr_w = reinterpret_cast<float *>(smem + LDS_CTR) + wave * Q * C1;
-  const unsigned char *w3_lane = smem + lane * 16;
-  const __amdgpu_buffer_rsrc_t wrsrc =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(wpack), 0, (int)(Cfg::TOTAL * 4), 0x00020000);
-  const int wvoff = lane * 16;
-  float4 ring[RS];  // layer-2 weight groups: group g (= k-step t of layer 2, its four output tiles) in stage g % RS
-  auto fetch2 = [&](int g) __attribute__((always_inline)) { ring[g % RS] = bload16(wrsrc, wvoff, W2_BYTES_OFF + g * 1024); };
-#pragma unroll
-  for (int g = 0; g < RD; ++g) fetch2(g);
-  auto bias_lds = [&](const float *bs, int ot) __attribute__((always_inline)) {
-    f32x16 v;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const float4 q = *reinterpret_cast<const float4 *>(bs + ot * 32 + 8 * g + 4 * half);
-      v[4 * g + 0] = q.x, v[4 * g + 1] = q.y, v[4 * g + 2] = q.z, v[4 * g + 3] = q.w;
-    }
-    return v;
-  };
-
-  // ---- the units of this wave: handed out by a device-side queue (one counter per XCD: an environment's 16 units go
-  // to the waves of one XCD, in order, so its first-layer rows are read through one L2).  A wave asks for its next
-  // unit when it starts the current one: the atomic's latency is off the path.  Unit sizes differ 1 : 30; with a
-  // static stride the waves were resident only 87 % of the kernel. ------------------------------------------------
-  const int64_t n_units = (n_query + Q - 1) / Q;
-  const int upe = npoint / Q;  // units per environment (xcd_aware only)
-  const int xcd = xcd_aware ? (blockIdx.x & 7) : 0;
-  const int64_t j_end = xcd_aware ? (n_query / npoint / 8) * upe : n_units;  // units of this queue
-  auto next_unit = [&]() __attribute__((always_inline)) {
-    unsigned int v = 0;
-    if (lane == 0) v = atomicAdd(queue + xcd, 1u);
-    return (int64_t)(unsigned int)__builtin_amdgcn_readfirstlane((int)v);
-  };
-  int64_t j_next = next_unit();
-  while (true) {
-    const int64_t j = j_next;
-    if (j >= j_end) break;
-    j_next = next_unit();
-    const int64_t unit = xcd_aware ? ((j / upe) * 8 + xcd) * upe + j % upe : j;
-    const int64_t q0 = unit * Q;
-    const int nq = (int)min((int64_t)Q, n_query - q0);
-    int my_cnt = 1, my_rows = 0, my_env = 0;
-    if (lane < nq) {
-      const int c = cnt[q0 + lane];
-      my_cnt = c <= 0 ? 1 : (c > nsample ? nsample : c);  // no hit: the zero-initialised row = point 0
-      my_rows = (my_cnt + 3) & ~3;
-      my_env = (int)((q0 + lane) / npoint);
-    }
-    int pre = my_rows;
-#pragma unroll
-    for (int o = 1; o < Q; o <<= 1) {
-      const int t = __shfl_up(pre, o);
-      if (lane >= o) pre += t;
-    }
-    const int total = __builtin_amdgcn_readlane(pre, Q - 1);
-    pre -= my_rows;
-    int s_pre[Q], s_cnt[Q], s_env[Q];
-#pragma unroll
-    for (int i = 0; i < Q; ++i) {
-      s_pre[i] = __builtin_amdgcn_readlane(pre, i);
-      s_cnt[i] = __builtin_amdgcn_readlane(my_cnt, i);
-      s_env[i] = __builtin_amdgcn_readlane(my_env, i);
-    }
-    // this unit's per-query first-layer terms -> this wave's LDS rows (Q x 32 float4: Q / 2 per lane)
-#pragma unroll
-    for (int u = 0; u < Q / 2; ++u) {
-      const int i = lane + 64 * u, qi = i >> 5, c4 = i & 31;
-      if (qi < nq)
-        *reinterpret_cast<float4 *>(ctr_w + qi * C1 + 4 * c4) =
-            *reinterpret_cast<const float4 *>(ctr + (q0 + qi) * C1 + 4 * c4);
-    }
-    __builtin_amdgcn_wave_barrier();
-
-    // row -> (local query, environment, neighbour slot); rows past the end repeat the last query's first slot
-    auto map_row = [&](int p, int &qi, int &env, int &off) __attribute__((always_inline)) {
-      int qpre = 0, qcnt = s_cnt[0];
-      qi = 0;
-      env = s_env[0];
-#pragma unroll
-      for (int i = 1; i < Q; ++i) {
-        const bool ge = i < nq && p >= s_pre[i];
-        qi = ge ? i : qi;
-        env = ge ? s_env[i] : env;
-        qpre = ge ? s_pre[i] : qpre;
-        qcnt = ge ? s_cnt[i] : qcnt;
-      }
-      const int slot = p - qpre;
-      off = slot < qcnt ? slot : 0;
-    };
-    float raw_f[C1 / 2];  // this lane-half's 4-channel groups of the gathered first-layer row
-    auto gather = [&](int env, int k) __attribute__((always_inline)) {
-      const float *pa = pre_rows + ((int64_t)env * N + k) * (int64_t)C1 + 4 * half;
-#pragma unroll
-      for (int i = 0; i < C1 / 8; ++i) {
-        const float4 v = *reinterpret_cast<const float4 *>(pa + 8 * i);
-        raw_f[4 * i + 0] = v.x, raw_f[4 * i + 1] = v.y, raw_f[4 * i + 2] = v.z, raw_f[4 * i + 3] = v.w;
-      }
-    };
-    float run[Cfg::OT3];
-#pragma unroll
-    for (int ot = 0; ot < Cfg::OT3; ++ot) run[ot] = -__builtin_inff();
-    int cur = 0;  // local query being merged (wave-uniform)
-    auto flush = [&](int ot, int qi) __attribute__((always_inline)) {
-      float v = run[ot];
-      v = mpx_max_across_halves(v);
-      const int ch = ot * 32 + col;
-      v = fmaxf(v + b3_s[ch], 0.0f);
-      if (half == 0) out[(q0 + qi) * out_stride + ch] = v;
-      run[ot] = -__builtin_inff();
-    };
-    // layer-2 B operands of the tile being computed: relu(pre - ctr); register r of tile ot = channel
-    // 32 * ot + 8 * (r >> 2) + 4 * half + (r & 3) = 4-channel group i = 4 * ot + (r >> 2) of raw_f.  Formed for the NEXT
-    // tile during layer 3 of this one, one 4-channel group (8 VALU + one LDS read) at a time.
-    f32x16 a1[4];
-    float4 cpre[2];  // the query-term float4 of group i is read one group ahead (cpre[i & 1]): no LDS wait inside form_g
-    auto form_load = [&](const float *cqp, int i) __attribute__((always_inline)) {
-      cpre[i & 1] = *reinterpret_cast<const float4 *>(cqp + 8 * i);
-    };
-    auto form_g = [&](const float *cqp, int i) __attribute__((always_inline)) {
-      const float4 c = cpre[i & 1];
-      if (i + 1 < C1 / 8) form_load(cqp, i + 1);
-      a1[i >> 2][4 * (i & 3) + 0] = fmaxf(raw_f[4 * i + 0] - c.x, 0.0f);
-      a1[i >> 2][4 * (i & 3) + 1] = fmaxf(raw_f[4 * i + 1] - c.y, 0.0f);
-      a1[i >> 2][4 * (i & 3) + 2] = fmaxf(raw_f[4 * i + 2] - c.z, 0.0f);
-      a1[i >> 2][4 * (i & 3) + 3] = fmaxf(raw_f[4 * i + 3] - c.w, 0.0f);
-    };
-
-    int ql_cur, ql_next = 0, env_next = 0, k_next = 0;
-    {  // unit prologue: the first tile's rows, formed without cover (once per ~16 tiles)
-      int env, off;
-      map_row(col, ql_cur, env, off);
-      const int k0 = idx[(q0 + ql_cur) * nsample + off];
-      gather(env, k0);
-      map_row(32 + col, ql_next, env_next, off);
-      k_next = idx[(q0 + ql_next) * nsample + off];
-      const float *cqp = ctr_w + ql_cur * C1 + 4 * half;
-      form_load(cqp, 0);
-#pragma unroll
-      for (int i = 0; i < C1 / 8; ++i) form_g(cqp, i);
-    }
-    f32x16 a2n[4];  // layer-2 bias tiles for the next tile (read at the end of the tile before)
-#pragma unroll
-    for (int ot = 0; ot < 4; ++ot) a2n[ot] = bias_lds(b2_s, ot);
-    int ql_nn = 0, env_nn = 0, k_nn = 0;  // row after next: computed behind layer 3's MFMAs
-    {
-      int off;
-      map_row(64 + col, ql_nn, env_nn, off);
-      k_nn = idx[(q0 + ql_nn) * nsample + off];
-    }
-    for (int rt = 0; rt < total; rt += 32) {
-      const int ql_tile = ql_cur;
-      const int env_gather = env_next, k_gather = k_next;
-      const float *cq_next = ctr_w + ql_next * C1 + 4 * half;  // LDS row of the next tile's query (this lane's row)
-      ql_cur = ql_next;
-      ql_next = ql_nn, env_next = env_nn, k_next = k_nn;  // (k_nn was loaded a tile ago; it is refreshed in layer 3 below)
-      SA2P_FENCE();
-      int gq[8];
-#pragma unroll
-      for (int g = 0; g < 8; ++g) gq[g] = __builtin_amdgcn_readlane(ql_tile, 4 * g);
-      SA2P_FENCE();
-      // ---- layer 2: H2^T = W2 . H1^T; group g = k-step t = g of all four output tiles (the a1 tiles are the B operands
-      // in place), weights from the ring ---------------------------------------------------------------------------
-      f32x16 a2[4];
-#pragma unroll
-      for (int ot = 0; ot < 4; ++ot) a2[ot] = a2n[ot];
-      SA2P_FENCE();
-#pragma unroll
-      for (int g = 0; g < G2; ++g) {
-        if (g + RD < G2) fetch2(g + RD);
-        const float4 w = ring[g % RS];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) a2[u] = mfma32(comp(w, u), a1[g >> 4][g & 15], a2[u]);
-        SA2P_FENCE();
-      }
-      // the next tile's rows are requested now: layer 3 reads LDS only, so these slower loads are not in front of
-      // anything the matrix stream waits for; they are consumed from output pair 1 on (>= 8000 cycles from here)
-      gather(env_gather, k_gather);
-      // ReLU of the first layer-2 tile (the A operands of layer 3's first 16 k-steps); tiles 1-3 follow behind MFMAs
-#pragma unroll
-      for (int r = 0; r < 16; ++r) a2[0][r] = fmaxf(a2[0][r], 0.0f);
-      SA2P_FENCE();
-      // ---- layer 3 (roles flipped: activations are A, weights B), output tiles FOUR at a time on four accumulators
-      // (consecutive MFMAs are independent; each tile's k order is the single-tile order: bit-identical pooled values),
-      // weights from LDS: running group n3 = quad * 16 + gg, stage n3 % 3, read two groups ahead -----------------------
-      float4 w3r[3][4];
-      auto load3 = [&](int n3) __attribute__((always_inline)) {
-        const int qd = n3 >> 4, gg = n3 & 15;
-#pragma unroll
-        for (int o = 0; o < 4; ++o)
-          w3r[n3 % 3][o] = *reinterpret_cast<const float4 *>(w3_lane + ((4 * qd + o) * GPT + gg) * 1024);
-      };
-      load3(0);
-      load3(1);
-      f32x16 a3[2][4];
-      // merge the four row-group maxima of output tile ot into the running maxima (flush when the query changes)
-      auto merge_ot = [&](int ot, const float (&gm)[4]) __attribute__((always_inline)) {
-        if (gq[7] == cur) {  // the whole tile belongs to the query being merged (the common case): no flush
-          run[ot] = fmaxf(run[ot], fmaxf(fmaxf(gm[0], gm[1]), fmaxf(gm[2], gm[3])));
-        } else {
-          int c = cur;
-#pragma unroll
-          for (int grp = 0; grp < 8; ++grp) {
-            if (gq[grp] != c) {
-              flush(ot, c);
-              c = gq[grp];
-            }
-            run[ot] = fmaxf(run[ot], ((grp & 1) == half) ? gm[grp >> 1] : -__builtin_inff());
-          }
-        }
-      };
-      auto merge = [&](int p, const float (&gm)[4]) __attribute__((always_inline)) { merge_ot(p, gm); };  // first quad: ot = p
-      auto pool = [&](int qd, int part) __attribute__((always_inline)) {  // output quad qd, tile o = part, in one piece
-        const f32x16 &a = a3[qd & 1][part];
-        float gm[4];
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj)
-          gm[jj] = fmaxf(fmaxf(a[4 * jj], a[4 * jj + 1]), fmaxf(a[4 * jj + 2], a[4 * jj + 3]));
-        merge_ot(4 * qd + part, gm);
-      };
-      SA2P_FENCE();
-      // Fillers ride behind INDIVIDUAL MFMAs, a few instructions each (m3 = running MFMA of layer 3, 0..511): a wave
-      // blocks on the issue of the next MFMA while the pipe is busy, so a lump of 15-60 instructions after a group of
-      // four MFMAs only has the last MFMA's 64 cycles for cover (measured: +100 cycles per lump of 14).
-      float gmq[4][4];  // per-group maxima of the first quad's four tiles (pooled behind the second quad's MFMAs)
-      auto filler = [&](int m3) __attribute__((always_inline)) {
-        if (m3 < 192 && (m3 & 3) == 1) {  // quad 0: ReLU of layer-2 tiles 1..3, one register at a time, ahead of its k-step
-          const int k = m3 >> 2;
-          a2[1 + (k >> 4)][k & 15] = fmaxf(a2[1 + (k >> 4)][k & 15], 0.0f);
-        }
-        if (m3 == 250) form_load(cq_next, 0);
-        if (m3 >= 256) {
-          const int rel = m3 - 256;
-          if (rel < 64 && (rel & 3) == 2) {  // first quad's pooling: tile p = rel / 16, row group jj = (rel % 16) / 4
-            const int p = rel >> 4, jj = (rel & 15) >> 2;
-            const f32x16 &a = a3[0][p];
-            gmq[p][jj] = fmaxf(fmaxf(a[4 * jj], a[4 * jj + 1]), fmaxf(a[4 * jj + 2], a[4 * jj + 3]));
-          }
-          if (rel < 80 && rel >= 16 && (rel & 15) == 1) merge(rel / 16 - 1, gmq[rel / 16 - 1]);  // tile p once its four maxima exist
-          if (rel >= 24 && rel < 24 + 8 * RD && ((rel - 24) & 7) == 0) fetch2((rel - 24) >> 3);  // next tile's first layer-2 groups
-          if (rel == 86) {  // neighbour index of the row after next (consumed by the gather one tile later)
-            int off;
-            map_row(rt + 96 + col, ql_nn, env_nn, off);
-            k_nn = idx[(q0 + ql_nn) * nsample + off];
-          }
-          if (rel >= 64 && rel < 64 + 3 * 64 && (rel - 64) % 3 == 0) {  // next tile's relu(pre - ctr), one element at a time
-            const int e = (rel - 64) / 3, i = e >> 2, k = e & 3;
-            if (k == 0 && i + 1 < C1 / 8) form_load(cq_next, i + 1);
-            a1[i >> 2][4 * (i & 3) + k] = fmaxf(raw_f[4 * i + k] - comp(cpre[i & 1], k), 0.0f);
-          }
-          if (rel >= 200 && rel < 248 && (rel - 200) % 3 == 1) {  // next tile's layer-2 bias tiles, one float4 at a time
-            const int bq = (rel - 200) / 3, ot = bq >> 2, g = bq & 3;
-            const float4 q = *reinterpret_cast<const float4 *>(b2_s + ot * 32 + 8 * g + 4 * half);
-            a2n[ot][4 * g + 0] = q.x, a2n[ot][4 * g + 1] = q.y, a2n[ot][4 * g + 2] = q.z, a2n[ot][4 * g + 3] = q.w;
-          }
-        }
-      };
-#pragma unroll
-      for (int n3 = 0; n3 < 32; ++n3) {
-        const int qd = n3 >> 4, gg = n3 & 15;
-        if (n3 + 2 < 32) load3(n3 + 2);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int t = 4 * gg + u;
-#pragma unroll
-          for (int o = 0; o < 4; ++o) {
-            const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-            a3[qd & 1][o] = mfma32(a2[t >> 4][t & 15], comp(w3r[n3 % 3][o], u), t == 0 ? zero : a3[qd & 1][o]);
-            filler((n3 * 4 + u) * 4 + o);
-            SA2P_FENCE();
-          }
-        }
-      }
-      pool(1, 0);
-      pool(1, 1);
-      pool(1, 2);
-      pool(1, 3);
-      cur = gq[7];
-      SA2P_FENCE();
-
-    }
-#pragma unroll
-    for (int ot = 0; ot < Cfg::OT3; ++ot) flush(ot, cur);
-    __builtin_amdgcn_wave_barrier();  // (this wave's ctr rows are rewritten by the next unit)
-  }
-}
-
 // ---- host entry points -----------------------------------------------------------------------------------
 template <int CF, int C1, int C2, int C3>
 static int launch_sa(const float *xyz, int stride, const float *new_xyz, int new_stride, const float *feat,
@@ -1055,31 +697,6 @@ MPX_EXPORT int mpx_sa_mlp_factored(const float *pre, const float *ctr, const int
                        mpx_s(stream), nullptr, 0, nullptr, 0, nullptr, 0, idx, cnt, nq, N, npoint, nsample, wpack, out,
                        out_stride, bpe, pre, ctr, 0);
   };
-  // MPX_SA2_PERSISTENT=1 (opt-in): the persistent one-wave-per-SIMD kernel, bit-identical to the two-wave kernel and, as
-  // measured, no faster (50.2 vs 49.9 ms at 8192 mixed envs): with one wave per SIMD every non-matrix instruction adds
-  // its issue time to the matrix stream (tile time = 64 x 768 + 4.2 x N_other cycles fits every section of the s_memtime
-  // probe), so ~1500 other instructions per tile cost what the imperfect overlap of two waves costs.  Kept as the
-  // reference for that measurement and as the structure a hand-scheduled (assembly) stream would fill.
-  static const int persistent = getenv("MPX_SA2_PERSISTENT") ? atoi(getenv("MPX_SA2_PERSISTENT")) : 0;
-  if (persistent && nq >= 1024 * 8 * 8) {
-    static int cus[64];
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (!cus[dev & 63]) {
-      int n = 0;
-      MPX_REQUIRE(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0,
-                  "mpx_sa_mlp_factored: cannot query the CU count");
-      cus[dev & 63] = n;
-    }
-    const int grid = cus[dev & 63];
-    const int xcd_aware = (B % 8 == 0 && grid % 8 == 0 && npoint % sa2p::Q == 0) ? 1 : 0;
-    MPX_LDS_LIMIT_ONCE(sa2_fp32_persistent_kernel, sa2p::LDS_BYTES, "mpx_sa_mlp_factored");
-    unsigned int *queue = mpx_next_unit_queue(mpx_s(stream));
-    MPX_REQUIRE(queue != nullptr, "mpx_sa_mlp_factored: cannot reset the unit queue");
-    hipLaunchKernelGGL(sa2_fp32_persistent_kernel, dim3(grid), dim3(64 * sa2p::WV), sa2p::LDS_BYTES, mpx_s(stream), idx, cnt, nq,
-                       N, npoint, nsample, wpack, out, out_stride, pre, ctr, xcd_aware, queue);
-    MPX_LAUNCH_CHECK("mpx_sa_mlp_factored");
-  }
   if (nq >= 1024 * 8) go(std::integral_constant<int, 8>{});
   else if (nq >= 1024) go(std::integral_constant<int, 2>{});
   else go(std::integral_constant<int, 1>{});  // a handful of problems: one query (1-2 tiles) per wave

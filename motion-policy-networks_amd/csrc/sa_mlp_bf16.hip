@@ -17,6 +17,9 @@
 // split into packed bf16 hi/lo pairs in place and are the next layer's B operand as they are.
 #include "common.h"
 
+#include <mutex>
+#include <unordered_map>
+
 #include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -268,20 +271,17 @@ __device__ __forceinline__ f32x16 bias_tile_lds(const float *bias_lds, int ot, i
 // neighbour, and max-pooling is idempotent) are rounded up to multiples of 4 rows and packed back to
 // back into 32-row tiles.  `order` (optional) lists the queries sorted by row count so that the 8
 // lockstep waves of a workgroup carry (nearly) the same number of tiles; the workgroup runs max(tiles).
-// FACT: the first layer is evaluated per point / per query by the caller (see sa_mlp.hip): the kernel starts at
-// relu(pre[j] - ctr[i]) and walks only the chunks of layers 2 and 3.
-template <int CF, int C1, int C2, int C3, int Q, bool FACT>
+// (The factored form of the second module -- first layer per point / per query -- is the persistent kernel below.)
+template <int CF, int C1, int C2, int C3, int Q>
 __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(2, 2)))
     sa_mlp_bf16_kernel(const float *__restrict__ xyz, int stride, const float *__restrict__ new_xyz, int new_stride,
                        const float *__restrict__ feat, int feat_stride, const int32_t *__restrict__ idx,
                        const int32_t *__restrict__ cnt, const int32_t *__restrict__ order, int64_t n_query, int N,
                        int npoint, int nsample, const unsigned char *__restrict__ wpack, float *__restrict__ out,
-                       int out_stride, const float *__restrict__ pre_rows, const float *__restrict__ ctr) {
+                       int out_stride) {
   using Cfg = BCfg<CF, C1, C2, C3>;
-  constexpr int FIRST = FACT ? Cfg::O2 / G : 0;  // first chunk of the walk
-  static_assert(!FACT || Cfg::O2 % G == 0, "layer 2 must start on a chunk boundary");
+  constexpr int FIRST = 0;  // first chunk of the walk
   __shared__ __attribute__((aligned(16))) unsigned char ring[2 * CHUNK_BYTES + 4 * (C1 + C2) + 64];
-  __shared__ __attribute__((aligned(16))) float ctr_s[FACT ? WAVES * Q * C1 : 4];
   float *bias_lds = reinterpret_cast<float *>(ring + 2 * CHUNK_BYTES);  // [b1 | b2]
   int *tiles_lds = reinterpret_cast<int *>(ring + 2 * CHUNK_BYTES + 4 * (C1 + C2));
   const int lane = threadIdx.x & 63;
@@ -327,12 +327,6 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
   ws.first = FIRST;
   ws.next_cc = FIRST;
   ws.nch = Cfg::NCH;
-  if constexpr (FACT) {  // this wave's per-query terms (lanes 0..31: one float4 of a 128-float row each)
-    for (int i = 0; i < nq; ++i)
-      for (int c4 = lane; c4 < C1 / 4; c4 += 64)
-        *reinterpret_cast<float4 *>(ctr_s + (wave * Q + i) * C1 + 4 * c4) =
-            *reinterpret_cast<const float4 *>(ctr + (int64_t)s_q[i] * C1 + 4 * c4);
-  }
   ws.start();  // (its barrier also publishes the biases and the per-wave row counts)
   int n_rows = 0;
 #pragma unroll
@@ -340,36 +334,23 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
   const float *bias3 = reinterpret_cast<const float *>(wpack + Cfg::B3_OFF);
 
   // row -> (global query id, neighbour index); rows past this wave's end repeat its last query's slot 0
-  int ql_tmp = 0;  // local index (0..Q-1) of the query found by the latest map_row
   auto map_row = [&](int p, int &qg, int &nb_off) {
     int qpre = 0, qcnt = s_cnt[0];
     qg = s_q[0];
-    ql_tmp = 0;
 #pragma unroll
     for (int i = 1; i < Q; ++i) {
       const bool ge = i < nq && p >= s_pre[i];
       qg = ge ? s_q[i] : qg;
-      ql_tmp = ge ? i : ql_tmp;
       qpre = ge ? s_pre[i] : qpre;
       qcnt = ge ? s_cnt[i] : qcnt;
     }
     const int slot = p - qpre;
     nb_off = slot < qcnt ? slot : 0;
   };
-  float raw_pre[FACT ? C1 / 2 : 1];  // FACT: this lane-half's 4-channel groups of the point's first-layer row
   auto gather = [&](RawIn<CF> &raw, int qg, int k) {
     const int64_t b = qg / npoint;
-    if constexpr (FACT) {
-      const float *pa = pre_rows + (b * N + k) * (int64_t)C1 + 4 * half;
-#pragma unroll
-      for (int i = 0; i < C1 / 8; ++i) {
-        const float4 v = *reinterpret_cast<const float4 *>(pa + 8 * i);
-        raw_pre[4 * i + 0] = v.x, raw_pre[4 * i + 1] = v.y, raw_pre[4 * i + 2] = v.z, raw_pre[4 * i + 3] = v.w;
-      }
-    } else {
-      raw.load(xyz + (b * N + k) * (int64_t)stride, new_xyz + (int64_t)qg * new_stride,
-               feat + (b * N + k) * (int64_t)feat_stride, half);
-    }
+    raw.load(xyz + (b * N + k) * (int64_t)stride, new_xyz + (int64_t)qg * new_stride,
+             feat + (b * N + k) * (int64_t)feat_stride, half);
   };
 
   float run[Cfg::OT3];  // running max of the query being merged, per output tile (this lane's half of the rows)
@@ -390,44 +371,24 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
 
   // gather pipeline: neighbour index one tile ahead (issued at tile start), neighbour data issued in layer 3
   RawIn<CF> raw;
-  int q_cur, q_next = 0, k_next = 0, ql_cur = 0, ql_next = 0;
+  int q_cur, q_next = 0, k_next = 0;
   {
     int off;
     map_row(col, q_cur, off);
-    ql_cur = ql_tmp;
     const int k0 = idx[(int64_t)q_cur * nsample + off];
     gather(raw, q_cur, k0);
     if (n_rows > 32) {
       map_row(32 + col, q_next, off);
-      ql_next = ql_tmp;
       k_next = idx[(int64_t)q_next * nsample + off];
     }
   }
 
   for (int rt = 0; rt < n_rows; rt += 32) {
-    // ---- layer-1 operands from the prefetched row, split hi/lo (direct form only) ---------------------------
-    bf16x8 xh[FACT ? 1 : Cfg::KS0], xl[FACT ? 1 : Cfg::KS0];
+    // ---- layer-1 operands from the prefetched row, split hi/lo -------------------------------------------------
+    bf16x8 xh[Cfg::KS0], xl[Cfg::KS0];
     f32x16 a1[Cfg::OT1], a2[Cfg::OT2];
     bf16x8 h1[Cfg::OT1][2], l1[Cfg::OT1][2];
-    if constexpr (FACT) {
-      // register r of tile ot = channel 32*ot + 8*(r>>2) + 4*half + (r&3) = group i = 4*ot + (r>>2) of raw_pre;
-      // the layer-2 operands (hi/lo bf16) are formed right here, one tile at a time: no fp32 tile stays alive
-      const float *cq = ctr_s + (wave * Q + ql_cur) * C1 + 4 * half;
-#pragma unroll
-      for (int ot = 0; ot < Cfg::OT1; ++ot) {
-        f32x16 t;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int i = 4 * ot + g;
-          const float4 c = *reinterpret_cast<const float4 *>(cq + 8 * i);
-          t[4 * g + 0] = raw_pre[4 * i + 0] - c.x;
-          t[4 * g + 1] = raw_pre[4 * i + 1] - c.y;
-          t[4 * g + 2] = raw_pre[4 * i + 2] - c.z;
-          t[4 * g + 3] = raw_pre[4 * i + 3] - c.w;
-        }
-        relu_split_tile(t, h1[ot], l1[ot]);
-      }
-    } else {
+    {
       float v[8 * Cfg::KS0];
 #pragma unroll
       for (int i = 0; i < 8 * Cfg::KS0; ++i) v[i] = 0.0f;
@@ -451,23 +412,19 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
     const int q_tile = q_cur;  // query of this lane's row in the tile being computed
     const int q_gather = q_next, k_gather = k_next;
     q_cur = q_next;
-    ql_cur = ql_next;
     if (rt + 64 < n_rows) {  // index of the row after next: issued now, consumed a tile later
       int off;
       map_row(rt + 64 + col, q_next, off);
-      ql_next = ql_tmp;
       k_next = idx[(int64_t)q_next * nsample + off];
     }
     // The next tile's row data is fetched inside the chunk walk below, at the first chunk of layer 3
     // (register pressure peaks in layer 2; layer 3 is long enough to cover the latency).
-    constexpr int GATHER_CHUNK = Cfg::O3 / G + (FACT ? 1 : 0);  // FACT: one chunk later, when the layer-2 accumulators are gone
+    constexpr int GATHER_CHUNK = Cfg::O3 / G;
 
     bf16x8 h2[Cfg::OT2][2], l2[Cfg::OT2][2];
     f32x16 a3[Cfg::OPC][2];
-    if constexpr (!FACT) {
 #pragma unroll
-      for (int ot = 0; ot < Cfg::OT1; ++ot) a1[ot] = bias_tile_lds(bias_lds, ot, half);
-    }
+    for (int ot = 0; ot < Cfg::OT1; ++ot) a1[ot] = bias_tile_lds(bias_lds, ot, half);
 
 #pragma unroll
     for (int c = FIRST; c < Cfg::NCH; ++c) {
@@ -483,7 +440,7 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
         if (!Cfg::is_real(st)) continue;
         if (st >= Cfg::O2 && st < Cfg::O3) {  // layer 2, first use of input tile s>>1 (ot == 0, even s)
           const int q = st - Cfg::O2, s = q / Cfg::OT2, ot = q % Cfg::OT2;
-          if (!FACT && ot == 0 && (s & 1) == 0) relu_split_tile(a1[s >> 1], h1[s >> 1], l1[s >> 1]);
+          if (ot == 0 && (s & 1) == 0) relu_split_tile(a1[s >> 1], h1[s >> 1], l1[s >> 1]);
         } else if (st >= Cfg::O3) {            // layer 3, first output tile walks the input tiles in order
           const int q = st - Cfg::O3, s = q % Cfg::KS2, ot = q / Cfg::KS2;
           if (ot == 0 && (s & 1) == 0) relu_split_tile(a2[s >> 1], h2[s >> 1], l2[s >> 1]);
@@ -495,7 +452,7 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
       }
       // operands are fetched SUB step-tiles at a time (register budget); within a sub-group three passes
       // (hi*hi, lo*hi, hi*lo) so that consecutive MFMAs hit different accumulators
-      constexpr int SUB = FACT ? 1 : 4;
+      constexpr int SUB = 4;
 #pragma unroll
       for (int g0 = 0; g0 < G; g0 += SUB) {
         bf16x8 wh[SUB], wl[SUB];
@@ -510,10 +467,8 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
             if (!Cfg::is_real(st)) continue;
             const bf16x8 w = pass == 1 ? wl[j] : wh[j];
             if (st < Cfg::O2) {
-              if constexpr (!FACT) {
-                const int s = st / Cfg::OT1, ot = st % Cfg::OT1;
-                a1[ot] = mfma_bf16(w, pass == 2 ? xl[s] : xh[s], a1[ot]);
-              }
+              const int s = st / Cfg::OT1, ot = st % Cfg::OT1;
+              a1[ot] = mfma_bf16(w, pass == 2 ? xl[s] : xh[s], a1[ot]);
             } else if (st < Cfg::O3) {
               const int q = st - Cfg::O2, s = q / Cfg::OT2, ot = q % Cfg::OT2;
               a2[ot] = mfma_bf16(w, pass == 2 ? l1[s >> 1][s & 1] : h1[s >> 1][s & 1], a2[ot]);
@@ -871,6 +826,42 @@ static_assert(Cfg::ST2 == 32 && Cfg::ST3 == 64 && Cfg::KS1 == 8 && Cfg::KS2 == 8
 
 #define V2_FENCE() __builtin_amdgcn_sched_barrier(0)
 
+// Unit queues of the persistent kernel: 8 counters (one per XCD) per launch, in device memory that belongs to the
+// library image (nothing is allocated).  ONE SLOT PER (device, stream): the launches of a stream are ordered (memset,
+// kernel, memset, kernel, ...), so they can share a slot, and launches on different streams never alias -- two engines
+// that share a model on two streams (rollout.PipelinedRollout) each get their own counters.  The slot is zeroed on the
+// launch stream in front of the kernel (stream-ordered, hipGraph-capturable).  Limits, stated in include/mpinets_hip.h:
+// 256 distinct streams per process use distinct slots (later ones share by hash); a captured graph bakes its capture
+// stream's slot in, so two graphs captured on the SAME stream must not be replayed concurrently on different streams.
+__device__ unsigned int sa2_unit_queues[256 * 8];
+static unsigned int *unit_queue_for(hipStream_t stream) {
+  static std::mutex mu;
+  static std::unordered_map<unsigned long long, int> slot_of;  // (device << 56) ^ stream handle -> slot
+  static unsigned int *base[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  unsigned int *q;
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    unsigned int *&b = base[dev & 63];
+    if (!b) {
+      void *p = nullptr;
+      if (hipGetSymbolAddress(&p, HIP_SYMBOL(sa2_unit_queues)) != hipSuccess) return nullptr;
+      b = static_cast<unsigned int *>(p);
+    }
+    const unsigned long long key = ((unsigned long long)(dev & 63) << 56) ^ (unsigned long long)(uintptr_t)stream;
+    auto it = slot_of.find(key);
+    if (it == slot_of.end()) {
+      const int n = (int)slot_of.size();
+      const int slot = n < 256 ? n : (int)((key * 0x9E3779B97F4A7C15ull) >> 56);
+      it = slot_of.emplace(key, slot).first;
+    }
+    q = b + 8 * it->second;
+  }
+  if (hipMemsetAsync(q, 0, 8 * sizeof(unsigned int), stream) != hipSuccess) return nullptr;
+  return q;
+}
+
 __global__ void __launch_bounds__(64 * v2::WV) __attribute__((amdgpu_waves_per_eu(1, 1)))
     sa2_bf16x3_persistent_kernel(const int32_t *__restrict__ idx, const int32_t *__restrict__ cnt, int64_t n_query, int N,
                                  int npoint, int nsample, const unsigned char *__restrict__ wpack, float *__restrict__ out,
@@ -1173,10 +1164,10 @@ __global__ void __launch_bounds__(64 * v2::WV) __attribute__((amdgpu_waves_per_e
     return 1;                                                                               \
   }
 
-// 1 (default): the weight-resident kernel for the modules whose pack fits LDS; 0: the lockstep kernel everywhere
-static int bf16_resident() {
-  static const int v = getenv("MPX_BF16_RESIDENT") ? atoi(getenv("MPX_BF16_RESIDENT")) : 1;
-  return v;
+// Which kernel serves mpx_sa_mlp_bf16x3: the weight-resident one for the first module (pack fits LDS) up to 128 slots
+// per neighbourhood, the lockstep one otherwise.  ONE predicate for the launcher and for mpx_sa_mlp_bf16x3_wants_order.
+static bool bf16_uses_resident(int C, int c1, int c2, int c3, int nsample) {
+  return C == 1 && c1 == 64 && c2 == 64 && c3 == 64 && nsample <= 128;
 }
 
 template <int CF, int C1, int C2, int C3>
@@ -1188,7 +1179,7 @@ static int launch_sa_bf16(const float *xyz, int stride, const float *new_xyz, in
   MPX_REQUIRE(nq < ((int64_t)1 << 31), "mpx_sa_mlp_bf16x3: too many query points");
   constexpr int Q = CF == 1 ? 16 : 4;  // queries per wave
   if constexpr (CF == 1) {
-    if (bf16_resident() && nsample <= 128) {  // (walks the queries in their natural order: `order` is not needed)
+    if (bf16_uses_resident(CF, C1, C2, C3, nsample)) {  // (walks the queries in their natural order: `order` is not needed)
       const int64_t per_wg = (int64_t)res::WV * Q;
       const int wpe = (npoint % per_wg == 0 && B % 8 == 0) ? (int)(npoint / per_wg) : 0;
       const int row16 = (feat == xyz + 3 && stride == 4 && feat_stride == 4 && ((uintptr_t)xyz & 15) == 0) ? 1 : 0;
@@ -1207,19 +1198,15 @@ static int launch_sa_bf16(const float *xyz, int stride, const float *new_xyz, in
   }
   MPX_REQUIRE(!append_centre, "mpx_sa_mlp_bf16x3: append_centre is implemented by the weight-resident kernel only");
   const int64_t per_block = (int64_t)WAVES * Q;
-  hipLaunchKernelGGL((sa_mlp_bf16_kernel<CF, C1, C2, C3, Q, false>), dim3((unsigned)((nq + per_block - 1) / per_block)),
+  hipLaunchKernelGGL((sa_mlp_bf16_kernel<CF, C1, C2, C3, Q>), dim3((unsigned)((nq + per_block - 1) / per_block)),
                      dim3(64 * WAVES), 0, mpx_s(stream), xyz, stride, new_xyz, new_stride, feat, feat_stride, idx, cnt, order, nq, N, npoint, nsample,
-                     static_cast<const unsigned char *>(wpack), out, out_stride, nullptr, nullptr);
+                     static_cast<const unsigned char *>(wpack), out, out_stride);
   MPX_LAUNCH_CHECK("mpx_sa_mlp_bf16x3");
 }
 
-static int bf16_factored_v2() {
-  static const int use_v2 = getenv("MPX_BF16_V2") ? atoi(getenv("MPX_BF16_V2")) : 1;
-  return use_v2;
-}
-
-// 1: the factored kernel walks the queries in the caller's `order` (lockstep variant); 0: it ignores it
-MPX_EXPORT int mpx_sa_mlp_bf16x3_factored_wants_order(void) { return bf16_factored_v2() ? 0 : 1; }
+// The factored form has ONE kernel (persistent, barrier-free, its own device-side unit queue): `order` is never needed.
+// (Kept in the ABI: callers written against version 200 ask before they sort.)
+MPX_EXPORT int mpx_sa_mlp_bf16x3_factored_wants_order(void) { return 0; }
 
 MPX_EXPORT int mpx_sa_mlp_bf16x3_factored(const float *pre, const float *ctr, const int32_t *idx, const int32_t *cnt,
                                           const int32_t *order, int B, int N, int npoint, int nsample, const void *wpack,
@@ -1234,30 +1221,23 @@ MPX_EXPORT int mpx_sa_mlp_bf16x3_factored(const float *pre, const float *ctr, co
   if (B == 0 || npoint == 0) return 0;
   const int64_t nq = (int64_t)B * npoint;
   MPX_REQUIRE(nq < ((int64_t)1 << 31), "mpx_sa_mlp_bf16x3_factored: too many query points");
-  if (bf16_factored_v2()) {  // persistent, barrier-free variant (ignores `order`: no sorting pass is needed)
-    static int cus[64];
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (!cus[dev & 63]) {
-      int n = 0;
-      MPX_REQUIRE(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0,
-                  "mpx_sa_mlp_bf16x3_factored: cannot query the CU count");
-      cus[dev & 63] = n;
-    }
-    const int grid = cus[dev & 63];
-    const int xcd_aware = (B % 8 == 0 && grid % 8 == 0 && npoint % v2::Q == 0) ? 1 : 0;
-    MPX_LDS_LIMIT_ONCE(sa2_bf16x3_persistent_kernel, v2::LDS_BYTES, "mpx_sa_mlp_bf16x3_factored");
-    unsigned int *queue = mpx_next_unit_queue(mpx_s(stream));
-    MPX_REQUIRE(queue != nullptr, "mpx_sa_mlp_bf16x3_factored: cannot reset the unit queue");
-    hipLaunchKernelGGL(sa2_bf16x3_persistent_kernel, dim3(grid), dim3(64 * v2::WV), v2::LDS_BYTES, mpx_s(stream), idx, cnt, nq, N,
-                       npoint, nsample, static_cast<const unsigned char *>(wpack), out, out_stride, pre, ctr, xcd_aware, queue);
-    MPX_LAUNCH_CHECK("mpx_sa_mlp_bf16x3_factored");
+  (void)order;  // the persistent kernel takes its units from a device-side queue: no sorting pass
+  static int cus[64];
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (!cus[dev & 63]) {
+    int n = 0;
+    MPX_REQUIRE(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0,
+                "mpx_sa_mlp_bf16x3_factored: cannot query the CU count");
+    cus[dev & 63] = n;
   }
-  constexpr int Q = 4;
-  const int64_t per_block = (int64_t)WAVES * Q;
-  hipLaunchKernelGGL((sa_mlp_bf16_kernel<64, 128, 128, 256, Q, true>), dim3((unsigned)((nq + per_block - 1) / per_block)),
-                     dim3(64 * WAVES), 0, mpx_s(stream), nullptr, 0, nullptr, 0, nullptr, 0, idx, cnt, order, nq, N, npoint,
-                     nsample, static_cast<const unsigned char *>(wpack), out, out_stride, pre, ctr);
+  const int grid = cus[dev & 63];
+  const int xcd_aware = (B % 8 == 0 && grid % 8 == 0 && npoint % v2::Q == 0) ? 1 : 0;
+  MPX_LDS_LIMIT_ONCE(sa2_bf16x3_persistent_kernel, v2::LDS_BYTES, "mpx_sa_mlp_bf16x3_factored");
+  unsigned int *queue = unit_queue_for(mpx_s(stream));
+  MPX_REQUIRE(queue != nullptr, "mpx_sa_mlp_bf16x3_factored: cannot reset the unit queue");
+  hipLaunchKernelGGL(sa2_bf16x3_persistent_kernel, dim3(grid), dim3(64 * v2::WV), v2::LDS_BYTES, mpx_s(stream), idx, cnt, nq, N,
+                     npoint, nsample, static_cast<const unsigned char *>(wpack), out, out_stride, pre, ctr, xcd_aware, queue);
   MPX_LAUNCH_CHECK("mpx_sa_mlp_bf16x3_factored");
 }
 
@@ -1281,8 +1261,8 @@ MPX_EXPORT int mpx_sa_mlp_bf16x3(const float *xyz, int stride, const float *new_
 
 // 1: mpx_sa_mlp_bf16x3 walks the queries in the caller's `order` for this module (the lockstep kernel: balanced
 // workgroups); 0: it ignores `order` (the weight-resident kernel) -- and only then supports append_centre
-MPX_EXPORT int mpx_sa_mlp_bf16x3_wants_order(int C, int c1, int c2, int c3) {
-  return (C == 1 && c1 == 64 && c2 == 64 && c3 == 64 && bf16_resident()) ? 0 : 1;
+MPX_EXPORT int mpx_sa_mlp_bf16x3_wants_order(int C, int c1, int c2, int c3, int nsample) {
+  return bf16_uses_resident(C, c1, c2, c3, nsample) ? 0 : 1;
 }
 
 MPX_EXPORT int64_t mpx_sa_pack_bf16x3_size(int C, int c1, int c2, int c3) {

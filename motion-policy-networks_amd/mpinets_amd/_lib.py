@@ -46,6 +46,8 @@ PROTOTYPES = {
     "mpx_depth_render": [P, F, F, F, F, I, I, I, P, P, I, P, P, P, I, P, P, I, F, P, P],
     "mpx_depth_select": [P, P, F, F, F, F, I, I, I, I, ctypes.c_uint64, L, P, L, I, P, P],
     "mpx_scene_cloud": [P, P, P, I, P, P, P, P, I, I, I, ctypes.c_uint64, L, P, P, P, P, L, I, I, P],
+    "mpx_set_variant": [I, I],
+    "mpx_get_variant": [I],
     "mpx_fps": [P, I, I, I, I, P, P, I, P],
     "mpx_ball_query": [P, I, P, I, I, I, I, F, I, P, P, P],
     "mpx_sort_queries": [P, L, I, P, P, P],
@@ -57,7 +59,7 @@ PROTOTYPES = {
     "mpx_sa_pack_size": [I, I, I, I],
     "mpx_sa_pack_weights": [P, P, P, P, P, P, I, I, I, I, P, P],
     "mpx_sa_mlp_bf16x3": [P, I, P, I, P, I, I, P, P, P, I, I, I, I, P, I, I, I, P, I, I, P],
-    "mpx_sa_mlp_bf16x3_wants_order": [I, I, I, I],
+    "mpx_sa_mlp_bf16x3_wants_order": [I, I, I, I, I],
     "mpx_sa_pack_bf16x3_size": [I, I, I, I],
     "mpx_sa_pack_bf16x3": [P, P, P, P, P, P, I, I, I, I, P, P],
     "mpx_linear": [P, I, P, P, I, I, I, I, P, I, P],

@@ -32,7 +32,7 @@ ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
 # A handful of problems cannot fill the chip with any single kernel (FPS is ONE workgroup per problem), so below
 # this batch size independent branches of the forward are issued on a second HIP stream: the joint-angle encoder
 # next to the point-cloud encoder, SA2's sampling + ball query next to SA1's ball query + grouped MLP.
-OVERLAP_MAX_BATCH = int(os.environ.get("MPX_OVERLAP_MAX_BATCH", "512"))
+OVERLAP_MAX_BATCH = 512  # (= csrc/policy.hip OVERLAP_MAX_BATCH: the single-call forward makes the same choice)
 _SIDE_STREAMS = {}
 
 
@@ -69,6 +69,9 @@ class MPiNetsPointNet(nn.Module):
         self._sa3_w0 = None  # first group-all layer with K padded 259 -> 272 (whole 16-float slabs: direct-to-LDS GEMM)
         self.dense_precision = "fp32"  # "bf16x3": the large dense layers on the bf16 matrix cores (set_precision)
         self._split = SplitWeights()
+        # bf16x3 only: keep the group-all MLP's activations in the split "pairs" form between layers (default) or as
+        # fp32 rows that every layer splits again on its way in -- bit-identical results (tests), pairs are faster
+        self.dense_through_pairs = True
 
     def _lin(self, x, weight, bias, act=0, out=None, source=None):
         if self.dense_precision == "bf16x3":
@@ -296,7 +299,7 @@ class MPiNetsPointNet(nn.Module):
         # ---- SA3 (group-all): three GEMMs over B*128 rows + max over each environment's rows ------------
         c3 = sa3.convs()
         h = sa3_in.view(B * sa2.npoint, K3)
-        if (self.dense_precision == "bf16x3" and sa2.npoint == 128 and os.environ.get("MPX_BF16_PAIRS", "1") != "0"
+        if (self.dense_precision == "bf16x3" and sa2.npoint == 128 and self.dense_through_pairs
                 and all(c.out_channels % 16 == 0 for c in c3)):
             self.last_counts = (cnt1, cnt2)
             if aux is None and c3[2].out_channels % 16 == 0:  # (aux wants the pooled features as fp32)
@@ -396,20 +399,41 @@ class MotionPolicyNetwork(nn.Module):
         self._q_w0 = None
         return self
 
+    def cache_signature(self) -> tuple:
+        """What the derived weight buffers depend on: the parameters' storage and versions and the arithmetic switches.
+        The buffers are (re)built lazily by kernels on whichever stream first misses them; a caller that runs ONE model
+        on several streams (rollout.PipelinedRollout) compares signatures to know when a rebuild is about to happen and
+        orders the streams around it."""
+        enc = self.point_cloud_encoder
+        return (tuple((p.data_ptr(), p._version) for p in self.parameters()),
+                tuple((sa.precision, getattr(sa, "factored", None)) for sa in enc.SA_modules), enc.dense_precision,
+                tuple(len(sa._packed.packs) for sa in enc.SA_modules), enc._sa3_w0 is None, self._q_w0 is None)
+
     def configure_optimizers(self):
         return torch.optim.Adam(self.parameters(), lr=1e-4)
 
     @classmethod
-    def load_from_checkpoint(cls, path: str, map_location="cpu", **kwargs):
-        """Reads a Lightning ``.ckpt`` (``{'state_dict': ...}``) or a bare state dict
-        (run_inference.py:262).  Real Lightning checkpoints also pickle callback / hyper-parameter objects, which
-        torch >= 2.6's default ``weights_only=True`` refuses: such (trusted, local) files are re-read with
-        ``weights_only=False``, like ``LightningModule.load_from_checkpoint`` does."""
+    def load_from_checkpoint(cls, path: str, map_location="cpu", trust_checkpoint: bool = False, **kwargs):
+        """Reads a Lightning ``.ckpt`` (``{'state_dict': ...}``) or a bare state dict (run_inference.py:262) with
+        ``torch.load(weights_only=True)``: tensors and plain containers only, no code runs.
+
+        Real Lightning checkpoints may also pickle callback / hyper-parameter objects, which the safe loader refuses.
+        Unpickling those executes arbitrary code from the file, so it is opt-in: ``trust_checkpoint=True`` (a local file
+        you produced yourself) re-reads with ``weights_only=False`` like ``LightningModule.load_from_checkpoint`` does.
+        Without it the refusal is raised with that hint; other failures (truncated file, bad device map) are never
+        retried."""
         import pickle
 
         try:
             ckpt = torch.load(path, map_location=map_location, weights_only=True)
-        except (pickle.UnpicklingError, RuntimeError):
+        except pickle.UnpicklingError as e:
+            if not trust_checkpoint:
+                raise pickle.UnpicklingError(
+                    f"{path}: the checkpoint pickles objects beyond tensors ({e}).  If the file is yours, pass "
+                    "trust_checkpoint=True to load it with weights_only=False (this executes code stored in the file).") from e
+            import warnings
+
+            warnings.warn(f"{path}: loading with weights_only=False (trust_checkpoint=True): pickled code in the file runs")
             ckpt = torch.load(path, map_location=map_location, weights_only=False)
         sd = ckpt.get("state_dict", ckpt)
         mdl = cls(**kwargs)

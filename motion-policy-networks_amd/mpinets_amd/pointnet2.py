@@ -221,7 +221,7 @@ def launch_sa(precision: str, xyz_ptr: int, stride: int, new_xyz_ptr: int, new_s
                   _lib.ptr(cnt), B, N, npoint, nsample, _lib.ptr(wpack), c1, c2, c3, out_ptr, out_stride, int(fused))
         return fused
     order = None
-    wants_order = bool(_lib.load().mpx_sa_mlp_bf16x3_wants_order(C, c1, c2, c3))
+    wants_order = bool(_lib.load().mpx_sa_mlp_bf16x3_wants_order(C, c1, c2, c3, nsample))
     if cnt is not None and wants_order:
         order = torch.empty(B * npoint, dtype=torch.int32, device=idx.device)
         scratch = torch.empty(128, dtype=torch.int32, device=idx.device)
@@ -263,12 +263,8 @@ def sa_mlp_factored(point_rows: torch.Tensor, centre_rows: torch.Tensor, idx: to
     if precision == "bf16x3":
         pre = linear_x3(point_rows, wp, None, 0, split, source=convs[0].weight)
         ctr = linear(centre_rows, wc, nb1)  # K = 4: not worth the matrix cores
-        order = None
-        if not _NO_SORT and _lib.load().mpx_sa_mlp_bf16x3_factored_wants_order():
-            order = torch.empty(B * npoint, dtype=torch.int32, device=idx.device)
-            scratch = torch.empty(128, dtype=torch.int32, device=idx.device)
-            _lib.call("mpx_sort_queries", _lib.ptr(cnt), B * npoint, nsample, _lib.ptr(order), _lib.ptr(scratch))
-        _lib.call("mpx_sa_mlp_bf16x3_factored", _lib.ptr(pre), _lib.ptr(ctr), _lib.ptr(idx), _lib.ptr(cnt), _lib.ptr(order),
+        # (the factored kernel is persistent and takes its units from a device-side queue: no sorting pass, order = NULL)
+        _lib.call("mpx_sa_mlp_bf16x3_factored", _lib.ptr(pre), _lib.ptr(ctr), _lib.ptr(idx), _lib.ptr(cnt), None,
                   B, N, npoint, nsample, _lib.ptr(packed.get(convs, C, "bf16x3")), C, c1, c2, c3, out_ptr, out_stride)
         return
     pre = linear(point_rows, wp, None)
@@ -278,9 +274,6 @@ def sa_mlp_factored(point_rows: torch.Tensor, centre_rows: torch.Tensor, idx: to
 
 
 FACTORED_SHAPE = (64, 128, 128, 256)
-import os as _os
-
-_NO_SORT = _os.environ.get("MPX_BF16_NO_SORT") == "1"  # development switch (tools/fast_timing.py A/B runs)
 
 
 # ---- module -------------------------------------------------------------------------------------------

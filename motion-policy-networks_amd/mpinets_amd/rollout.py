@@ -258,10 +258,18 @@ class PipelinedRollout:
         cur = torch.cuda.current_stream(self.device)
         for s in self.streams:
             s.wait_stream(cur)
-        enc = self.engines[0].model.point_cloud_encoder
+        model = self.engines[0].model
+        enc = model.point_cloud_encoder
+        # The shares use ONE model, whose derived weight buffers (MFMA-stream packs, factored SA2 weights, bf16 pairs,
+        # padded first layers) are built lazily by kernels on the stream that first misses them -- share 0's.  The other
+        # shares then hit the host-side cache and would read those buffers on their own streams with nothing ordering
+        # them after the build.  So whenever the model's cache signature is not the one this object last ran with (first
+        # use, optimizer step, set_precision, invalidate_caches ...), every other stream waits for share 0's first whole
+        # step of this call (the stagger is subsumed: a cold start is serialised for one step).
+        cold = model.cache_signature() != getattr(self, "_warm_signature", None)
         for t in range(steps):
             for i, (e, s) in enumerate(zip(self.engines, self.streams)):
-                first = self.stagger and t == 0 and self.steps_done == 0 and i + 1 < self.ways
+                first = self.stagger and not cold and t == 0 and self.steps_done == 0 and i + 1 < self.ways
                 if first:  # share i+1 starts when share i has issued its sampling and entered its matrix kernels
                     ev = torch.cuda.Event()
                     enc.after_sampling = lambda ev=ev: ev.record()
@@ -270,6 +278,12 @@ class PipelinedRollout:
                 if first:
                     enc.after_sampling = None
                     self.streams[i + 1].wait_event(ev)
+                if cold and t == 0 and i == 0:
+                    built = torch.cuda.Event()
+                    built.record(s)
+                    for other in self.streams[1:]:
+                        other.wait_event(built)
+        self._warm_signature = model.cache_signature()
         self.steps_done += steps
         for s in self.streams:
             cur.wait_stream(s)

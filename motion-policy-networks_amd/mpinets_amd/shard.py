@@ -21,26 +21,55 @@ def world() -> Tuple[int, int, int]:
 
 
 def init(backend: Optional[str] = None, device: Optional[torch.device] = None) -> Tuple[int, int, int]:
-    """Join the job torchrun started (no-op for a single process) and make this rank's GPU the current device --
-    for EVERY backend: the engine enqueues on torch's current stream of the current device, so a gloo job that
-    skipped ``set_device`` would put every rank's kernels on device 0.  ``device`` defaults to
-    ``cuda:LOCAL_RANK``.  Backend: RCCL ("nccl") when GPUs are present, gloo otherwise; ``MPX_DIST_BACKEND``
-    overrides (tests run 2 ranks on one GPU with gloo)."""
+    """Join the job torchrun started and make this rank's GPU the current device -- for EVERY backend: the engine
+    enqueues on torch's current stream of the current device, so a gloo job that skipped ``set_device`` would put every
+    rank's kernels on device 0.  Backend: RCCL ("nccl") when GPUs are present, gloo otherwise; ``MPX_DIST_BACKEND``
+    overrides.
+
+    ``device`` defaults to ``cuda:LOCAL_RANK``.  RCCL needs one device per rank: with fewer visible GPUs than local ranks
+    an "nccl" job fails here with a clear message.  A gloo job may share GPUs (tests run 2 ranks on the box's one GPU):
+    its default device is ``cuda:(LOCAL_RANK mod device_count)``.
+
+    A single process (WORLD_SIZE 1) does not create a process group -- unless ``MPX_DIST_FORCE=1``: then the group is
+    created anyway (world size 1), so that barrier / max_over_ranks / gather_to_rank0 run on a REAL communicator
+    (tests/test_gpu_shard.py exercises the RCCL calls of ``bench.py --gpus N`` on a one-GPU box this way)."""
     rank, ws, local = world()
+    backend = backend or os.environ.get("MPX_DIST_BACKEND")
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
     if torch.cuda.is_available():
-        device = torch.device("cuda", local) if device is None else torch.device(device)
+        ndev = torch.cuda.device_count()
+        if device is None:
+            if local >= ndev and backend == "nccl":
+                raise RuntimeError(f"shard.init: LOCAL_RANK {local} but only {ndev} GPU(s) visible -- RCCL needs one device "
+                                   "per rank (share GPUs only with backend='gloo')")
+            device = torch.device("cuda", local % ndev)
+        else:
+            device = torch.device(device)
         torch.cuda.set_device(device)
-    if ws > 1 and not dist.is_initialized():
+    force = os.environ.get("MPX_DIST_FORCE") == "1"
+    if (ws > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        backend = backend or os.environ.get("MPX_DIST_BACKEND")
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
         kwargs = {}
         if backend == "nccl":
             kwargs["device_id"] = device
         dist.init_process_group(backend, rank=rank, world_size=ws, **kwargs)
     return rank, ws, local
+
+
+def backend_name() -> Optional[str]:
+    """"nccl" (= RCCL on ROCm) / "gloo" of the live process group, None for a plain single process."""
+    return dist.get_backend() if dist.is_initialized() else None
+
+
+def gather_objects(obj) -> list:
+    """Small picklable per-rank records (device name, per-rank timings) -> the list over ranks, on every rank."""
+    if not dist.is_initialized():
+        return [obj]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, obj)
+    return out
 
 
 def env_range(rank: int, world_size: int, envs_per_rank: int) -> range:
@@ -66,7 +95,9 @@ def barrier() -> None:
 
 def _comm_device(device=None):
     """Collectives run on the GPU with RCCL and on the host with gloo."""
-    return device if dist.get_backend() == "nccl" else torch.device("cpu")
+    if dist.get_backend() != "nccl":
+        return torch.device("cpu")
+    return torch.device("cuda", torch.cuda.current_device()) if device is None else device
 
 
 def max_over_ranks(value: float, device=None) -> float:

@@ -229,24 +229,3 @@ def test_ball_query_bucketed_ragged_query_counts(oracle, N, npoint, nsample):
     np.testing.assert_array_equal(cnt.cpu().numpy(), rcnt)
     np.testing.assert_array_equal(idx.cpu().numpy(), ridx)
     assert rcnt.max() == nsample and rcnt.min() >= 1
-
-
-def test_sampling_kernels_equal_the_plain_kernels_on_the_bench_scenes():
-    """1024 mixed bench environments through the policy forward with the culled FPS, the wave-per-query and the bucketed
-    ball query (defaults) and with the plain kernels (environment switches, read once per process: two subprocesses):
-    every index tensor and the policy output agree bit for bit."""
-    import os
-    import re
-    import subprocess
-    import sys
-
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = {}
-    for v in ("1", "0"):
-        r = subprocess.run([sys.executable, os.path.join(root, "tools", "sampling_ab.py"), "1024"],
-                           env=dict(os.environ, MPX_FPS_CULL=v, MPX_BQ_WAVE=v, MPX_BQ_GRID=v), capture_output=True, text=True,
-                           timeout=600)
-        assert r.returncode == 0, r.stderr[-2000:]
-        out[v] = re.findall(r"(?:fps_idx1|ball_idx1|ball_cnt1|fps_idx2|ball_idx2|ball_cnt2|dq) ([0-9a-f]{16})", r.stdout)
-        assert len(out[v]) == 7, r.stdout
-    assert out["0"] == out["1"], out

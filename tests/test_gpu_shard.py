@@ -105,3 +105,84 @@ def test_pipelined_rollout_equals_single_engine():
     torch.cuda.synchronize()
     assert torch.equal(pr.q, one.q) and torch.equal(pr.q_norm, one.q_norm) and torch.equal(pr.flags, one.flags)
     assert torch.equal(prob["xyz"], one.xyz)  # the shares are views of the caller's slab: updated in place
+
+
+def test_pipelined_rollout_on_a_cold_model():
+    """the shares of a PipelinedRollout use ONE model whose derived weight buffers are built by kernels on
+    share 0's stream.  With a model nobody has run yet (and again after set_precision / an in-place weight update) the
+    other shares must not read those buffers before they are built: first use == a single engine on a twin model."""
+    from mpinets_amd.model import MotionPolicyNetwork
+    from mpinets_amd.rollout import PipelinedRollout, RolloutEngine
+    from mpinets_amd.scenes import make_problem_batch
+
+    dev = torch.device("cuda:0")
+    B = 2080
+    mk = lambda: make_problem_batch(B, seed=13, device=dev, kinds=("tabletop", "cubby", "dresser"), M1=40, M2=16, scene_pool=64,
+                                    device_clouds=True)
+    torch.manual_seed(3)
+    cold = MotionPolicyNetwork().to(dev).eval()  # never run: every pack / pad is missing
+    torch.manual_seed(3)
+    twin = MotionPolicyNetwork().to(dev).eval()
+    pr = PipelinedRollout(cold, mk(), ways=2, rerender_scene=True, scene_seed=4)
+    pr.run(2)
+    one = RolloutEngine(twin, mk(), rerender_scene=True, scene_seed=4)
+    one.step(), one.step()
+    torch.cuda.synchronize()
+    assert torch.equal(pr.q, one.q) and torch.equal(pr.flags, one.flags)
+    # caches go cold again: precision switch, then an optimizer-like in-place update
+    for mdl in (cold, twin):
+        mdl.set_precision("bf16x3")
+    pr.run(1), one.step()
+    with torch.no_grad():
+        for mdl in (cold, twin):
+            mdl.point_cloud_encoder.SA_modules[1].convs()[1].weight.mul_(1.25)
+    pr.run(1), one.step()
+    torch.cuda.synchronize()
+    assert torch.equal(pr.q, one.q) and torch.equal(pr.flags, one.flags)
+
+
+def test_bench_distributed_path_on_a_real_rccl_communicator():
+    """`bench.py`'s N > 1 code path -- shard.init -> init_process_group("nccl", device_id=...), barrier, MAX all-reduce,
+    gather_to_rank0, all_gather_object -- executed on a REAL RCCL communicator: one rank under torch.distributed.run with
+    the process group forced for world size 1 (MPX_DIST_FORCE=1).  The box has one GPU, so this is every RCCL call of the
+    8-GPU run except the inter-GPU transport itself.  The JSON must say so itself (rccl_ranks, per-rank records).
+    Reference launcher: mpinets/run_training.py:71-77 (one process per GPU under DDP)."""
+    import json
+
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, MPX_DIST_FORCE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("MPX_DIST_BACKEND", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "1", "--envs", "1040", "--steps", "2",
+           "--warmup", "1", "--extra", "0", "--fast-steps", "1", "--pipeline-steps", "0", "--cpu-envs", "0", "--scene-pool", "64"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["dist_backend"] == "nccl" and out["rccl_ranks"] == 1 and out["n_gpus"] == 1
+    rec = out["ranks"]
+    assert len(rec) == 1 and rec[0]["rank"] == 0 and rec[0]["device"] == "cuda:0" and rec[0]["env_ids"] == [0, 1040]
+    assert "MI3" in rec[0]["device_name"] or "gfx" in rec[0]["gcn_arch"], rec
+    assert abs(rec[0]["ms_per_step"] - out["ms_per_step"]) <= 0.05 * out["ms_per_step"] + 0.5  # MAX over one rank
+    assert out["value"] > 0 and out["result_check"]["gathered_q"] == [1040, 7]
+    assert out["fast_mode"]["value"] > 0
+
+
+def test_shard_init_device_defaults(monkeypatch):
+    """shard.init(): a gloo rank whose LOCAL_RANK exceeds the device count shares a GPU (device = LOCAL_RANK mod count);
+    an RCCL rank in the same position fails with a clear message instead of 'invalid device ordinal'."""
+    from mpinets_amd import shard
+
+    ndev = torch.cuda.device_count()
+    monkeypatch.setenv("LOCAL_RANK", str(ndev))  # one past the last device
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.delenv("MPX_DIST_FORCE", raising=False)
+    prev = torch.cuda.current_device()
+    try:
+        shard.init(backend="gloo")
+        assert torch.cuda.current_device() == 0
+        with pytest.raises(RuntimeError, match="RCCL needs one device per rank"):
+            shard.init(backend="nccl")
+    finally:
+        torch.cuda.set_device(prev)

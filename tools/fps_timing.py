@@ -1,4 +1,4 @@
-"""FPS timing at the model's sizes (development aid). usage: fps_timing.py [B] [npoint]"""
+"""FPS timing at the model's sizes, fast kernels (variant 1) and plain kernels (variant 0). usage: fps_timing.py [B] [npoint]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "motion-policy-networks_amd")]
@@ -14,10 +14,13 @@ idx = torch.empty((B, NP), dtype=torch.int32, device=dev)
 nx = torch.empty((B, NP, 3), device=dev)
 def run():
     _lib.call("mpx_fps", _lib.ptr(xyz), B, 6272, 4, NP, _lib.ptr(idx), _lib.ptr(nx), 3)
-for _ in range(2): run()
-torch.cuda.synchronize()
-e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-e0.record()
-for _ in range(5): run()
-e1.record(); torch.cuda.synchronize()
-print(f"MPX_FPS_CULL={os.environ.get('MPX_FPS_CULL','1')}: fps 6272->{NP}, B={B}: {e0.elapsed_time(e1)/5:.3f} ms  checksum {int(idx.sum())}")
+for variant in (1, 0):
+    _lib.load().mpx_set_variant(0, variant)
+    for _ in range(2): run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5): run()
+    e1.record(); torch.cuda.synchronize()
+    print(f"variant {variant}: fps 6272->{NP}, B={B}: {e0.elapsed_time(e1)/5:.3f} ms  checksum {int(idx.sum())}")
+_lib.load().mpx_set_variant(0, 1)
