@@ -455,6 +455,14 @@ int64_t mpx_policy_workspace(int B, int N);
 int mpx_policy_forward(const mpx_policy_weights *w, const float *xyz, int N, const float *q, int B,
                        float *dq, void *workspace, int64_t workspace_bytes, mpx_stream_t stream);
 
+/* Per-call robot-point subset.  robofin's FrankaSampler.sample redraws np.random.choice(P, num_points, replace=False) on
+ * EVERY call, ONE subset shared by the batch (call sites mpinets/model.py:170-181, run_inference.py:188-189); NumPy's
+ * global RNG cannot be reproduced on a device, so the distribution is what is kept: out int32 [n_out] <- n_out of the
+ * `total` table rows, uniformly without replacement, in uniform order (row i keyed by Philox4x32-10 with counter
+ * (i >> 2, draw, 11, 0) and key `seed`; the n_out smallest (key, row) pairs in that order).  n_out <= 4096.  Depends on
+ * (seed, draw) only: every rank of a sharded batch draws the same subset, like one process would.                 */
+int mpx_draw_subset(int total, int n_out, uint64_t seed, int draw, int32_t *out, mpx_stream_t stream);
+
 /* ---- closed-loop steps in one call: TrainingMotionPolicyNetwork.rollout's loop body (model.py:160-181) plus the
  * collision check of validation_step (model.py:293-314), i.e. what mpinets_amd.rollout.RolloutEngine.step() does
  * with a static scene:  dq = policy(xyz, q_norm);  q_norm = clamp(q_norm + dq, -1, 1);  q = unnormalise(q_norm);
@@ -502,6 +510,12 @@ typedef struct mpx_rollout_options {
    * this call (row 0 is normally the caller's start configuration, so the first call passes trajectory_row = 1)  */
   float *trajectory;
   int trajectory_len, trajectory_row;
+  /* per-step robot-point subset (subset_table_size = 0: off, the scene's fixed `subset` is used): before the FK cloud
+   * refresh of step s, subset_buf (int32 [n_robot], caller's device buffer) <- mpx_draw_subset(subset_table_size,
+   * n_robot, subset_seed, s) and the refresh writes THOSE table rows -- the reference's per-call redraw.         */
+  int subset_table_size;
+  uint64_t subset_seed;
+  int32_t *subset_buf;
 } mpx_rollout_options;
 
 /* workspace bytes (256-byte aligned) of mpx_rollout / mpx_rollout_step */

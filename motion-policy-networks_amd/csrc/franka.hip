@@ -14,6 +14,8 @@
 // threads stream table points through them.
 #include "common.h"
 #include "sdf_device.h"
+#include "philox.h"
+#include "select_device.h"
 
 constexpr int FRAME_FLOATS = MPX_NUM_FRAMES * 12;  // 180
 
@@ -176,6 +178,78 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// Per-environment form (the default whenever M1, M2 <= 64): a workgroup owns ONE environment and a chunk of up to
+// COL_TC of its waypoints, so everything that depends on the environment alone is done once:
+//   * the zero-volume masks of its primitives become two 64-bit wave-uniform words (a ballot over lanes = primitives);
+//     the evaluation loops walk the SET bits only (s_ff1 / clear lowest bit), and an unmasked primitive's frame and
+//     sizes arrive through scalar loads as SGPR operands -- a masked row costs nothing, not even a compare;
+//   * FK runs once per waypoint (lanes of the first wave), frames parked in LDS;
+//   * the (waypoint, sphere) pairs of the chunk are FLATTENED over the lanes: 50 x 56 pairs fill 43.75 waves instead
+//     of 50 waves that each idle 8 of 64 lanes.
+// Arithmetic per (sphere, primitive) and the order of the minima are those of franka_collision_kernel: bit-identical.
+constexpr int COL_TC = 64;
+
+template <int BLOCK>
+__global__ void __launch_bounds__(BLOCK)
+    franka_collision_env_kernel(const float *__restrict__ q, int T, int chunks, float finger, const float *__restrict__ sc,
+                                const float *__restrict__ sr, const int32_t *__restrict__ sl, int S,
+                                const float *__restrict__ cub_f, const float *__restrict__ cub_d, int M1,
+                                const float *__restrict__ cyl_f, const float *__restrict__ cyl_r,
+                                const float *__restrict__ cyl_h, int M2, int32_t *__restrict__ flags,
+                                float *__restrict__ min_sdf) {
+  extern __shared__ float lds[];  // nt x FRAME_FLOATS
+  const int b = blockIdx.x / chunks, t0 = (blockIdx.x - b * chunks) * COL_TC;  // (block-uniform)
+  const int nt = min(COL_TC, T - t0);
+  const int lane = threadIdx.x & 63;
+  if ((int)threadIdx.x < nt) {
+    float qq[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) qq[j] = q[((size_t)b * T + t0 + threadIdx.x) * 7 + j];
+    franka_fk_frames(qq, finger, lds + threadIdx.x * FRAME_FLOATS);
+  }
+  const float *cf = cub_f + (size_t)b * M1 * 16;
+  const float *cd = cub_d + (size_t)b * M1 * 3;
+  const float *yf = cyl_f + (size_t)b * M2 * 16;
+  const float *yr = cyl_r + (size_t)b * M2;
+  const float *yh = cyl_h + (size_t)b * M2;
+  // live-primitive masks: lane m tests primitive m (every wave computes the same two words)
+  bool clive = false, ylive = false;
+  if (lane < M1) clive = !(mpx_is_zero(cd[3 * lane + 0]) || mpx_is_zero(cd[3 * lane + 1]) || mpx_is_zero(cd[3 * lane + 2]));
+  if (lane < M2) ylive = !(mpx_is_zero(yr[lane]) || mpx_is_zero(yh[lane]));
+  const unsigned long long cmask = __builtin_amdgcn_ballot_w64(clive), ymask = __builtin_amdgcn_ballot_w64(ylive);
+  __syncthreads();
+  const int npairs = nt * S;
+  const int dq = BLOCK / S, dr = BLOCK - dq * S;  // a step of BLOCK pairs = dq waypoints + dr spheres
+  int t = (int)threadIdx.x / S, s = (int)threadIdx.x - t * S;
+  bool any_hit = false;
+  for (int p0 = 0; p0 < npairs; p0 += BLOCK) {  // (block-uniform trip count)
+    const bool on = p0 + (int)threadIdx.x < npairs;
+    const int tt = on ? t : 0, ss = on ? s : 0;
+    float x, y, z;
+    rigid_apply(lds + tt * FRAME_FLOATS + 12 * sl[ss], sc[3 * ss + 0], sc[3 * ss + 1], sc[3 * ss + 2], x, y, z);
+    float best = __builtin_inff();
+    for (unsigned long long m = cmask; m; m &= m - 1) {
+      const int i = __builtin_ctzll(m);  // wave-uniform: the frame and the sizes are scalar loads
+      const float v = cuboid_sdf_live(cf + 16 * i, cd[3 * i + 0], cd[3 * i + 1], cd[3 * i + 2], x, y, z);
+      best = v < best ? v : best;
+    }
+    float besty = __builtin_inff();
+    for (unsigned long long m = ymask; m; m &= m - 1) {
+      const int i = __builtin_ctzll(m);
+      const float v = cylinder_sdf_live(yf + 16 * i, yr[i], yh[i], x, y, z);
+      besty = v < besty ? v : besty;
+    }
+    best = fminf(best, besty);  // torch.minimum(cuboids, cylinders), model.py:304-307
+    if (on) {
+      if (min_sdf) min_sdf[((size_t)b * T + t0 + tt) * S + ss] = best;
+      any_hit |= best <= sr[ss];  // model.py:309-311
+    }
+    t += dq, s += dr;
+    if (s >= S) s -= S, ++t;
+  }
+  if (__any(any_hit) && lane == 0) atomicOr(flags + b, 1);
+}
+
 MPX_EXPORT int mpx_franka_collision(const float *q, int B, int T, float finger, const float *sph_centers,
                                     const float *sph_radii, const int32_t *sph_link, int S,
                                     const float *cub_frames, const float *cub_dims, int M1,
@@ -185,11 +259,58 @@ MPX_EXPORT int mpx_franka_collision(const float *q, int B, int T, float finger, 
   MPX_REQUIRE(B >= 0 && T >= 0 && S >= 0 && M1 >= 0 && M2 >= 0, "mpx_franka_collision: negative size");
   MPX_REQUIRE((int64_t)B * T < (int64_t)1 << 31, "mpx_franka_collision: B*T overflows int32");
   if (B == 0 || T == 0 || S == 0) return 0;
+  if (M1 <= 64 && M2 <= 64 && S <= 64) {  // per-environment form: masks in two scalar words, pairs flattened over the lanes
+    const int chunks = cdiv(T, COL_TC);
+    const size_t lds = (size_t)min(T, COL_TC) * FRAME_FLOATS * sizeof(float);
+    MPX_REQUIRE((int64_t)B * chunks < (int64_t)1 << 31, "mpx_franka_collision: too many workgroups");
+    if (T * S <= 64)  // one waypoint (the rollout step): one wave per environment
+      hipLaunchKernelGGL(franka_collision_env_kernel<64>, dim3((unsigned)(B * chunks)), dim3(64), lds, mpx_s(stream), q, T,
+                         chunks, finger, sph_centers, sph_radii, sph_link, S, cub_frames, cub_dims, M1, cyl_frames, cyl_radii,
+                         cyl_heights, M2, flags, min_sdf);
+    else
+      hipLaunchKernelGGL(franka_collision_env_kernel<256>, dim3((unsigned)(B * chunks)), dim3(256), lds, mpx_s(stream), q, T,
+                         chunks, finger, sph_centers, sph_radii, sph_link, S, cub_frames, cub_dims, M1, cyl_frames, cyl_radii,
+                         cyl_heights, M2, flags, min_sdf);
+    MPX_LAUNCH_CHECK("mpx_franka_collision");
+  }
   const int G = B * T;
   hipLaunchKernelGGL(franka_collision_kernel, dim3(cdiv(G, COL_PPB)), dim3(256), 0, mpx_s(stream), q, G, T,
                      finger, sph_centers, sph_radii, sph_link, S, cub_frames, cub_dims, M1, cyl_frames,
                      cyl_radii, cyl_heights, M2, flags, min_sdf);
   MPX_LAUNCH_CHECK("mpx_franka_collision");
+}
+
+// ---- per-call robot-point subset ------------------------------------------------------------------------------------
+// robofin's FrankaSampler.sample redraws np.random.choice(P, num_points, replace=False) on EVERY call, one subset for
+// the whole batch (mpinets/model.py:170-181, run_inference.py:188-189).  Device form: row i of the point table gets a
+// Philox key (counter (i >> 2, draw, STREAM_SUBSET, 0), key = seed); the n_out smallest (key, row) pairs are the subset,
+// in key order (uniform without replacement, uniform order).  One workgroup: radix select + counting sort in LDS
+// (select_device.h, shared with the scene and depth draws).  Restated in oracle/mpn_oracle.c orc_draw_subset.
+enum { STREAM_SUBSET = 11 };
+__global__ void __launch_bounds__(SEL_THREADS)
+    draw_subset_kernel(int total, int n_out, uint32_t k0, uint32_t k1, uint32_t draw, int32_t *__restrict__ out) {
+  __shared__ unsigned long long sel[SEL_CAP];
+  __shared__ int hist[2048];
+  __shared__ int s3[3];
+  mpx_select_smallest(
+      total, n_out,
+      [&](int g, uint32_t (&key)[4], bool (&valid)[4]) {
+        const Philox r = philox4x32((uint32_t)g, draw, STREAM_SUBSET, 0u, k0, k1);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) key[u] = r.c[u], valid[u] = 4 * g + u < total;
+      },
+      sel, hist, s3);
+  for (int i = threadIdx.x; i < n_out; i += SEL_THREADS) out[i] = (int32_t)(uint32_t)sel[i];
+}
+
+MPX_EXPORT int mpx_draw_subset(int total, int n_out, uint64_t seed, int draw, int32_t *out, mpx_stream_t stream) {
+  MPX_REQUIRE(draw >= 0, "mpx_draw_subset: negative draw index");
+  MPX_REQUIRE(total >= 1 && n_out >= 1 && n_out <= total, "mpx_draw_subset: need 1 <= n_out <= total (%d of %d)", n_out, total);
+  MPX_REQUIRE(n_out <= SEL_MAX_OUT, "mpx_draw_subset: n_out must be <= %d", SEL_MAX_OUT);
+  MPX_REQUIRE(out, "mpx_draw_subset: NULL output");
+  hipLaunchKernelGGL(draw_subset_kernel, dim3(1), dim3(SEL_THREADS), 0, mpx_s(stream), total, n_out, (uint32_t)seed,
+                     (uint32_t)(seed >> 32), (uint32_t)draw, out);
+  MPX_LAUNCH_CHECK("mpx_draw_subset");
 }
 
 // ---- rollout joint update ------------------------------------------------------------------------

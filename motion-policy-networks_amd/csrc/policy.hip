@@ -297,6 +297,8 @@ MPX_EXPORT int mpx_rollout(const mpx_policy_weights *w, const mpx_rollout_scene 
   MPX_REQUIRE(!opt->trajectory || (opt->trajectory_row >= 0 && opt->trajectory_len >= opt->trajectory_row + opt->steps),
               "mpx_rollout: trajectory rows hold %d waypoints, rows [%d, %d) are written", opt->trajectory_len,
               opt->trajectory_row, opt->trajectory_row + opt->steps);
+  MPX_REQUIRE(opt->subset_table_size == 0 || (opt->subset_buf && opt->subset_table_size >= sc->n_robot),
+              "mpx_rollout: per-step subset needs subset_buf and a table of >= n_robot rows");
   if (B == 0 || opt->steps == 0) return 0;
   const int64_t need = mpx_rollout_workspace(B, N);
   MPX_REQUIRE(workspace && workspace_bytes >= need, "mpx_rollout: workspace of %lld bytes, mpx_rollout_workspace asks for %lld",
@@ -317,7 +319,12 @@ MPX_EXPORT int mpx_rollout(const mpx_policy_weights *w, const mpx_rollout_scene 
     if (opt->target_poses)  // 1 cm / 15 deg early-stop test (run_inference.py:176-187): finished environments freeze
       MPX_TRY(mpx_franka_success(q, opt->target_poses, B, sc->finger, opt->pos_tol, opt->cos_rot_tol, opt->done,
                                  opt->steps_taken, nullptr, nullptr, stream));
-    MPX_TRY(mpx_franka_cloud(q, B, sc->finger, sc->table_pts, sc->table_link, sc->subset, sc->n_robot, xyz, (int64_t)N * 4, 4,
+    const int32_t *subset = sc->subset;
+    if (opt->subset_table_size > 0) {  // the reference redraws the robot-point subset on every sampler call
+      MPX_TRY(mpx_draw_subset(opt->subset_table_size, sc->n_robot, opt->subset_seed, step, opt->subset_buf, stream));
+      subset = opt->subset_buf;
+    }
+    MPX_TRY(mpx_franka_cloud(q, B, sc->finger, sc->table_pts, sc->table_link, subset, sc->n_robot, xyz, (int64_t)N * 4, 4,
                              stream));
     MPX_TRY(mpx_franka_collision(q, B, 1, sc->finger, sc->sph_centers, sc->sph_radii, sc->sph_link, sc->n_spheres,
                                  sc->cub_frames, sc->cub_dims, sc->M1, sc->cyl_frames, sc->cyl_radii, sc->cyl_heights, sc->M2,

@@ -24,10 +24,17 @@ __device__ __forceinline__ void mpx_project(const float *__restrict__ f, float x
   pz = a2 + f[11];
 }
 
+// geometry.py:276-287 for an UNMASKED cuboid (the caller has tested the mask)
+__device__ __forceinline__ float cuboid_sdf_live(const float *__restrict__ f, float dx, float dy, float dz,
+                                                 float x, float y, float z);
 // geometry.py:276-287; masked (zero-volume) cuboid -> +inf
 __device__ __forceinline__ float cuboid_sdf(const float *__restrict__ f, float dx, float dy, float dz,
                                             float x, float y, float z) {
   if (mpx_is_zero(dx) || mpx_is_zero(dy) || mpx_is_zero(dz)) return __builtin_inff();
+  return cuboid_sdf_live(f, dx, dy, dz, x, y, z);
+}
+__device__ __forceinline__ float cuboid_sdf_live(const float *__restrict__ f, float dx, float dy, float dz,
+                                                 float x, float y, float z) {
   float px, py, pz;
   mpx_project(f, x, y, z, px, py, pz);
   float d0 = __builtin_fabsf(px) - dx / 2.0f;
@@ -39,10 +46,17 @@ __device__ __forceinline__ float cuboid_sdf(const float *__restrict__ f, float d
   return outside + inside;
 }
 
-// geometry.py:486-506
+// geometry.py:486-506 for an UNMASKED cylinder
+__device__ __forceinline__ float cylinder_sdf_live(const float *__restrict__ f, float radius, float height,
+                                                   float x, float y, float z);
+// geometry.py:486-506; masked (zero radius or height) -> +inf
 __device__ __forceinline__ float cylinder_sdf(const float *__restrict__ f, float radius, float height,
                                               float x, float y, float z) {
   if (mpx_is_zero(radius) || mpx_is_zero(height)) return __builtin_inff();
+  return cylinder_sdf_live(f, radius, height, x, y, z);
+}
+__device__ __forceinline__ float cylinder_sdf_live(const float *__restrict__ f, float radius, float height,
+                                                   float x, float y, float z) {
   float px, py, pz;
   mpx_project(f, x, y, z, px, py, pz);
   float rho = sqrtf(mpx_fma(py, py, px * px));

@@ -31,6 +31,7 @@ PROTOTYPES = {
     "mpx_pose_cloud": [P, I, P, P, I, P, L, I, P],
     "mpx_franka_spheres": [P, I, F, P, P, I, P, P],
     "mpx_franka_collision": [P, I, I, F, P, P, P, I, P, P, I, P, P, P, I, P, P, P],
+    "mpx_draw_subset": [I, I, ctypes.c_uint64, I, P, P],
     "mpx_joint_step": [P, P, P, I, P, P, P, P],
     "mpx_franka_success": [P, P, I, F, F, F, P, P, P, P, P],
     "mpx_trajectory_metrics": [P, P, P, P, I, I, F, P, P, P, P, P, P, P],

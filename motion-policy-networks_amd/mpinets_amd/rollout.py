@@ -25,12 +25,18 @@ from .robot import FrankaCollisionSampler, FrankaSampler
 class RolloutEngine:
     def __init__(self, model: MotionPolicyNetwork, problem: Dict[str, torch.Tensor], num_robot_points: int = 2048,
                  robot_subset: Optional[torch.Tensor] = None, rerender_scene: bool = False, scene_seed: int = 0,
-                 env_offset: Optional[int] = None):
+                 env_offset: Optional[int] = None, resample_subset: bool = False, subset_seed: int = 0):
         """``rerender_scene``: draw a fresh 4096-point scene cloud from the primitives at the start of every step
         (BASELINE config 5, "closed-loop point-cloud re-render"); default keeps the scene rows of the slab.
         ``env_offset``: global id of this batch's first environment (default: the problem's own ``env_offset`` entry,
         else 0).  The re-render draws are keyed by (``scene_seed``, step, global environment id), so a rank that owns
-        environments [o, o+B) of a sharded batch computes exactly what a single process computes for those rows."""
+        environments [o, o+B) of a sharded batch computes exactly what a single process computes for those rows.
+        ``resample_subset``: redraw the robot cloud's point subset at EVERY step, one draw shared by the batch -- what the
+        reference's loop does (robofin's ``FrankaSampler.sample`` draws ``np.random.choice`` per call: model.py:170-181,
+        run_inference.py:188-189).  The draw happens on the device (``mpx_draw_subset``, keyed by (``subset_seed``,
+        step): no host RNG, no synchronisation, the same subset on every rank of a sharded batch).  Default ``False``:
+        one subset for the whole rollout (a fixed robot sampling pattern: the same distribution at every single step,
+        bit-reproducible FPS indices from step to step)."""
         self.model = model
         dev = problem["xyz"].device
         self.device = dev
@@ -42,6 +48,10 @@ class RolloutEngine:
         self.subset = robot_subset if robot_subset is not None else problem.get("robot_subset")
         if self.subset is None:
             self.subset = self.sampler.draw_subset(num_robot_points)
+        self.resample_subset, self.subset_seed = bool(resample_subset), int(subset_seed)
+        if self.resample_subset:  # own buffer: rewritten every step
+            self.subset = self.subset.to(device=dev, dtype=torch.int32).clone().contiguous()
+            assert self.subset.numel() <= self.sampler.table_pts.size(0)
         self.collision = FrankaCollisionSampler(dev, with_base_link=False)
         self.cuboids = TorchCuboids(problem["cuboid_centers"], problem["cuboid_dims"], problem["cuboid_quats"])
         self.cylinders = TorchCylinders(problem["cylinder_centers"], problem["cylinder_radii"],
@@ -103,6 +113,9 @@ class RolloutEngine:
         if self.done is not None:
             lib.call("mpx_franka_success", lib.ptr(self.q), lib.ptr(self.targets), self.B, self.sampler.finger,
                      self.pos_tol, self.cos_tol, lib.ptr(self.done), lib.ptr(self.steps), None, None)
+        if self.resample_subset:
+            lib.call("mpx_draw_subset", self.sampler.table_pts.size(0), self.subset.numel(), self.subset_seed & (2 ** 64 - 1),
+                     self.steps_done, lib.ptr(self.subset))
         self.sampler.sample_into(self.q, self.xyz, self.subset)
         c = self.collision
         lib.call("mpx_franka_collision", lib.ptr(self.q), self.B, 1, c.finger, lib.ptr(c.centers),
@@ -128,7 +141,8 @@ class RolloutEngine:
                     ("cub_quats", ctypes.c_void_p), ("cyl_centers", ctypes.c_void_p), ("cyl_quats", ctypes.c_void_p),
                     ("target_poses", ctypes.c_void_p), ("pos_tol", ctypes.c_float), ("cos_rot_tol", ctypes.c_float),
                     ("done", ctypes.c_void_p), ("steps_taken", ctypes.c_void_p), ("trajectory", ctypes.c_void_p),
-                    ("trajectory_len", ctypes.c_int), ("trajectory_row", ctypes.c_int)]
+                    ("trajectory_len", ctypes.c_int), ("trajectory_row", ctypes.c_int),
+                    ("subset_table_size", ctypes.c_int), ("subset_seed", ctypes.c_uint64), ("subset_buf", ctypes.c_void_p)]
 
     @torch.no_grad()
     def run_native(self, steps: int = 1, trajectory: Optional[torch.Tensor] = None, trajectory_row: int = 1) -> torch.Tensor:
@@ -159,6 +173,9 @@ class RolloutEngine:
         if self.done is not None:
             opt.target_poses, opt.pos_tol, opt.cos_rot_tol = self.targets.data_ptr(), self.pos_tol, self.cos_tol
             opt.done, opt.steps_taken = self.done.data_ptr(), self.steps.data_ptr()
+        if self.resample_subset:
+            opt.subset_table_size, opt.subset_seed = self.sampler.table_pts.size(0), self.subset_seed & (2 ** 64 - 1)
+            opt.subset_buf = self.subset.data_ptr()
         if trajectory is not None:
             assert trajectory.is_contiguous() and trajectory.dtype == torch.float32 and trajectory.shape[::2] == (self.B, 7)
             opt.trajectory, opt.trajectory_len, opt.trajectory_row = trajectory.data_ptr(), trajectory.size(1), int(trajectory_row)

@@ -853,3 +853,21 @@ ORC_API void orc_depth_select(const float *depth, const float *cam, float fx, fl
   }
   free(keys);
 }
+
+/* Per-call robot-point subset (csrc/franka.hip mpx_draw_subset).  The reference redraws the column subset of the robot
+ * cloud on every sampler(q) call -- robofin's FrankaSampler.sample: np.random.choice(P, num_points, replace=False), ONE
+ * draw shared by the whole batch (call sites mpinets/model.py:170-181, run_inference.py:188-189).  NumPy's global RNG
+ * is not reproducible on a device, so only the DISTRIBUTION is defined: n_out of `total` table rows, uniformly without
+ * replacement, in uniform order.  Engine definition (restated here): row i gets the Philox4x32-10 key
+ * philox(ctr = (i >> 2, draw, 11, 0), key = seed)[i & 3]; the n_out smallest (key, row) pairs win, in that order.     */
+ORC_API void orc_draw_subset(int total, int n_out, uint32_t k0, uint32_t k1, uint32_t draw, int32_t *out) {
+  uint64_t *keys = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)total);
+  for (int i = 0; i < total; ++i) {
+    uint32_t r[4];
+    orc_philox((uint32_t)(i >> 2), draw, 11u, 0u, k0, k1, r);
+    keys[i] = ((uint64_t)r[i & 3] << 32) | (uint32_t)i;
+  }
+  qsort(keys, (size_t)total, sizeof(uint64_t), orc_cmp_u64);
+  for (int i = 0; i < n_out && i < total; ++i) out[i] = (int32_t)(uint32_t)keys[i];
+  free(keys);
+}

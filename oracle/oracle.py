@@ -245,6 +245,14 @@ def depth_select(depth, cam_poses, intr, W, H, n_out: int, seed: int, env_offset
 
 
 # ---------------------------------------------------------------- batch assembly (row N2)
+def draw_subset(total: int, n_out: int, seed: int, draw: int) -> np.ndarray:
+    """Restatement of csrc/franka.hip mpx_draw_subset: n_out of `total` rows, without replacement, in draw order."""
+    out = np.empty(n_out, np.int32)
+    lib().orc_draw_subset(int(total), int(n_out), ctypes.c_uint32(seed & 0xFFFFFFFF), ctypes.c_uint32((seed >> 32) & 0xFFFFFFFF),
+                          ctypes.c_uint32(draw), _p(out))
+    return out
+
+
 def batch_configs(traj, traj_idx, timestep, limits, noise_scale: float = 0.0, seed: int = 0, finger: float = 0.025,
                   sample_offset: int = 0, train: Optional[bool] = None):
     """Restates the joint part of PointCloudBase.get_inputs (data_loader.py:155-185) + the supervision row of

@@ -95,13 +95,16 @@ def test_collision_spheres_grouping(oracle):
     assert FrankaCollisionSampler(dev(), with_base_link=True).num_spheres == 57
 
 
-@pytest.mark.parametrize("B,Tn", [(5, 1), (3, 50), (33, 7)])
-def test_fused_collision_check_matches_oracle(oracle, B, Tn):
+@pytest.mark.parametrize("B,Tn,M1,M2", [(5, 1, 16, 16), (3, 50, 16, 16), (33, 7, 16, 16), (4, 130, 40, 16), (2, 65, 64, 64),
+                                        (3, 9, 70, 16), (2, 1, 16, 65)])
+def test_fused_collision_check_matches_oracle(oracle, B, Tn, M1, M2):
+    """(M1, M2 <= 64: the per-environment kernel -- masks as two scalar words, waypoint chunks of 64, pairs flattened over
+    the lanes; above: the general kernel.  Both are bit-identical in their minima.)"""
     from mpinets_amd.geometry import TorchCuboids, TorchCylinders
     from mpinets_amd.robot import FrankaCollisionSampler
     from mpinets_amd.scenes import linear_trajectories, make_scenes
 
-    scn = make_scenes(B, 11, ("tabletop", "cubby"), 16, 16)
+    scn = make_scenes(B, 11, ("tabletop", "cubby", "dresser") if M1 >= 40 else ("tabletop", "cubby"), M1, M2)
     traj = linear_trajectories(B, Tn, 9)
     cs = FrankaCollisionSampler(dev())
     cub = TorchCuboids(T(scn["cuboid_centers"]), T(scn["cuboid_dims"]), T(scn["cuboid_quats"]))
@@ -141,3 +144,18 @@ def test_joint_step(oracle):
     ref_n = np.clip(qn + dq, -1, 1)
     np.testing.assert_array_equal(a.cpu().numpy(), ref_n)
     np.testing.assert_allclose(b.cpu().numpy(), oracle.unnormalize(ref_n, ft.JOINT_LIMITS_REAL), atol=1e-6)
+
+
+@pytest.mark.parametrize("total,n,seed,draw", [(4096, 2048, 0, 0), (4096, 2048, 12345678901, 49), (100, 100, 3, 1),
+                                               (5000, 1, 7, 2), (4099, 4096, 1, 5), (64, 16, 9, 0)])
+def test_device_subset_draw_equals_oracle(oracle, total, n, seed, draw):
+    """mpx_draw_subset (radix select of the n smallest Philox keys + ordering, one workgroup) == the oracle's
+    sort-all-keys restatement, index for index."""
+    from mpinets_amd import _lib
+
+    out = torch.full((n,), -1, dtype=torch.int32, device="cuda:0")
+    _lib.call("mpx_draw_subset", total, n, seed, draw, _lib.ptr(out))
+    np.testing.assert_array_equal(out.cpu().numpy(), oracle.draw_subset(total, n, seed, draw))
+    lib = _lib.load()
+    assert lib.mpx_draw_subset(10, 11, 0, 0, out.data_ptr(), None) != 0  # more rows than the table has
+    assert lib.mpx_draw_subset(9000, 5000, 0, 0, out.data_ptr(), None) != 0 and b"4096" in lib.mpx_last_error()

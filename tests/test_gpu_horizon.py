@@ -103,6 +103,47 @@ def test_rerender_step_matches_oracle_loop(oracle):
     assert not torch.equal(eng2._scene_scratch[0], eng._scene_scratch[0])
 
 
+def test_per_step_robot_subset_matches_oracle_loop(oracle):
+    """RolloutEngine(resample_subset=True): the robot cloud's point subset is redrawn at every step, one draw for the
+    batch -- the reference's loop (FrankaSampler.sample's per-call np.random.choice; model.py:170-181,
+    run_inference.py:188-189) -- on the device.  4 steps vs the oracle loop with the oracle's restated draw: subsets
+    index-exact, FPS / ball-query indices bit-exact, joint state within 1e-5; the single-call C path (mpx_rollout with
+    subset_table_size) leaves the identical state."""
+    from mpinets_amd.model import MotionPolicyNetwork
+    from mpinets_amd.rollout import RolloutEngine
+    from mpinets_amd.scenes import make_problem_batch
+
+    torch.manual_seed(4)
+    model = MotionPolicyNetwork().to(dev()).eval()
+    B, sseed = 3, 2024
+    mk = lambda: make_problem_batch(B, seed=19, device=dev(), kinds=("tabletop", "cubby", "dresser"), M1=40, M2=16,
+                                    device_clouds=True)
+    prob = mk()
+    eng = RolloutEngine(model, prob, resample_subset=True, subset_seed=sseed)
+    frozen = RolloutEngine(model, mk())  # the default: one subset for the whole rollout
+    eng.capture = {}
+    loop = OracleLoop(oracle, model, eng, prob)
+    x, qn = prob["xyz"].cpu().numpy().copy(), prob["q_norm"].cpu().numpy().copy()
+    P = eng.sampler.table_pts.size(0)
+    seen = []
+    for step in range(4):
+        eng.step(), frozen.step()
+        loop.subset = oracle.draw_subset(P, 2048, sseed, step)
+        np.testing.assert_array_equal(eng.subset.cpu().numpy(), loop.subset)
+        seen.append(loop.subset.copy())
+        qn, q, flags, aux = loop.step(x, qn)
+        assert _same_indices(eng.capture, aux), f"step {step}: FPS / ball-query indices differ"
+        np.testing.assert_allclose(eng.q_norm.cpu().numpy(), qn, rtol=0, atol=TOL)
+        np.testing.assert_allclose(eng.xyz[:, :2048, :3].cpu().numpy(), x[:, :2048, :3], rtol=0, atol=5e-5)
+    assert not any(np.array_equal(seen[0], s) for s in seen[1:])  # a new subset every step
+    assert not torch.equal(eng.xyz[:, :2048], frozen.xyz[:, :2048])  # ... which the frozen default does not do
+    # the same four steps through mpx_rollout (one C call)
+    nat = RolloutEngine(model, mk(), resample_subset=True, subset_seed=sseed)
+    nat.run_native(4)
+    assert torch.equal(nat.q, eng.q) and torch.equal(nat.q_norm, eng.q_norm) and torch.equal(nat.xyz, eng.xyz)
+    assert torch.equal(nat.subset, eng.subset)
+
+
 @pytest.fixture(scope="module")
 def horizon_report():
     rep = {}

@@ -139,3 +139,21 @@ def test_device_clouds_feed_the_policy(oracle):
     # and the clouds differ between environments that share primitives (scene_pool tiling)
     prob2 = make_problem_batch(4, seed=2, device="cuda:0", device_clouds=True, scene_pool=1)
     assert not torch.equal(prob2["xyz"][0, 2048:6144], prob2["xyz"][1, 2048:6144])
+
+
+def test_oracle_subset_draw_is_a_uniform_draw_without_replacement(oracle):
+    """orc_draw_subset (the per-call robot-point subset, robofin FrankaSampler.sample's np.random.choice(P, n, replace=False),
+    model.py:170-181): distinct rows in range, a function of (seed, draw) only, every row about equally likely, and
+    n_out = total is a permutation."""
+    a = oracle.draw_subset(4096, 2048, 5, 0)
+    assert a.dtype == np.int32 and len(np.unique(a)) == 2048 and a.min() >= 0 and a.max() < 4096
+    np.testing.assert_array_equal(a, oracle.draw_subset(4096, 2048, 5, 0))
+    assert not np.array_equal(a, oracle.draw_subset(4096, 2048, 5, 1))
+    assert not np.array_equal(a, oracle.draw_subset(4096, 2048, 6, 0))
+    np.testing.assert_array_equal(np.sort(oracle.draw_subset(77, 77, 1, 3)), np.arange(77))
+    hits = np.zeros(64)
+    for d in range(400):  # 16 of 64 rows, 400 draws: each row is chosen 100 times on average
+        hits[oracle.draw_subset(64, 16, 9, d)] += 1
+    assert hits.min() > 60 and hits.max() < 140, hits
+    first = np.bincount([oracle.draw_subset(64, 16, 9, d)[0] for d in range(400)], minlength=64)
+    assert first.max() < 25  # (uniform ORDER too: no row is favoured as the first pick)
