@@ -172,6 +172,7 @@ def main():
     ap.add_argument("--extra", type=int, default=1, help="also time BASELINE configs 2 and 4 (collision validation only)")
     ap.add_argument("--static-steps", type=int, default=2, help="steps of the extra without scene re-render on tabletop-only scenes (BASELINE config 3 shape at this batch size); 0 = skip")
     ap.add_argument("--all-slots-steps", type=int, default=2, help="steps of the worst-case extra: padding elision off, all 128 slots per neighbourhood (0 = skip)")
+    ap.add_argument("--whole-batch-steps", type=int, default=0, help="opt-in extra: steps of the whole 65 536-environment configs[4] batch on this one GPU (0 = skip; needs ~90 GB)")
     ap.add_argument("--pipeline-steps", type=int, default=3, help="steps of the two-stream pipelined measurement of the headline workload (0 = skip)")
     ap.add_argument("--cpu-envs", type=int, default=64, help="env-steps in the CPU baseline sample (0 = skip)")
     ap.add_argument("--scene-pool", type=int, default=1024, help="distinct host-generated primitive sets tiled over the batch (clouds are drawn per env on the device)")
@@ -424,6 +425,31 @@ def main():
                              "neighbourhood (what the reference computes; same result bit for bit) -- the density-independent "
                              "floor of the headline number"}
 
+    # ---- extra (opt-in, rank 0): the WHOLE of BASELINE configs[4] -- 65 536 environments -- resident on ONE GPU (the
+    # launchers walk the batch in slabs past gridDim.y / 4 GB-per-operand limits; ~90 GB of the 288 GB)
+    whole = None
+    if rank == 0 and args.whole_batch_steps > 0 and not shared_devices:
+        del eng
+        torch.cuda.empty_cache()
+        BW = 65536
+        prob_w = make_problem_batch(BW, seed=1000, device=dev, kinds=("tabletop", "cubby", "dresser"), M1=40, M2=16,
+                                    scene_pool=args.scene_pool, device_clouds=True)
+        eng_w = RolloutEngine(model, prob_w, rerender_scene=True, scene_seed=17)
+        eng_w.step()
+        torch.cuda.synchronize()
+        tw0 = time.perf_counter()
+        for _ in range(args.whole_batch_steps):
+            eng_w.step()
+        torch.cuda.synchronize()
+        el_w = time.perf_counter() - tw0
+        whole = {"envs": BW, "steps": args.whole_batch_steps, "ms_per_step": el_w / args.whole_batch_steps * 1e3,
+                 "env_steps_per_s": BW * args.whole_batch_steps / el_w, "dtype": "f32",
+                 "peak_memory_gb": torch.cuda.max_memory_allocated(dev) / 1e9,
+                 "collision_rate": float((eng_w.flags != 0).float().mean().item()),
+                 "what": "BASELINE configs[4] whole (65 536 mixed environments, re-render + policy step) on ONE MI355X"}
+        del eng_w, prob_w
+        torch.cuda.empty_cache()
+
     if rank == 0:
         # SA1 = mpx_sa_mlp; SA2 = mpx_sa_mlp_factored (first layer evaluated per point / per query by two
         # mpx_linear calls, which are timed under linear_all)
@@ -514,6 +540,8 @@ def main():
             out["pipelined_two_streams"] = pipelined
         if all_slots is not None:
             out["all_slots"] = all_slots
+        if whole is not None:
+            out["whole_config4_one_gpu"] = whole
         if fast is not None:
             fel, f1_ms, f2_ms, fdense_ms = fast
             out["fast_mode"] = {

@@ -51,6 +51,23 @@ void mpx_set_error(const char *fmt, ...);
 static inline hipStream_t mpx_s(mpx_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// ---- launch slabs ----------------------------------------------------------------------------------------------------
+// gridDim.y is limited to 65535, and kernels that reach an operand through a 32-bit buffer offset need it under 4 GB.
+// A batched entry point whose batch exceeds one launch walks it in slabs (same kernels, same per-row arithmetic: results
+// do not depend on the slabbing) -- the whole of BASELINE configs[4] (65 536 environments) runs on one 288 GB GPU.
+constexpr int MPX_GRID_Y = 65535;
+// rows one launch of a row-blocked GEMM may cover: <= 65528 blocks of `bm` rows (a multiple of 8 blocks: the XCD-aware
+// tile order keeps its shape) and rows * row_bytes < 4 GB when row_bytes > 0
+static inline int64_t mpx_row_slab(int bm, int64_t row_bytes) {
+  int64_t blocks = 65528;
+  if (row_bytes > 0) {
+    const int64_t fit = ((((int64_t)1 << 32) - 8192) / row_bytes / bm) & ~(int64_t)7;
+    if (fit < blocks) blocks = fit;
+  }
+  if (blocks < 8) blocks = 8;
+  return blocks * bm;
+}
+
 // ---- device math with a pinned evaluation order ----------------------------------------------
 // Build uses -ffp-contract=off: fused multiply-adds exist only where __builtin_fmaf is written,
 // so these helpers evaluate exactly like their restatement in oracle/mpn_oracle.c.

@@ -341,7 +341,12 @@ MPX_EXPORT int mpx_linear(const float *x, int ldx, const float *w, const float *
     gemv_launch(x, ldx, w, bias, M, N, K, act, y, ldy, stream);
     MPX_LAUNCH_CHECK("mpx_linear");
   }
-  MPX_REQUIRE(cdiv(M, BM) <= 65535, "mpx_linear: M too large");
+  if (const int64_t slab = mpx_row_slab(BM, (int64_t)ldx * 4); M > slab) {  // more rows than one launch covers
+    for (int64_t m0 = 0; m0 < M; m0 += slab)
+      if (int rc = mpx_linear(x + m0 * ldx, ldx, w, bias, (int)(M - m0 < slab ? M - m0 : slab), N, K, act, y + m0 * ldy, ldy, stream))
+        return rc;
+    return 0;
+  }
   // (BK = 32 slabs were measured: no gain, twice the LDS)
   // (A 256 x 128-tile form with a three-stage counted-vmcnt ring at two waves per SIMD -- the structure of
   // dense_bf16.hip's pairs kernel -- was measured on the 1 M-row layers: 8.98 vs 8.32 ms and 4.56 vs 4.21 ms: with
@@ -428,7 +433,13 @@ MPX_EXPORT int mpx_linear_rowmax(const float *x, int ldx, const float *w, const 
   MPX_REQUIRE((((uintptr_t)x | (uintptr_t)w) & 15) == 0, "mpx_linear_rowmax: x and w must be 16-byte aligned");
   MPX_REQUIRE(ldx >= K && ldy >= N, "mpx_linear_rowmax: leading dimension too small");
   if (M == 0) return 0;
-  MPX_REQUIRE(M / BM <= 65535, "mpx_linear_rowmax: M too large");
+  if (const int64_t slab = mpx_row_slab(BM, (int64_t)ldx * 4); M > slab) {
+    for (int64_t m0 = 0; m0 < M; m0 += slab)
+      if (int rc = mpx_linear_rowmax(x + m0 * ldx, ldx, w, bias, (int)(M - m0 < slab ? M - m0 : slab), N, K, rows,
+                                     y + (m0 / BM) * ldy, ldy, stream))
+        return rc;
+    return 0;
+  }
   hipError_t e = hipMemset2DAsync(y, (size_t)ldy * sizeof(float), 0, (size_t)N * sizeof(float), (size_t)(M / BM),
                                   mpx_s(stream));
   MPX_REQUIRE(e == hipSuccess, "mpx_linear_rowmax: memset failed: %s", hipGetErrorString(e));
@@ -545,8 +556,14 @@ __global__ void __launch_bounds__(256)
 MPX_EXPORT int mpx_rowmax(const float *x, int ldx, int G, int rows, int C, float *y, int ldy,
                           mpx_stream_t stream) {
   MPX_REQUIRE(G >= 0 && rows >= 1 && C >= 1 && ldx >= C && ldy >= C, "mpx_rowmax: bad size");
-  MPX_REQUIRE(G <= 65535, "mpx_rowmax: G > 65535 (slab the batch)");
   if (G == 0) return 0;
+  if (G > MPX_GRID_Y) {
+    for (int64_t g0 = 0; g0 < G; g0 += MPX_GRID_Y)
+      if (int rc = mpx_rowmax(x + g0 * rows * ldx, ldx, (int)(G - g0 < MPX_GRID_Y ? G - g0 : MPX_GRID_Y), rows, C, y + g0 * ldy, ldy,
+                              stream))
+        return rc;
+    return 0;
+  }
   hipLaunchKernelGGL(rowmax_kernel, dim3(cdiv(C, 64), G), dim3(256), 0, mpx_s(stream), x, ldx, rows, C, y, ldy);
   MPX_LAUNCH_CHECK("mpx_rowmax");
 }

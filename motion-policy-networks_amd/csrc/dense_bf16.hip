@@ -407,7 +407,13 @@ MPX_EXPORT int mpx_linear_bf16x3(const float *x, int ldx, const void *w_pairs, c
   if (hb_check("mpx_linear_bf16x3", x, ldx, w_pairs, M, N, K, ldy)) return 1;
   MPX_REQUIRE(act >= 0 && act <= 2, "mpx_linear_bf16x3: unknown activation %d", act);
   if (M == 0) return 0;
-  MPX_REQUIRE(cdiv(M, HB_BM) <= 65535, "mpx_linear_bf16x3: M too large");
+  if (const int64_t slab = mpx_row_slab(HB_BM, 0); M > slab) {
+    for (int64_t m0 = 0; m0 < M; m0 += slab)
+      if (int rc = mpx_linear_bf16x3(x + m0 * ldx, ldx, w_pairs, bias, (int)(M - m0 < slab ? M - m0 : slab), N, K, act,
+                                     y + m0 * ldy, ldy, stream))
+        return rc;
+    return 0;
+  }
   hipLaunchKernelGGL((linear_bf16x3_kernel<false>), dim3(cdiv(N, HB_BN), cdiv(M, HB_BM)), dim3(256), 0, mpx_s(stream), x,
                      ldx, reinterpret_cast<const __bf16 *>(w_pairs), 2 * hb_kp(K), bias, M, N, K, hb_kp(K), act, y, ldy,
                      (__bf16 *)nullptr, 0);
@@ -420,7 +426,13 @@ MPX_EXPORT int mpx_linear_bf16x3_to_pairs(const float *x, int ldx, const void *w
   if (hb_check_pairs_out("mpx_linear_bf16x3_to_pairs", y_pairs, N, ldp)) return 1;
   MPX_REQUIRE(act >= 0 && act <= 2, "mpx_linear_bf16x3_to_pairs: unknown activation %d", act);
   if (M == 0) return 0;
-  MPX_REQUIRE(cdiv(M, HB_BM) <= 65535, "mpx_linear_bf16x3_to_pairs: M too large");
+  if (const int64_t slab = mpx_row_slab(HB_BM, 0); M > slab) {
+    for (int64_t m0 = 0; m0 < M; m0 += slab)
+      if (int rc = mpx_linear_bf16x3_to_pairs(x + m0 * ldx, ldx, w_pairs, bias, (int)(M - m0 < slab ? M - m0 : slab), N, K, act,
+                                              static_cast<__bf16 *>(y_pairs) + m0 * ldp, ldp, stream))
+        return rc;
+    return 0;
+  }
   hipLaunchKernelGGL((linear_bf16x3_kernel<false>), dim3(cdiv(N, HB_BN), cdiv(M, HB_BM)), dim3(256), 0, mpx_s(stream), x,
                      ldx, reinterpret_cast<const __bf16 *>(w_pairs), 2 * hb_kp(K), bias, M, N, K, hb_kp(K), act,
                      (float *)nullptr, 0, reinterpret_cast<__bf16 *>(y_pairs), ldp);
@@ -432,7 +444,13 @@ MPX_EXPORT int mpx_linear_rowmax_bf16x3(const float *x, int ldx, const void *w_p
   if (hb_check("mpx_linear_rowmax_bf16x3", x, ldx, w_pairs, M, N, K, ldy)) return 1;
   MPX_REQUIRE(rows == HB_BM && M % HB_BM == 0, "mpx_linear_rowmax_bf16x3: pooled groups must be exactly %d rows", HB_BM);
   if (M == 0) return 0;
-  MPX_REQUIRE(M / HB_BM <= 65535, "mpx_linear_rowmax_bf16x3: M too large");
+  if (const int64_t slab = mpx_row_slab(HB_BM, 0); M > slab) {
+    for (int64_t m0 = 0; m0 < M; m0 += slab)
+      if (int rc = mpx_linear_rowmax_bf16x3(x + m0 * ldx, ldx, w_pairs, bias, (int)(M - m0 < slab ? M - m0 : slab), N, K, rows,
+                                            y + (m0 / HB_BM) * ldy, ldy, stream))
+        return rc;
+    return 0;
+  }
   hipError_t e = hipMemset2DAsync(y, (size_t)ldy * sizeof(float), 0, (size_t)N * sizeof(float), (size_t)(M / HB_BM),
                                   mpx_s(stream));
   MPX_REQUIRE(e == hipSuccess, "mpx_linear_rowmax_bf16x3: memset failed: %s", hipGetErrorString(e));
@@ -448,9 +466,8 @@ static int pb_check(const char *name, const void *a, int lda, const void *w, int
   MPX_REQUIRE(K % 16 == 0 && lda % 8 == 0 && lda >= 2 * K, "%s: K must be a multiple of 16, lda of 8 and >= 2 K (got %d, %d)",
               name, K, lda);
   MPX_REQUIRE(((uintptr_t)a & 15) == 0, "%s: the activation pairs must be 16-byte aligned", name);
-  MPX_REQUIRE((int64_t)M * lda * 2 < ((int64_t)1 << 32) - 16 && (int64_t)N * K * 4 < ((int64_t)1 << 32) - 16,
-              "%s: an operand must stay under 4 GB (split the rows over several calls)", name);
-  MPX_REQUIRE(cdiv(M, Y_BM) <= 65535, "%s: M too large", name);
+  MPX_REQUIRE((int64_t)N * K * 4 < ((int64_t)1 << 32) - 16, "%s: the weight pairs must stay under 4 GB", name);
+  // (rows: the entry points walk them in slabs of mpx_row_slab(Y_BM, lda * 2): activation pairs under 4 GB per launch)
   return hb_check_w(name, w, N, K);
 }
 #define PB_LAUNCH(OUT, grid, s, ...)                                                                       \
@@ -470,6 +487,14 @@ MPX_EXPORT int mpx_linear_bf16x3_pairs(const void *a_pairs, int lda, const void 
     return 1;
   }
   if (M == 0) return 0;
+  if (const int64_t slab = mpx_row_slab(Y_BM, (int64_t)lda * 2); M > slab) {
+    for (int64_t m0 = 0; m0 < M; m0 += slab)
+      if (int rc = mpx_linear_bf16x3_pairs(static_cast<const __bf16 *>(a_pairs) + m0 * lda, lda, w_pairs, bias,
+                                           (int)(M - m0 < slab ? M - m0 : slab), N, K, act, y ? y + m0 * ldy : nullptr, ldy,
+                                           y_pairs ? static_cast<__bf16 *>(y_pairs) + m0 * ldp : nullptr, ldp, stream))
+        return rc;
+    return 0;
+  }
   const dim3 grid(cdiv(N, Y_BN), cdiv(M, Y_BM));
   const __bf16 *ap = reinterpret_cast<const __bf16 *>(a_pairs), *wp = reinterpret_cast<const __bf16 *>(w_pairs);
   if (y)
@@ -492,6 +517,15 @@ MPX_EXPORT int mpx_linear_rowmax_bf16x3_pairs(const void *a_pairs, int lda, cons
     MPX_REQUIRE(ldp >= 2 * hb_kp(N) && ((uintptr_t)y_pairs & 1) == 0, "mpx_linear_rowmax_bf16x3_pairs: bad output pairs");
   }
   if (M == 0) return 0;
+  if (const int64_t slab = mpx_row_slab(Y_BM, (int64_t)lda * 2); M > slab) {
+    for (int64_t m0 = 0; m0 < M; m0 += slab)
+      if (int rc = mpx_linear_rowmax_bf16x3_pairs(static_cast<const __bf16 *>(a_pairs) + m0 * lda, lda, w_pairs, bias,
+                                                  (int)(M - m0 < slab ? M - m0 : slab), N, K, rows,
+                                                  y ? y + (m0 / 128) * ldy : nullptr, ldy,
+                                                  y_pairs ? static_cast<__bf16 *>(y_pairs) + (m0 / 128) * ldp : nullptr, ldp, stream))
+        return rc;
+    return 0;
+  }
   const dim3 grid(cdiv(N, Y_BN), cdiv(M, Y_BM));
   const __bf16 *ap = reinterpret_cast<const __bf16 *>(a_pairs), *wp = reinterpret_cast<const __bf16 *>(w_pairs);
   if (y)

@@ -114,8 +114,15 @@ __global__ void __launch_bounds__(256)
 MPX_EXPORT int mpx_pose_cloud(const float *poses, int B, const float *table_pts, const int32_t *subset,
                               int n_out, float *out, int64_t out_batch_stride, int out_point_stride,
                               mpx_stream_t stream) {
-  MPX_REQUIRE(B >= 0 && B <= 65535 && n_out >= 0, "mpx_pose_cloud: bad size (B <= 65535)");
+  MPX_REQUIRE(B >= 0 && n_out >= 0, "mpx_pose_cloud: bad size");
   if (B == 0 || n_out == 0) return 0;
+  if (B > MPX_GRID_Y) {  // more poses than one launch's gridDim.y: slabs
+    for (int64_t b0 = 0; b0 < B; b0 += MPX_GRID_Y)
+      if (int rc = mpx_pose_cloud(poses + b0 * 16, (int)(B - b0 < MPX_GRID_Y ? B - b0 : MPX_GRID_Y), table_pts, subset, n_out,
+                                  out + b0 * out_batch_stride, out_batch_stride, out_point_stride, stream))
+        return rc;
+    return 0;
+  }
   hipLaunchKernelGGL(pose_cloud_kernel, dim3(cdiv(n_out, 256), B), dim3(256), 0, mpx_s(stream), poses,
                      table_pts, subset, n_out, out, out_batch_stride, out_point_stride);
   MPX_LAUNCH_CHECK("mpx_pose_cloud");

@@ -1127,8 +1127,15 @@ MPX_EXPORT int mpx_ball_query(const float *new_xyz, int new_stride, const float 
                               mpx_stream_t stream) {
   MPX_REQUIRE(B >= 0 && N >= 0 && npoint >= 0 && nsample >= 0, "mpx_ball_query: negative size");
   MPX_REQUIRE(stride >= 3 && new_stride >= 3, "mpx_ball_query: stride < 3");
-  MPX_REQUIRE(B <= 65535, "mpx_ball_query: B > 65535 (slab the batch)");
   if (B == 0 || npoint == 0 || nsample == 0) return 0;
+  if (B > MPX_GRID_Y) {  // more environments than one launch's gridDim.y: slabs
+    for (int64_t b0 = 0; b0 < B; b0 += MPX_GRID_Y)
+      if (int rc = mpx_ball_query(new_xyz + b0 * npoint * new_stride, new_stride, xyz + b0 * N * stride, stride,
+                                  (int)(B - b0 < MPX_GRID_Y ? B - b0 : MPX_GRID_Y), N, npoint, radius, nsample,
+                                  idx + b0 * npoint * nsample, cnt ? cnt + b0 * npoint : nullptr, stream))
+        return rc;
+    return 0;
+  }
   const float r2 = radius * radius;  // float product, like the reference kernel
   // large cloud, small radius (the first set-abstraction module): bucketed search, bit-identical output
   const int fast = g_variant[MPX_VARIANT_BALL_QUERY].load(std::memory_order_relaxed);

@@ -185,7 +185,7 @@ MPX_EXPORT int64_t mpx_policy_workspace(int B, int N) {
 MPX_EXPORT int mpx_policy_forward(const mpx_policy_weights *w, const float *xyz, int N, const float *q, int B, float *dq,
                                   void *workspace, int64_t workspace_bytes, mpx_stream_t stream) {
   MPX_REQUIRE(w && xyz && q && dq, "mpx_policy_forward: NULL operand");
-  MPX_REQUIRE(B >= 0 && B <= 65535, "mpx_policy_forward: B = %d outside [0, 65535] (slab the batch)", B);
+  MPX_REQUIRE(B >= 0, "mpx_policy_forward: negative batch");  // (any size: the batched launchers walk slabs)
   MPX_REQUIRE(N >= NP1 && N <= 8192, "mpx_policy_forward: N = %d outside [%d, 8192]", N, NP1);
   if (B == 0) return 0;
   MPX_REQUIRE(workspace && (((uintptr_t)workspace) & 255) == 0, "mpx_policy_forward: workspace must be 256-byte aligned");

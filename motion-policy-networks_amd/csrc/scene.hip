@@ -209,11 +209,22 @@ MPX_EXPORT int mpx_scene_cloud(const float *cub_centers, const float *cub_dims, 
   MPX_REQUIRE(B >= 0 && M1 >= 0 && M2 >= 0 && num_points >= 0, "mpx_scene_cloud: negative size");
   MPX_REQUIRE(M1 + M2 <= MAX_OBS, "mpx_scene_cloud: more than %d primitives per environment", MAX_OBS);
   MPX_REQUIRE(num_points <= SEL_MAX_OUT, "mpx_scene_cloud: num_points > %d (the draw is ordered in LDS)", SEL_MAX_OUT);
-  MPX_REQUIRE(B <= 65535, "mpx_scene_cloud: B > 65535 (slab the batch)");
   MPX_REQUIRE(env_offset >= 0 && env_offset + B <= 0xFFFFFFFFll, "mpx_scene_cloud: env_offset + B exceeds 2^32");
   MPX_REQUIRE(out_point_stride >= (write_label ? 4 : 3), "mpx_scene_cloud: out_point_stride too small");
   MPX_REQUIRE(assign != nullptr, "mpx_scene_cloud: assign scratch [B,num_points] uint16 is required");
   if (B == 0 || num_points == 0) return 0;
+  if (B > MPX_GRID_Y) {  // more environments than one launch's gridDim.y: slabs (the draws are keyed by env_offset + row)
+    for (int64_t b0 = 0; b0 < B; b0 += MPX_GRID_Y) {
+      const int nb = (int)(B - b0 < MPX_GRID_Y ? B - b0 : MPX_GRID_Y);
+      if (int rc = mpx_scene_cloud(cub_centers + b0 * M1 * 3, cub_dims + b0 * M1 * 3, cub_quats + b0 * M1 * 4, M1,
+                                   cyl_centers + b0 * M2 * 3, cyl_radii + b0 * M2, cyl_heights + b0 * M2, cyl_quats + b0 * M2 * 4,
+                                   M2, nb, num_points, seed, env_offset + b0, assign + b0 * num_points,
+                                   labels ? labels + b0 * (M1 + M2) : nullptr, n_obstacles ? n_obstacles + b0 : nullptr,
+                                   out + b0 * out_batch_stride, out_batch_stride, out_point_stride, write_label, stream))
+        return rc;
+    }
+    return 0;
+  }
   const uint32_t lo = (uint32_t)seed, hi = (uint32_t)(seed >> 32), env0 = (uint32_t)env_offset;
   hipLaunchKernelGGL(scene_assign_kernel, dim3(B), dim3(SEL_THREADS), 0, mpx_s(stream), cub_dims, M1, cyl_radii,
                      cyl_heights, M2, B, num_points, lo, hi, env0, assign, labels, n_obstacles);

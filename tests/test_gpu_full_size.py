@@ -139,3 +139,42 @@ def test_rollout_step_keeps_the_slab_consistent(problem):
     assert torch.equal(prob["xyz"][:, :2048, :3], again) and (prob["xyz"][:, :2048, 3] == 0).all()
     lim = eng.limits
     assert (q >= lim[:, 0] - 1e-6).all() and (q <= lim[:, 1] + 1e-6).all()
+
+
+def test_batches_beyond_one_launch_run_in_slabs():
+    """B >= 16 384 environments per GPU used to fail (a GEMM over B * 512 rows needs more than 65 535
+    row blocks of gridDim.y).  The launchers now walk row / batch slabs: B = 20 000 through the single-call C forward
+    (mpx_policy_forward) and through the Python path; rows are independent, so the first and the last 1 040
+    environments equal their own 1 040-environment forward bit for bit (same launch-shape regime)."""
+    from mpinets_amd.model import MotionPolicyNetwork
+    from mpinets_amd.scenes import make_problem_batch
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(2)
+    mdl = MotionPolicyNetwork().to(dev).eval()
+    B, n = 20000, 1040
+    prob = make_problem_batch(B, seed=77, device=dev, kinds=("tabletop", "cubby", "dresser"), M1=40, M2=16, scene_pool=256,
+                              device_clouds=True)
+    with torch.no_grad():
+        dq_native = mdl.forward_native(prob["xyz"], prob["q_norm"]).clone()
+        dq_py = mdl(prob["xyz"], prob["q_norm"]).clone()
+        assert torch.equal(dq_native, dq_py)
+        for sl in (slice(0, n), slice(B - n, B)):
+            part = mdl(prob["xyz"][sl].contiguous(), prob["q_norm"][sl].contiguous())
+            assert torch.equal(part, dq_py[sl]), sl
+    assert torch.isfinite(dq_py).all() and dq_py.abs().max() > 0
+    # the batched launchers with a batch axis on gridDim.y: more than 65 535 environments
+    from mpinets_amd.pointnet2 import ball_query
+    from mpinets_amd.scenes import sample_scene_clouds
+
+    Bq = 65540
+    xyz = torch.rand((Bq, 96, 3), device=dev)
+    q = xyz[:, :5].contiguous()
+    idx, cnt = ball_query(0.4, 32, xyz, q, return_counts=True)
+    ref_i, ref_c = ball_query(0.4, 32, xyz[-8:].contiguous(), q[-8:].contiguous(), return_counts=True)
+    assert torch.equal(idx[-8:], ref_i) and torch.equal(cnt[-8:], ref_c)
+    prims = {k: v[:4].repeat((Bq + 3) // 4, *([1] * (v.ndim - 1)))[:Bq].contiguous() for k, v in prob.items()
+             if k.startswith(("cuboid_", "cylinder_"))}
+    cloud = sample_scene_clouds(prims, 64, 5)
+    tail = sample_scene_clouds({k: v[-4:].contiguous() for k, v in prims.items()}, 64, 5, env_offset=Bq - 4)
+    assert torch.equal(cloud[-4:], tail)
