@@ -84,20 +84,40 @@ def cpu_baseline(prob, model, n_env: int):
 
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E ~8 TB/s
-TRAFFIC_RECORD = "r02_traffic.json"  # written by tools/pmc_traffic.py from the PMC passes of this round
+FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector peak (64 FLOP / clk / SIMD)
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak at 2.4 GHz
+TRAFFIC_RECORD = "r03_traffic.json"  # written by tools/pmc_traffic.py from the PMC passes of this round
+FAST_RECORD = "r03_fast_traffic.json"  # the same for the bf16x3 kernels (tools/pmc_fast.py)
+
+# FLOPs per (collision sphere, unmasked primitive) pair, counted from csrc/sdf_device.h (one fma = 2): cuboid =
+# projection 18 + 3 abs-sub + 3 max + 5 (norm) + sqrt + 3 (max3, min) + 2 (add, min-select) = 35; cylinder = 18 + 4 (rho)
+# + 2 sub + 2 max + 3 + sqrt + 2 + 1 = 33; per sphere the FK-frame transform 18; per (env, waypoint) the 7-joint FK ~600
+COL_CUB_FLOPS, COL_CYL_FLOPS, COL_SPHERE_FLOPS, COL_FK_FLOPS = 35, 33, 18, 600
 
 
-def kernel_source_hash() -> str:
-    """SHA-256 over the sources of the dominant kernel (csrc/sa_mlp.hip + common.h): stamps the PMC traffic record."""
+def collision_flops(prob, rows, T: int, S: int = 56) -> float:
+    """EXECUTED arithmetic of one swept-sphere collision call over environments `rows` x T waypoints: zero-volume
+    (masked) primitives are skipped wave-uniformly by the kernel and are not counted."""
+    live_c = int((prob["cuboid_dims"][rows].abs() > 1e-8).all(-1).sum().item())
+    live_y = int(((prob["cylinder_radii"][rows].abs() > 1e-8) & (prob["cylinder_heights"][rows].abs() > 1e-8)).sum().item())
+    n = prob["cuboid_dims"][rows].size(0)
+    return float(T * S * (live_c * COL_CUB_FLOPS + live_y * COL_CYL_FLOPS) + n * T * (S * COL_SPHERE_FLOPS + COL_FK_FLOPS))
+
+
+def kernel_source_hash(files=("sa_mlp.hip", "common.h")) -> str:
+    """SHA-256 over kernel sources (default: the dominant kernel's, csrc/sa_mlp.hip + common.h): stamps a PMC record."""
     import hashlib
 
     h = hashlib.sha256()
-    for f in ("sa_mlp.hip", "common.h"):
+    for f in files:
         h.update(open(os.path.join(ROOT, "motion-policy-networks_amd", "csrc", f), "rb").read())
     return h.hexdigest()
 
 
-def stage_table(prof, steps, B, sa1_ms, sa1_exec, sa2_ms, sa2_exec):
+FAST_SOURCES = ("sa_mlp_bf16.hip", "dense_bf16.hip", "common.h")
+
+
+def stage_table(prof, steps, B, sa1_ms, sa1_exec, sa2_ms, sa2_exec, col_flops):
     """achieved / peak per stage of the step: HBM stages in GB/s of algorithmic bytes, MFMA stages in TFLOP/s of
     executed FLOPs, FPS / ball query in G point-pair distance evaluations per second (VALU / latency bound: their
     HBM traffic, the 100 KB slab read once, is negligible)."""
@@ -116,8 +136,12 @@ def stage_table(prof, steps, B, sa1_ms, sa1_exec, sa2_ms, sa2_exec):
                         "unit": "TFLOP/s", "frac": fl / (t * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS}
     return {
         "fk_robot_cloud": dict(hbm(B * 2048 * 12.0, ms("mpx_franka_cloud")), note="24,576 B written per env"),
-        "sphere_sdf_collision": dict(hbm(B * 1250.0, ms("mpx_franka_collision")),
-                                     note="~1.25 KB per env-waypoint: launch / latency bound at T = 1, not HBM"),
+        "sphere_sdf_collision": {"bound": "valu", "ms": ms("mpx_franka_collision"),
+                                 "achieved": col_flops / (ms("mpx_franka_collision") * 1e-3) / 1e12, "peak": FP32_VALU_PEAK_TFLOPS,
+                                 "unit": "TFLOP/s", "frac": col_flops / (ms("mpx_franka_collision") * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS,
+                                 "note": "executed FLOPs (unmasked primitives only) vs the fp32 VALU peak; one waypoint per "
+                                         "environment here (56 of 64 lanes, one wave per environment): the T = 50 shape is "
+                                         "extra_configs.c4_collision_validation"},
         "fps": {"bound": "valu/latency", "ms": ms("mpx_fps"), "achieved": pairs / (ms("mpx_fps") * 1e-3) / 1e9,
                 "unit": "G point-distance updates/s", "note": "511 + 127 dependent picks per env"},
         "ball_query": {"bound": "valu", "ms": ms("mpx_ball_query"),
@@ -129,6 +153,30 @@ def stage_table(prof, steps, B, sa1_ms, sa1_exec, sa2_ms, sa2_exec):
         "groupnorm_leaky": {"bound": "hbm", "ms": ms("mpx_groupnorm_leaky")},
         "joint_step": {"bound": "latency", "ms": ms("mpx_joint_step")},
     }
+
+
+def fast_roofline(B, live_ms, live_flops):
+    """`roofline` of the bf16x3 mode's dominant kernel (sa2_bf16x3_persistent_kernel): achieved = the bf16 MFMA FLOPs of
+    the live run / its live time; clock, pipe-busy fraction and HBM traffic from the committed PMC record -- dropped
+    (null) when the kernel sources have changed since the passes were taken."""
+    out = {"kernel": "sa2_bf16x3_persistent_kernel", "bound": "mfma", "achieved": live_flops / (live_ms * 1e-3) / 1e12,
+           "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": live_flops / (live_ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS,
+           "ms_per_launch": live_ms, "flops_per_launch": live_flops, "clock_ghz": None, "mfma_busy_frac": None,
+           "frac_of_clock_adjusted_peak": None, "traffic": None}
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", FAST_RECORD)))
+        if rec["envs_per_gpu"] == B and rec["kernel_source_sha256"] == kernel_source_hash(FAST_SOURCES):
+            k = rec["kernels"]["sa2_bf16x3_persistent_kernel"]
+            peak_at_clock = BF16_MFMA_PEAK_TFLOPS * k["clock_ghz"] / 2.4
+            out.update(clock_ghz=k["clock_ghz"], mfma_busy_frac=k["mfma_busy_frac"], traffic=k["hbm_bytes_per_launch"],
+                       frac_of_clock_adjusted_peak=out["achieved"] / peak_at_clock,
+                       counters=f"profiles/{FAST_RECORD} (rocprofv3 --pmc passes at {B} envs; clock = GRBM_GUI_ACTIVE / 8 / "
+                                "kernel time under the profiler; busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x cycles))")
+        else:
+            out["counters"] = f"profiles/{FAST_RECORD} is stale (kernel source or batch size changed since the PMC passes)"
+    except Exception as e:
+        out["counters"] = f"no PMC record: {e}"
+    return out
 
 
 # multiply-adds per (query, neighbour) row of SA2 inside the fused kernel: layers 2 and 3 (128x128 + 128x256);
@@ -340,9 +388,20 @@ def main():
                                                  "the headline fields exact fp32"},
             "c4_collision_validation": {"envs": B, "waypoints": 50, "ms": c4_ms, "env_waypoints_per_s": B * 50 / c4_ms * 1e3,
                                         "cpu_port_env_waypoints_per_s": c4_cpu, "cpu_cores": 1,
+                                        "roofline": {"bound": "valu", "achieved": collision_flops(prob, slice(None), 50) / (c4_ms * 1e-3) / 1e12,
+                                                     "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                                     "frac": collision_flops(prob, slice(None), 50) / (c4_ms * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS,
+                                                     "executed_gflop": collision_flops(prob, slice(None), 50) / 1e9,
+                                                     "note": "executed FLOPs: unmasked primitives only (35 per sphere-cuboid, 33 per "
+                                                             "sphere-cylinder pair, csrc/sdf_device.h); counters: profiles/r03_collision_pmc.md"},
                                         "what": "FK + 56-sphere SDF vs 40 cuboids + 16 cylinders (zero-padded), has_collision[B] (model.py:293-314)"},
             "c2_fk_sdf_1024": {"envs": 1024, "ms": c2_ms, "env_steps_per_s": 1024 / c2_ms * 1e3,
                                "cpu_port_env_steps_per_s": c2_cpu, "cpu_cores": 1,
+                               "roofline": {"bound": "valu (launch / latency bound at this size)",
+                                            "achieved": collision_flops(prob, slice(0, 1024), 1) / (c2_ms * 1e-3) / 1e12,
+                                            "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                            "frac": collision_flops(prob, slice(0, 1024), 1) / (c2_ms * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS,
+                                            "note": "1024 one-wave workgroups of ~45 us: four per CU; a launch-latency-sized call"},
                                "what": "FK + sphere SDF, flags + min-sdf [1024,56] written"},
         }
 
@@ -526,7 +585,8 @@ def main():
                 "linear_all": float(np.sum(prof["mpx_linear"]) + np.sum(prof["mpx_linear_ws"]) + np.sum(prof["mpx_linear_rowmax"])) / args.steps,
             },
             # per-stage achieved / peak with the ALGORITHMIC work of SURVEY.md section 8(d) (per env-step, x B envs)
-            "stages": stage_table(prof, args.steps, B, sa1_ms, sa1_exec, sa2_ms, sa2_exec),
+            "stages": stage_table(prof, args.steps, B, sa1_ms, sa1_exec, sa2_ms, sa2_exec,
+                                  collision_flops(prob, slice(None), 1)),
             "result_check": {"gathered_q": list(q_all.shape), "collision_rate": float((f_all != 0).float().mean())},
             # N-rank self-check: the communicator the barrier / MAX / gather ran on ("nccl" = RCCL; null = a plain single
             # process, no group), the number of ranks on it, and every rank's device + own ms_per_step (`ms_per_step`
@@ -556,10 +616,8 @@ def main():
                 # the same tile count; three bf16 MFMAs per fp32 product
                 "sa2_executed_tflops": t2 * 32 * SA2_ROW_MACS * 2 / (f2_ms * 1e-3) / 1e12,
                 "sa2_bf16_mfma_tflops": 3 * t2 * 32 * SA2_ROW_MACS * 2 / (f2_ms * 1e-3) / 1e12,
-                "sa2_frac_of_bf16_peak_2500": 3 * t2 * 32 * SA2_ROW_MACS * 2 / (f2_ms * 1e-3) / 1e12 / 2500.0,
-                "sa2_note": "frac charges the 3 split MFMAs per fp32 product against the 2.5 PF data-sheet peak at 2.4 GHz; under "
-                            "this kernel the chip clocks at ~1.46 GHz (GRBM_GUI_ACTIVE / time, profiles/r02_bf16_sa2_pmc.md) and "
-                            "the matrix pipes are busy 46.5 % of those cycles",
+                "sa2_frac_of_bf16_peak_2500": 3 * t2 * 32 * SA2_ROW_MACS * 2 / (f2_ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS,
+                "roofline": fast_roofline(B, f2_ms, 3 * t2 * 32 * SA2_ROW_MACS * 2),
             }
         if args.cpu_envs > 0:  # rank 0's host cores, for every N (the other ranks wait at the final barrier)
             out["cpu_baseline"] = cpu_baseline(prob, model, args.cpu_envs)

@@ -376,6 +376,21 @@ int mpx_sa_pack_bf16x3(const float *w1, const float *b1, const float *w2, const 
                        const float *w3, const float *b3, int C, int c1, int c2, int c3, void *wpack,
                        mpx_stream_t stream);
 
+/* The group-all set-abstraction module (PointnetSAModule(mlp=[256(+3), 512, 512, 1024]), npoint = None: model.py:377-383)
+ * as ONE kernel: x rows [B*rows, K1] (ldx floats apart; [xyz | features | 0], K1 = 272 = 259 padded to whole 16-float
+ * slabs), rows = 128 per environment -> Linear + ReLU (K1 -> c1) -> Linear + ReLU (c1 -> c2) -> Linear + ReLU (c2 -> c3)
+ * -> max over the environment's rows -> out [B, c3] (ldo floats apart).  Nothing between the input rows and the pooled row
+ * touches HBM (the layer-by-layer form writes and re-reads two [B*128, 512] intermediates).  fp32 MFMA, exact fp32
+ * products; the summation order inside a dot product differs from mpx_linear's (1e-7 relative).  One workgroup per
+ * environment: meant for B >= 256.  pack: mpx_sa3_pack_weights (size in floats: mpx_sa3_pack_size; -1 = unsupported
+ * shape; supported: (K1, c1, c2, c3) = (272, 512, 512, 1024)); w1 is [c1, k1_real] row-major with k1_real <= K1 real
+ * input columns (259), w2 [c2, c1], w3 [c3, c2].                                                                       */
+int64_t mpx_sa3_pack_size(int K1, int c1, int c2, int c3);
+int mpx_sa3_pack_weights(const float *w1, int k1_real, const float *b1, const float *w2, const float *b2, const float *w3,
+                         const float *b3, int K1, int c1, int c2, int c3, float *pack, mpx_stream_t stream);
+int mpx_sa3_chain(const float *x, int ldx, int B, int rows, const float *pack, int K1, int c1, int c2, int c3, float *out,
+                  int ldo, mpx_stream_t stream);
+
 /* ---- dense layers: model.py:47-66, 385-393 ------------------------------------------------- */
 
 #define MPX_ACT_NONE 0
@@ -436,7 +451,8 @@ int mpx_append_columns(const float *src, int src_stride, int ncols, int nzero, i
  *   sa2_wcentre [128,4]  ... over rows [xyz (3) | *]                             (W1[:,:3] | 0)
  *   sa2_nb1 [128]        minus its bias
  *   sa3_w[0] [512,272]   group-all first layer, K padded 259 -> 272 with zero columns; sa3_w[1] [512,512];
- *                        sa3_w[2] [1024,512]; sa3_b[i] the biases
+ *                        sa3_w[2] [1024,512]; sa3_b[i] the biases (the layer-by-layer form: B < 256 problems)
+ *   sa3_pack             the same three layers packed by mpx_sa3_pack_weights (the fused form: B >= 256)
  *   fc_w / fc_b          1024 -> 4096 -> 2048 -> 2048; gn_g / gn_b: the two GroupNorm(16) affine vectors
  *   qe_w[0] [32,8]       joint encoder, first layer K padded 7 -> 8; then 32 -> 64 -> 128 -> 128 -> 64
  *   de_w / de_b          decoder 2112 -> 512 -> 256 -> 128 -> 7                                                  */
@@ -446,6 +462,7 @@ typedef struct mpx_policy_weights {
   const float *fc_w[3], *fc_b[3], *gn_g[2], *gn_b[2];
   const float *qe_w[5], *qe_b[5];
   const float *de_w[4], *de_b[4];
+  const float *sa3_pack; /* mpx_sa3_pack_weights of the group-all module (K1 = 272): the fused chain of B >= 256 problems */
 } mpx_policy_weights;
 
 /* bytes of 256-byte aligned device workspace a batch of B problems with N-point slabs needs */

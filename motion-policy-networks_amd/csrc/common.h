@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <type_traits>
 #include <stdint.h>
 #include <stdio.h>
 
@@ -179,18 +180,14 @@ __device__ __forceinline__ void rigid_apply(const float *f /*12*/, float x, floa
   oz = a2 + f[11];
 }
 
-// Franka Panda chain (public URDF constants).  Writes 15 frames x 12 floats to `out`
-// (any address space the caller indexes with a plain pointer: LDS or global).
-__device__ __forceinline__ void franka_fk_frames(const float *q7, float finger, float *out) {
+// Franka Panda chain (public URDF constants).  `visit(id, frame)` is called once per frame, in chain order
+// (0 = link0 ... 8 = link8, 9 hand, 10 / 11 fingers, 12 / 13 fingertips, 14 right_gripper), with the frame in registers:
+// a caller that consumes a frame as soon as it exists (the lanes-as-waypoints collision kernel) never stores the chain.
+template <class Visit>
+__device__ __forceinline__ void franka_fk_visit(const float *q7, float finger, Visit &&visit) {
   constexpr float SH = 0.70710678118654752440f;
   Rigid cur = {{1, 0, 0, 0, 1, 0, 0, 0, 1}, {0, 0, 0}};
-  auto put = [&](int id, const Rigid &g) {
-#pragma unroll
-    for (int k = 0; k < 9; ++k) out[12 * id + k] = g.r[k];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) out[12 * id + 9 + k] = g.t[k];
-  };
-  put(0, cur);
+  visit(std::integral_constant<int, 0>{}, cur);
   const float JR[7][9] = {
       {1, 0, 0, 0, 1, 0, 0, 0, 1},  {1, 0, 0, 0, 0, 1, 0, -1, 0}, {1, 0, 0, 0, 0, -1, 0, 1, 0},
       {1, 0, 0, 0, 0, -1, 0, 1, 0}, {1, 0, 0, 0, 0, 1, 0, -1, 0}, {1, 0, 0, 0, 0, -1, 0, 1, 0},
@@ -200,32 +197,50 @@ __device__ __forceinline__ void franka_fk_frames(const float *q7, float finger, 
       {0.0f, 0.0f, 0.333f},     {0.0f, 0.0f, 0.0f}, {0.0f, -0.316f, 0.0f}, {0.0825f, 0.0f, 0.0f},
       {-0.0825f, 0.384f, 0.0f}, {0.0f, 0.0f, 0.0f}, {0.088f, 0.0f, 0.0f},
   };
-#pragma unroll
-  for (int j = 0; j < 7; ++j) {
+  auto joint = [&](auto J) __attribute__((always_inline)) {
+    constexpr int j = decltype(J)::value;
     float s, c;
     mpx_sincos(q7[j], s, c);
     Rigid tmp = rigid_compose(cur, JR[j], JT[j]);
     cur = rigid_rotz(tmp, s, c);
-    put(j + 1, cur);
-  }
+    visit(std::integral_constant<int, j + 1>{}, cur);
+  };
+  joint(std::integral_constant<int, 0>{});
+  joint(std::integral_constant<int, 1>{});
+  joint(std::integral_constant<int, 2>{});
+  joint(std::integral_constant<int, 3>{});
+  joint(std::integral_constant<int, 4>{});
+  joint(std::integral_constant<int, 5>{});
+  joint(std::integral_constant<int, 6>{});
   const float I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
   const float T8[3] = {0.0f, 0.0f, 0.107f};
   Rigid l8 = rigid_compose(cur, I3, T8);
-  put(8, l8);
+  visit(std::integral_constant<int, 8>{}, l8);
   const float RH[9] = {SH, SH, 0, -SH, SH, 0, 0, 0, 1};
   const float Z3[3] = {0.0f, 0.0f, 0.0f};
   Rigid hand = rigid_compose(l8, RH, Z3);
-  put(9, hand);
+  visit(std::integral_constant<int, 9>{}, hand);
   const float TL[3] = {0.0f, finger, 0.0584f};
   const float TR[3] = {0.0f, -finger, 0.0584f};
   Rigid lf = rigid_compose(hand, I3, TL);
   Rigid rf = rigid_compose(hand, I3, TR);
-  put(10, lf);
-  put(11, rf);
+  visit(std::integral_constant<int, 10>{}, lf);
+  visit(std::integral_constant<int, 11>{}, rf);
   const float TT[3] = {0.0f, 0.0f, 0.045f};
-  put(12, rigid_compose(lf, I3, TT));
-  put(13, rigid_compose(rf, I3, TT));
+  visit(std::integral_constant<int, 12>{}, rigid_compose(lf, I3, TT));
+  visit(std::integral_constant<int, 13>{}, rigid_compose(rf, I3, TT));
   const float RG[9] = {-SH, -SH, 0, SH, -SH, 0, 0, 0, 1};
   const float TG[3] = {0.0f, 0.0f, 0.1f};
-  put(14, rigid_compose(l8, RG, TG));
+  visit(std::integral_constant<int, 14>{}, rigid_compose(l8, RG, TG));
+}
+
+// Writes the 15 frames x 12 floats to `out` (any address space the caller indexes with a plain pointer: LDS or global).
+__device__ __forceinline__ void franka_fk_frames(const float *q7, float finger, float *out) {
+  franka_fk_visit(q7, finger, [&](auto ID, const Rigid &g) __attribute__((always_inline)) {
+    constexpr int id = decltype(ID)::value;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) out[12 * id + k] = g.r[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) out[12 * id + 9 + k] = g.t[k];
+  });
 }

@@ -13,6 +13,8 @@
 // lanes at once (one instruction stream), parks the 15 frames of each in LDS and then all 256
 // threads stream table points through them.
 #include "common.h"
+
+#include <stdlib.h>
 #include "sdf_device.h"
 #include "philox.h"
 #include "select_device.h"
@@ -194,9 +196,7 @@ __global__ void __launch_bounds__(256)
 //   * the (waypoint, sphere) pairs of the chunk are FLATTENED over the lanes: 50 x 56 pairs fill 43.75 waves instead
 //     of 50 waves that each idle 8 of 64 lanes.
 // Arithmetic per (sphere, primitive) and the order of the minima are those of franka_collision_kernel: bit-identical.
-constexpr int COL_TC = 64;
-
-template <int BLOCK>
+template <int BLOCK, int COL_TC>
 __global__ void __launch_bounds__(BLOCK)
     franka_collision_env_kernel(const float *__restrict__ q, int T, int chunks, float finger, const float *__restrict__ sc,
                                 const float *__restrict__ sr, const int32_t *__restrict__ sl, int S,
@@ -267,17 +267,23 @@ MPX_EXPORT int mpx_franka_collision(const float *q, int B, int T, float finger, 
   MPX_REQUIRE((int64_t)B * T < (int64_t)1 << 31, "mpx_franka_collision: B*T overflows int32");
   if (B == 0 || T == 0 || S == 0) return 0;
   if (M1 <= 64 && M2 <= 64 && S <= 64) {  // per-environment form: masks in two scalar words, pairs flattened over the lanes
-    const int chunks = cdiv(T, COL_TC);
-    const size_t lds = (size_t)min(T, COL_TC) * FRAME_FLOATS * sizeof(float);
-    MPX_REQUIRE((int64_t)B * chunks < (int64_t)1 << 31, "mpx_franka_collision: too many workgroups");
-    if (T * S <= 64)  // one waypoint (the rollout step): one wave per environment
-      hipLaunchKernelGGL(franka_collision_env_kernel<64>, dim3((unsigned)(B * chunks)), dim3(64), lds, mpx_s(stream), q, T,
-                         chunks, finger, sph_centers, sph_radii, sph_link, S, cub_frames, cub_dims, M1, cyl_frames, cyl_radii,
-                         cyl_heights, M2, flags, min_sdf);
-    else
-      hipLaunchKernelGGL(franka_collision_env_kernel<256>, dim3((unsigned)(B * chunks)), dim3(256), lds, mpx_s(stream), q, T,
-                         chunks, finger, sph_centers, sph_radii, sph_link, S, cub_frames, cub_dims, M1, cyl_frames, cyl_radii,
-                         cyl_heights, M2, flags, min_sdf);
+#define COL_ENV(BLOCK, TC)                                                                                             \
+  do {                                                                                                                 \
+    const int chunks = cdiv(T, TC);                                                                                    \
+    MPX_REQUIRE((int64_t)B * chunks < (int64_t)1 << 31, "mpx_franka_collision: too many workgroups");                  \
+    hipLaunchKernelGGL((franka_collision_env_kernel<BLOCK, TC>), dim3((unsigned)(B * chunks)), dim3(BLOCK),            \
+                       (size_t)min(T, TC) * FRAME_FLOATS * sizeof(float), mpx_s(stream), q, T, chunks, finger,         \
+                       sph_centers, sph_radii, sph_link, S, cub_frames, cub_dims, M1, cyl_frames, cyl_radii,           \
+                       cyl_heights, M2, flags, min_sdf);                                                               \
+  } while (0)
+    static const int tc_probe = getenv("MPX_COL_TC_PROBE") ? atoi(getenv("MPX_COL_TC_PROBE")) : 0;  // (measurement only; removed once settled)
+    if (T * S <= 64) COL_ENV(64, 64);  // one waypoint (the rollout step): one wave per environment
+    else if (tc_probe == 16) COL_ENV(256, 16);
+    else if (tc_probe == 32) COL_ENV(256, 32);
+    else if (tc_probe == 164) COL_ENV(64, 16);
+    else if (tc_probe == 264) COL_ENV(128, 32);
+    else COL_ENV(256, 64);
+#undef COL_ENV
     MPX_LAUNCH_CHECK("mpx_franka_collision");
   }
   const int G = B * T;

@@ -352,26 +352,28 @@ __device__ __forceinline__ u64 wave_max64_staged(u64 k) {
   return pack64(mlo, mhi);
 }
 
-constexpr int FPSC_CELLS = 4096, FPSC_THREADS = 512, FPSC_WAVES = 8;
-// dynamic LDS: [0,256) reduction slots, [256,512) scalars (position of point 0, cloud bounding box exchange), then the
+constexpr int FPSC_CELLS = 4096;
+// dynamic LDS: [0,256) reduction slots, [256,768) scalars (position of point 0, cloud bounding box exchange), then the
 // cloud in sorted order sx | sy | sz (3 N floats); the prologue's histogram (16 KB) and position -> index map (2 N bytes)
 // live in the same area before the coordinates are written
 __host__ __device__ constexpr size_t fpsc_lds_bytes(int N) {
   const size_t cloud = (size_t)3 * N * 4, pro = (size_t)FPSC_CELLS * 4 + (((size_t)N * 2 + 15) & ~(size_t)15);
-  return 512 + (cloud > pro ? cloud : pro);
+  return 768 + (cloud > pro ? cloud : pro);
 }
-template <int PTS>
-__global__ void __launch_bounds__(FPSC_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
+template <int PTS, int FPSC_WAVES>
+__global__ void __launch_bounds__(64 * FPSC_WAVES) __attribute__((amdgpu_waves_per_eu(FPSC_WAVES / 2, FPSC_WAVES / 2)))
     fps_cull_kernel(const float *__restrict__ xyz, int N, int stride, int npoint, int32_t *__restrict__ idx,
                     float *__restrict__ new_xyz, int new_stride) {
   static_assert(PTS >= 2 && PTS <= 16, "slots per lane");
+  static_assert(FPSC_WAVES == 8 || FPSC_WAVES == 16, "8 waves x 13 points or 16 waves x 7 points");
+  constexpr int FPSC_THREADS = 64 * FPSC_WAVES, CPT = FPSC_CELLS / FPSC_THREADS;  // cells per thread in the scan
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u64 *slots = reinterpret_cast<u64 *>(smem);                    // [2][16]
   int *scal = reinterpret_cast<int *>(smem + 256);               // [0]: sorted position of point 0
-  float *bbx = reinterpret_cast<float *>(smem + 256 + 16);       // [8 waves][6]
-  unsigned *hist = reinterpret_cast<unsigned *>(smem + 512);     // [4096]   (prologue)
-  unsigned short *pmap = reinterpret_cast<unsigned short *>(smem + 512 + FPSC_CELLS * 4);  // [N] (prologue)
-  float *sx = reinterpret_cast<float *>(smem + 512), *sy = sx + N, *sz = sy + N;           // (after the prologue)
+  float *bbx = reinterpret_cast<float *>(smem + 256 + 16);       // [waves][6] (16 waves: ends at byte 656)
+  unsigned *hist = reinterpret_cast<unsigned *>(smem + 768);     // [4096]   (prologue)
+  unsigned short *pmap = reinterpret_cast<unsigned short *>(smem + 768 + FPSC_CELLS * 4);  // [N] (prologue)
+  float *sx = reinterpret_cast<float *>(smem + 768), *sy = sx + N, *sz = sy + N;           // (after the prologue)
 
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -429,11 +431,11 @@ __global__ void __launch_bounds__(FPSC_THREADS) __attribute__((amdgpu_waves_per_
     }
     __syncthreads();
   }
-  {  // exclusive scan of the 4096 cell counts: thread t owns cells 8 t .. 8 t + 7
-    unsigned c8[8], tot = 0;
+  {  // exclusive scan of the 4096 cell counts: thread t owns CPT consecutive cells
+    unsigned c8[CPT], tot = 0;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      c8[e] = hist[tid * 8 + e];
+    for (int e = 0; e < CPT; ++e) {
+      c8[e] = hist[tid * CPT + e];
       tot += c8[e];
     }
     unsigned inc = tot;
@@ -451,8 +453,8 @@ __global__ void __launch_bounds__(FPSC_THREADS) __attribute__((amdgpu_waves_per_
     for (int w = 0; w < FPSC_WAVES; ++w)
       if (w < wave) base += wtot[w];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      hist[tid * 8 + e] = base;
+    for (int e = 0; e < CPT; ++e) {
+      hist[tid * CPT + e] = base;
       base += c8[e];
     }
     __syncthreads();
@@ -637,21 +639,25 @@ MPX_EXPORT int mpx_fps(const float *xyz, int B, int N, int stride, int npoint, i
   }
   if (fast && N > 512) {  // (log2bs == 9 here: the key layout of fps_cull_kernel assumes it)
     const size_t lds_c = fpsc_lds_bytes(N);
-    dim3 gc(B), tc(FPSC_THREADS);
-#define FPS_CULL(P)                                                                                              \
+    // (a 1024-thread form -- 16 waves x 7 points per lane, 64 VGPRs, eight waves per SIMD -- was measured in round 3:
+    // 8.31 ms against 6.41 ms at 8192 environments; the cross-wave reduction over 16 slots and the wider barrier
+    // cost more than the shorter per-wave pass saves.  The kernel stays templated on the wave count.)
+    constexpr int waves = 8;
+    dim3 gc(B), tc(64 * waves);
+#define FPS_CULL(P, W)                                                                                           \
   do {                                                                                                           \
-    if (lds_c > 64 * 1024) MPX_LDS_LIMIT_ONCE(fps_cull_kernel<P>, fpsc_lds_bytes(FPS_MAX_N), "mpx_fps");          \
-    hipLaunchKernelGGL(fps_cull_kernel<P>, gc, tc, lds_c, mpx_s(stream), xyz, N, stride, npoint, idx, new_xyz,   \
+    if (lds_c > 64 * 1024) MPX_LDS_LIMIT_ONCE((fps_cull_kernel<P, W>), fpsc_lds_bytes(FPS_MAX_N), "mpx_fps");     \
+    hipLaunchKernelGGL((fps_cull_kernel<P, W>), gc, tc, lds_c, mpx_s(stream), xyz, N, stride, npoint, idx, new_xyz, \
                        new_stride);                                                                              \
   } while (0)
-    const int pts_c = (N + FPSC_THREADS - 1) / FPSC_THREADS;
-    if (pts_c <= 2) FPS_CULL(2);
-    else if (pts_c <= 4) FPS_CULL(4);
-    else if (pts_c <= 6) FPS_CULL(6);
-    else if (pts_c <= 8) FPS_CULL(8);
-    else if (pts_c <= 10) FPS_CULL(10);
-    else if (pts_c <= 13) FPS_CULL(13);
-    else FPS_CULL(16);
+    const int pts_c = (N + 64 * waves - 1) / (64 * waves);
+    if (pts_c <= 2) FPS_CULL(2, 8);
+    else if (pts_c <= 4) FPS_CULL(4, 8);
+    else if (pts_c <= 6) FPS_CULL(6, 8);
+    else if (pts_c <= 8) FPS_CULL(8, 8);
+    else if (pts_c <= 10) FPS_CULL(10, 8);
+    else if (pts_c <= 13) FPS_CULL(13, 8);
+    else FPS_CULL(16, 8);
 #undef FPS_CULL
     MPX_LAUNCH_CHECK("mpx_fps");
   }

@@ -134,6 +134,7 @@ int64_t carve(char *base, int B, int N, Buffers &bu) {
 // consumes it (a stream wait captures the event's state at the time of the call, so re-use after the join wait has
 // been enqueued is safe; the side stream itself is in order).
 constexpr int OVERLAP_MAX_BATCH = 512;
+constexpr int SA3_CHAIN_MIN_BATCH = 256;  // one workgroup per problem: the fused group-all chain wants a full chip (= model.py)
 struct Side {
   hipStream_t stream = nullptr;
   hipEvent_t fork = nullptr, join = nullptr;
@@ -246,7 +247,12 @@ MPX_EXPORT int mpx_policy_forward(const mpx_policy_weights *w, const float *xyz,
   MPX_TRY(lin(bu.sa3_in, K3, w->sa2_wcentre, w->sa2_nb1, B * NP2, 128, 4, MPX_ACT_NONE, bu.ctr, 128));
   MPX_TRY(mpx_sa_mlp_factored(bu.pre, bu.ctr, bu.nbr2, bu.cnt2, B, NP1, NP2, NS, w->sa2_pack, C1, 128, 128, C2,
                               bu.sa3_in + 3, K3, stream));
-  // ---- group-all module: three dense layers over the B*128 rows, max over each environment's rows --------------
+  // ---- group-all module: B >= SA3_CHAIN_MIN_BATCH problems -> the fused chain (nothing between the rows and the pooled
+  // row touches HBM); fewer: three dense layers over the B*128 rows, max over each environment's rows -------------------
+  if (B >= SA3_CHAIN_MIN_BATCH) {
+    MPX_REQUIRE(w->sa3_pack, "mpx_policy_forward: sa3_pack missing (mpx_sa3_pack_weights)");
+    MPX_TRY(mpx_sa3_chain(bu.sa3_in, K3, B, NP2, w->sa3_pack, K3, H3, H3, C3, bu.pooled, C3, stream));
+  } else {
   MPX_TRY(lin(bu.sa3_in, K3, w->sa3_w[0], w->sa3_b[0], B * NP2, H3, K3, MPX_ACT_RELU, bu.h_a, H3));
   MPX_TRY(lin(bu.h_a, H3, w->sa3_w[1], w->sa3_b[1], B * NP2, H3, H3, MPX_ACT_RELU, bu.h_b, H3));
   if (B > 8) {
@@ -254,6 +260,7 @@ MPX_EXPORT int mpx_policy_forward(const mpx_policy_weights *w, const float *xyz,
   } else {  // a handful of problems: split-K layer + row-max (see model.py)
     MPX_TRY(lin(bu.h_b, H3, w->sa3_w[2], w->sa3_b[2], B * NP2, C3, H3, MPX_ACT_RELU, bu.h_a, C3));
     MPX_TRY(mpx_rowmax(bu.h_a, C3, B, NP2, C3, bu.pooled, C3, stream));
+  }
   }
   // ---- fc head: 1024 -> 4096 -> GN -> 2048 -> GN -> 2048 (into the left part of the decoder's input rows) ------
   MPX_TRY(lin(bu.pooled, C3, w->fc_w[0], w->fc_b[0], B, 4096, C3, MPX_ACT_NONE, bu.fc_a, 4096));

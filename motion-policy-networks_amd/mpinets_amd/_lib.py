@@ -63,6 +63,9 @@ PROTOTYPES = {
     "mpx_sa_mlp_bf16x3_wants_order": [I, I, I, I, I],
     "mpx_sa_pack_bf16x3_size": [I, I, I, I],
     "mpx_sa_pack_bf16x3": [P, P, P, P, P, P, I, I, I, I, P, P],
+    "mpx_sa3_pack_size": [I, I, I, I],
+    "mpx_sa3_pack_weights": [P, I, P, P, P, P, P, I, I, I, I, P, P],
+    "mpx_sa3_chain": [P, I, I, I, P, I, I, I, I, P, I, P],
     "mpx_linear": [P, I, P, P, I, I, I, I, P, I, P],
     "mpx_linear_workspace": [I, I, I],
     "mpx_linear_ws": [P, I, P, P, I, I, I, I, P, I, P, L, P],

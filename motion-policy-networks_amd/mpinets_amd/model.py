@@ -33,6 +33,10 @@ ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
 # this batch size independent branches of the forward are issued on a second HIP stream: the joint-angle encoder
 # next to the point-cloud encoder, SA2's sampling + ball query next to SA1's ball query + grouped MLP.
 OVERLAP_MAX_BATCH = 512  # (= csrc/policy.hip OVERLAP_MAX_BATCH: the single-call forward makes the same choice)
+# From this batch size on the group-all module runs as ONE kernel (mpx_sa3_chain: a workgroup per problem, activations in
+# LDS, nothing between the input rows and the pooled row in HBM); below it the layer-by-layer GEMMs (which split K over
+# the chip for a handful of problems) are quicker.  (= csrc/policy.hip SA3_CHAIN_MIN_BATCH)
+SA3_CHAIN_MIN_BATCH = 256
 _SIDE_STREAMS = {}
 
 
@@ -67,6 +71,7 @@ class MPiNetsPointNet(nn.Module):
         )
         self.after_sampling = None  # optional callable, invoked once SA1's sampling + neighbour search are enqueued
         self._sa3_w0 = None  # first group-all layer with K padded 259 -> 272 (whole 16-float slabs: direct-to-LDS GEMM)
+        self._sa3_pk = None  # (key, mpx_sa3_pack_weights of the group-all module)
         self.dense_precision = "fp32"  # "bf16x3": the large dense layers on the bf16 matrix cores (set_precision)
         self._split = SplitWeights()
         # bf16x3 only: keep the group-all MLP's activations in the split "pairs" form between layers (default) or as
@@ -202,6 +207,24 @@ class MPiNetsPointNet(nn.Module):
             self._sa3_w0 = (key, torch.nn.functional.pad(w, (0, (-w.size(1)) % 16)).contiguous())
         return self._sa3_w0[1]
 
+    def _sa3_pack(self, K3: int) -> Optional[torch.Tensor]:
+        """The group-all module's three layers in the stream order of ``mpx_sa3_chain`` (None: unsupported widths)."""
+        c3 = self.SA_modules[2].convs()
+        dims = (K3, c3[0].out_channels, c3[1].out_channels, c3[2].out_channels)
+        n = _lib.load().mpx_sa3_pack_size(*dims)
+        if n < 0:
+            return None
+        ps = [p for c in c3 for p in (c.weight, c.bias)]
+        key = tuple((p._version, p.data_ptr()) for p in ps) + dims
+        if self._sa3_pk is None or self._sa3_pk[0] != key:
+            pack = torch.empty(n, dtype=torch.float32, device=c3[0].weight.device)
+            w = [_lib.f32c(c.weight.detach().view(c.out_channels, -1)) for c in c3]
+            b = [_lib.f32c(c.bias.detach()) for c in c3]
+            _lib.call("mpx_sa3_pack_weights", _lib.ptr(w[0]), w[0].size(1), _lib.ptr(b[0]), _lib.ptr(w[1]), _lib.ptr(b[1]),
+                      _lib.ptr(w[2]), _lib.ptr(b[2]), *dims, _lib.ptr(pack))
+            self._sa3_pk = (key, pack)
+        return self._sa3_pk[1]
+
     def forward(self, point_cloud: torch.Tensor, out: Optional[torch.Tensor] = None,
                 aux: Optional[dict] = None, side_work: Optional[Callable[[], object]] = None) -> torch.Tensor:
         """point_cloud [B,N,4] (x,y,z,label) on the GPU -> [B,2048].  ``side_work``: launches of an independent
@@ -309,6 +332,17 @@ class MPiNetsPointNet(nn.Module):
                 aux.update(fps_idx1=idx1, xyz1=xyz1, ball_idx1=nbr1, ball_cnt1=cnt1, f1=f1, fps_idx2=idx2, ball_idx2=nbr2,
                            ball_cnt2=cnt2, sa3_in=sa3_in, f3=pooled)
             return self._fc(pooled, out=out)
+        pack3 = (self._sa3_pack(K3) if self.dense_precision == "fp32" and sa2.npoint == 128 and B >= SA3_CHAIN_MIN_BATCH
+                 else None)
+        if pack3 is not None:  # the whole module as one kernel: nothing between the rows and the pooled row in HBM
+            pooled = torch.empty((B, c3[2].out_channels), dtype=torch.float32, device=dev)
+            lib.call("mpx_sa3_chain", lib.ptr(h), K3, B, 128, lib.ptr(pack3), K3, c3[0].out_channels, c3[1].out_channels,
+                     c3[2].out_channels, lib.ptr(pooled), pooled.stride(0))
+            self.last_counts = (cnt1, cnt2)
+            if aux is not None:
+                aux.update(fps_idx1=idx1, xyz1=xyz1, ball_idx1=nbr1, ball_cnt1=cnt1, f1=f1, fps_idx2=idx2, ball_idx2=nbr2,
+                           ball_cnt2=cnt2, sa3_in=sa3_in, f3=pooled)
+            return self._fc(pooled, out=out)
         h = self._lin(h, self._sa3_first_weight(), c3[0].bias, ACT_RELU, source=c3[0].weight)
         h = self._lin(h, c3[1].weight.view(c3[1].out_channels, -1), c3[1].bias, ACT_RELU)
         # last layer + max over each environment's 128 points in one kernel (nothing [B*128,1024] is stored)
@@ -396,6 +430,7 @@ class MotionPolicyNetwork(nn.Module):
                 sa._split.cache.clear()
         enc._split.cache.clear()
         enc._sa3_w0 = None
+        enc._sa3_pk = None
         self._q_w0 = None
         return self
 
@@ -407,7 +442,8 @@ class MotionPolicyNetwork(nn.Module):
         enc = self.point_cloud_encoder
         return (tuple((p.data_ptr(), p._version) for p in self.parameters()),
                 tuple((sa.precision, getattr(sa, "factored", None)) for sa in enc.SA_modules), enc.dense_precision,
-                tuple(len(sa._packed.packs) for sa in enc.SA_modules), enc._sa3_w0 is None, self._q_w0 is None)
+                tuple(len(sa._packed.packs) for sa in enc.SA_modules), enc._sa3_w0 is None, enc._sa3_pk is None,
+                self._q_w0 is None)
 
     def configure_optimizers(self):
         return torch.optim.Adam(self.parameters(), lr=1e-4)
@@ -451,7 +487,8 @@ class MotionPolicyNetwork(nn.Module):
     class _NativeWeights(ctypes.Structure):  # field order = struct mpx_policy_weights (include/mpinets_hip.h)
         _fields_ = [(n, ctypes.c_void_p) for n in ("sa1_pack", "sa2_pack", "sa2_wpoint", "sa2_wcentre", "sa2_nb1")] + \
                    [(n, ctypes.c_void_p * k) for n, k in (("sa3_w", 3), ("sa3_b", 3), ("fc_w", 3), ("fc_b", 3), ("gn_g", 2),
-                                                          ("gn_b", 2), ("qe_w", 5), ("qe_b", 5), ("de_w", 4), ("de_b", 4))]
+                                                          ("gn_b", 2), ("qe_w", 5), ("qe_b", 5), ("de_w", 4), ("de_b", 4))] + \
+                   [("sa3_pack", ctypes.c_void_p)]
 
     def native_weights(self):
         """-> (struct mpx_policy_weights, tensors it points to).  Valid until a parameter changes."""
@@ -472,7 +509,8 @@ class MotionPolicyNetwork(nn.Module):
             "de_w": [f(m.weight) for m in de], "de_b": [f(m.bias) for m in de],
         }
         single = {"sa1_pack": sa1._packed.get(c1, 1, "fp32"), "sa2_pack": sa2._packed.get(c2, c1[-1].out_channels, "fp32"),
-                  "sa2_wpoint": wp, "sa2_wcentre": wc, "sa2_nb1": nb1}
+                  "sa2_wpoint": wp, "sa2_wcentre": wc, "sa2_nb1": nb1,
+                  "sa3_pack": enc._sa3_pack((3 + c2[-1].out_channels + 15) // 16 * 16)}
         w = self._NativeWeights()
         for k, t in single.items():
             setattr(w, k, t.data_ptr())

@@ -730,3 +730,68 @@ def test_operands_on_another_device_are_rejected():
     else:
         with pytest.raises(_lib.MpxError, match="current device"):
             _lib.require_cuda(torch.zeros(1, device="cuda:1"))
+
+
+def test_group_all_chain_kernel_matches_float64_and_the_layered_path():
+    """mpx_sa3_chain (the group-all module as ONE kernel: activations in LDS, nothing between the input rows and the pooled
+    row in HBM) vs a float64 evaluation of the same three layers + max, and vs the layer-by-layer kernels it replaces
+    (mpx_linear x 2 + mpx_linear_rowmax): same function, different fp32 summation order."""
+    from mpinets_amd import _lib
+    from mpinets_amd.model import MotionPolicyNetwork
+
+    torch.manual_seed(12)
+    mdl = MotionPolicyNetwork().to(dev()).eval()
+    enc = mdl.point_cloud_encoder
+    c3 = enc.SA_modules[2].convs()
+    B, K3 = 300, 272
+    x = torch.zeros((B * 128, K3), device=dev())
+    x[:, :259] = torch.randn((B * 128, 259), device=dev()) * 0.7
+    x[5 * 128:6 * 128] = 0.0  # an all-zero environment: the pooled row is relu of the bias chain
+    pack = enc._sa3_pack(K3)
+    assert pack is not None and pack.numel() == _lib.load().mpx_sa3_pack_size(272, 512, 512, 1024)
+    out = torch.empty((B, 1024), device=dev())
+    _lib.call("mpx_sa3_chain", _lib.ptr(x), K3, B, 128, _lib.ptr(pack), K3, 512, 512, 1024, _lib.ptr(out), 1024)
+    w = [c.weight.detach().view(c.out_channels, -1).double() for c in c3]
+    b = [c.bias.detach().double() for c in c3]
+    h = torch.relu(x[:, :259].double() @ w[0].T + b[0])
+    h = torch.relu(h @ w[1].T + b[1])
+    h = torch.relu(h @ w[2].T + b[2])
+    ref = h.view(B, 128, 1024).max(dim=1).values
+    err = (out.double() - ref).abs().max().item()
+    assert err < 1e-5 * max(1.0, ref.abs().max().item()), err
+    # the layered kernels on the same rows
+    from mpinets_amd.pointnet2 import linear
+
+    h1 = linear(x, enc._sa3_first_weight(), c3[0].bias, 1)
+    h2 = linear(h1, c3[1].weight.view(512, -1), c3[1].bias, 1)
+    lay = torch.empty((B, 1024), device=dev())
+    _lib.call("mpx_linear_rowmax", _lib.ptr(h2), 512, _lib.ptr(c3[2].weight.view(1024, -1)), _lib.ptr(c3[2].bias), B * 128, 1024,
+              512, 128, _lib.ptr(lay), 1024)
+    assert (out - lay).abs().max().item() < 2e-6 * max(1.0, ref.abs().max().item())
+    # strided output rows, a second call is bit-identical, bad shapes are refused
+    wide = torch.zeros((B, 1100), device=dev())
+    _lib.call("mpx_sa3_chain", _lib.ptr(x), K3, B, 128, _lib.ptr(pack), K3, 512, 512, 1024, _lib.ptr(wide), 1100)
+    assert torch.equal(wide[:, :1024], out) and (wide[:, 1024:] == 0).all()
+    lib = _lib.load()
+    assert lib.mpx_sa3_chain(x.data_ptr(), K3, B, 64, pack.data_ptr(), K3, 512, 512, 1024, out.data_ptr(), 1024, None) != 0
+    assert lib.mpx_sa3_pack_size(272, 512, 512, 512) == -1
+
+
+def test_policy_forward_is_consistent_across_the_chain_threshold():
+    """B >= 256 problems take the fused group-all kernel, fewer the layered GEMMs: the same problems evaluated on either
+    side of the threshold agree to fp32 rounding (and the single-call C forward makes the same choice: bit-identical)."""
+    from mpinets_amd.model import SA3_CHAIN_MIN_BATCH, MotionPolicyNetwork
+    from mpinets_amd.scenes import make_problem_batch
+
+    torch.manual_seed(6)
+    mdl = MotionPolicyNetwork().to(dev()).eval()
+    B = SA3_CHAIN_MIN_BATCH
+    prob = make_problem_batch(B, seed=41, device=dev(), kinds=("tabletop", "cubby", "dresser"), M1=40, scene_pool=32,
+                              device_clouds=True)
+    with torch.no_grad():
+        big = mdl(prob["xyz"], prob["q_norm"]).clone()
+        nat = mdl.forward_native(prob["xyz"], prob["q_norm"]).clone()
+        lo = torch.cat([mdl(prob["xyz"][i:i + B // 2].contiguous(), prob["q_norm"][i:i + B // 2].contiguous())
+                        for i in (0, B // 2)])
+    assert torch.equal(big, nat)
+    assert (big - lo).abs().max().item() < 2e-6, (big - lo).abs().max().item()

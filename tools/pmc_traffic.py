@@ -15,7 +15,7 @@ d, envs, out = sys.argv[1], int(sys.argv[2]), sys.argv[3]
 def per_launch(path, counter):
     for r in csv.DictReader(open(path)):
         if KERNEL in r["kernel"] and r["counter"] == counter:
-            return float(r["per_launch"])
+            return float(r.get("top_mean") or r["per_launch"])  # (mean over the full-size dispatches)
     raise SystemExit(f"{counter} of {KERNEL} not in {path}")
 
 
@@ -28,7 +28,7 @@ active = per_launch(f"{d}/pass3_summary.csv", "GRBM_GUI_ACTIVE")  # summed over 
 alg = envs * (512 * 128 * 4 + 128 * 128 * 4 + 128 * 256 * 4 + 128 * 128 * 4 // 3)
 json.dump({
     "kernel": "void " + KERNEL, "envs_per_gpu": envs,
-    "source": "profiles/r02_pmc_pass{1,2,3}_envs%d.csv (rocprofv3 --pmc, separate passes)" % envs,
+    "source": "profiles/r03_pmc_pass{1,2,3}_envs%d.csv (rocprofv3 --pmc, separate passes)" % envs,
     "kernel_source_sha256": kernel_source_hash(),
     "fetch_size_kib_per_launch": fetch, "write_size_kib_per_launch": write,
     "correction": "gfx950: FETCH_SIZE counts half of wide (16 B/lane) coalesced reads (MI355X_MICROARCH.md, HBM): reads doubled",
