@@ -13,8 +13,6 @@
 // lanes at once (one instruction stream), parks the 15 frames of each in LDS and then all 256
 // threads stream table points through them.
 #include "common.h"
-
-#include <stdlib.h>
 #include "sdf_device.h"
 #include "philox.h"
 #include "select_device.h"
@@ -276,12 +274,9 @@ MPX_EXPORT int mpx_franka_collision(const float *q, int B, int T, float finger, 
                        sph_centers, sph_radii, sph_link, S, cub_frames, cub_dims, M1, cyl_frames, cyl_radii,           \
                        cyl_heights, M2, flags, min_sdf);                                                               \
   } while (0)
-    static const int tc_probe = getenv("MPX_COL_TC_PROBE") ? atoi(getenv("MPX_COL_TC_PROBE")) : 0;  // (measurement only; removed once settled)
+    // (waypoints per workgroup, measured at 8192 x 50: 64 -> 0.486 ms, 32 -> 0.508, 16 -> 0.570; one- and two-wave
+    // workgroups with 16 / 32 waypoints 0.735 / 0.673: FK runs once per chunk on as many lanes as the chunk has waypoints)
     if (T * S <= 64) COL_ENV(64, 64);  // one waypoint (the rollout step): one wave per environment
-    else if (tc_probe == 16) COL_ENV(256, 16);
-    else if (tc_probe == 32) COL_ENV(256, 32);
-    else if (tc_probe == 164) COL_ENV(64, 16);
-    else if (tc_probe == 264) COL_ENV(128, 32);
     else COL_ENV(256, 64);
 #undef COL_ENV
     MPX_LAUNCH_CHECK("mpx_franka_collision");

@@ -19,7 +19,7 @@
 //   * the last layer flips roles (A = activations, B = weights): rows land on the register axis, the max over the rows is
 //     an in-lane max over 16 registers x 2 row tiles + one cross-half exchange; bias + ReLU after the max (they commute);
 //   * weights are packed on the device (mpx_sa3_pack_weights) in the order the waves consume them: 16 bytes per lane per 4
-//     k-steps, each wave a contiguous stream, fetched one group ahead through a two-deep register ring; the whole pack
+//     k-steps, each wave a contiguous stream, requested three groups ahead through a four-stage register ring; the whole pack
 //     (3.6 MB) is L2-resident and every workgroup streams it once per 64-row pass (7.8 B / clk / CU).
 // Per pass a wave issues 1088 + 2048 + 4096 MFMAs (463 k matrix cycles); the non-matrix work between layers (operand
 // write-back, staging of the next 64 input rows, 6 barriers) is ~2 % of that.
@@ -40,7 +40,6 @@ struct Cfg {
   static_assert(K1 % 8 == 0 && K1 % 16 == 0, "input rows are whole 16-float slabs");
   static_assert(C1 == 128 * WV && C2 == 128 * WV && C3 == 256 * WV, "a wave owns 128 channels (256 of the last layer)");
   static constexpr int KG1 = K1 / 8, KG2 = C1 / 8, KG3 = C2 / 8;  // groups of 4 k-steps (8 channels: 4 per lane half)
-  static_assert(KG1 % 2 == 0 && KG2 % 2 == 0 && KG3 % 2 == 0, "the operand ring has two stages");
   static constexpr int64_t W1_OFF = 0, W2_OFF = (int64_t)C1 * K1, W3_OFF = W2_OFF + (int64_t)C2 * C1;
   static constexpr int64_t B1_OFF = W3_OFF + (int64_t)C3 * C2, B2_OFF = B1_OFF + C1, B3_OFF = B2_OFF + C2;
   static constexpr int64_t TOTAL = B3_OFF + C3;
@@ -117,7 +116,11 @@ __global__ void __launch_bounds__(64 * sa3::WV) __attribute__((amdgpu_waves_per_
   auto run = [&](auto KGt, auto FLIPt, int wbase, f32x16 (&acc)[4][2]) __attribute__((always_inline)) {
     constexpr int KG = decltype(KGt)::value;
     constexpr bool FLIP = decltype(FLIPt)::value;
-    float4 wr[2][4], br[2][2];
+    // operand ring: NS stages, a group's operands are requested NS - 1 groups (96 MFMAs, ~6 k matrix cycles) before they
+    // are used -- the 3.6 MB pack competes with the activation rows for a 4 MB L2 and part of the stream comes from
+    // the Infinity Cache (measured with a two-stage ring: the matrix pipes waited ~18 % of the time on it)
+    constexpr int NS = 4;
+    float4 wr[NS][4], br[NS][2];
     auto fetch = [&](int st, int g) __attribute__((always_inline)) {
 #pragma unroll
       for (int ot = 0; ot < 4; ++ot) wr[st][ot] = sa3_bload16(rsrc, voff, wbase + (g * 4 + ot) * 1024);
@@ -135,14 +138,17 @@ __global__ void __launch_bounds__(64 * sa3::WV) __attribute__((amdgpu_waves_per_
             acc[ot][rt] = FLIP ? sa3_mfma(w, a, acc[ot][rt]) : sa3_mfma(a, w, acc[ot][rt]);
           }
     };
-    fetch(0, 0);
-    for (int g = 0; g < KG; g += 2) {
-      fetch(1, g + 1);
-      asm volatile("" ::: "memory");
-      compute(0);
-      if (g + 2 < KG) fetch(0, g + 2);
-      asm volatile("" ::: "memory");
-      compute(1);
+#pragma unroll
+    for (int st = 0; st < NS - 1; ++st) fetch(st, st);
+    for (int g0 = 0; g0 < KG; g0 += NS) {
+#pragma unroll
+      for (int st = 0; st < NS; ++st) {
+        if (g0 + st < KG) {  // (uniform; false only in the last, partial round)
+          if (g0 + st + NS - 1 < KG) fetch((st + NS - 1) % NS, g0 + st + NS - 1);
+          asm volatile("" ::: "memory");
+          compute(st);
+        }
+      }
     }
   };
   // accumulators of a flipped layer start at the bias: register 4 j + i of channel tile ot = channel 32 ot + 8 j + 4 half + i
