@@ -87,11 +87,19 @@ __device__ __forceinline__ float4 sa3_bload16(__amdgpu_buffer_rsrc_t rsrc, int v
   const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0);
   return make_float4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w));
 }
+template <int I, int E, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+  if constexpr (I < E) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, E>(f);
+  }
+}
 __device__ __forceinline__ float sa3_comp(const float4 &q, int i) { return i == 0 ? q.x : (i == 1 ? q.y : (i == 2 ? q.z : q.w)); }
 
-template <int K1, int C1, int C2, int C3>
+template <int K1, int C1, int C2, int C3, bool PROBE = false>
 __global__ void __launch_bounds__(64 * sa3::WV) __attribute__((amdgpu_waves_per_eu(1, 1)))
-    sa3_chain_kernel(const float *__restrict__ x, int ldx, const float *__restrict__ pack, float *__restrict__ out, int ldo) {
+    sa3_chain_kernel(const float *__restrict__ x, int ldx, const float *__restrict__ pack, float *__restrict__ out, int ldo,
+                     long long *__restrict__ probe = nullptr) {
   using C = sa3::Cfg<K1, C1, C2, C3>;
   using namespace sa3;
   extern __shared__ __attribute__((aligned(16))) float H[];  // [PR][LD]
@@ -122,8 +130,9 @@ __global__ void __launch_bounds__(64 * sa3::WV) __attribute__((amdgpu_waves_per_
     constexpr int NS = 4;
     float4 wr[NS][4], br[NS][2];
     auto fetch = [&](int st, int g) __attribute__((always_inline)) {
+      const int soff = wbase + g * 4096;  // (one scalar add per group: the channel tile rides in the instruction's offset field)
 #pragma unroll
-      for (int ot = 0; ot < 4; ++ot) wr[st][ot] = sa3_bload16(rsrc, voff, wbase + (g * 4 + ot) * 1024);
+      for (int ot = 0; ot < 4; ++ot) wr[st][ot] = sa3_bload16(rsrc, voff + ot * 1024, soff);
       br[st][0] = *reinterpret_cast<const float4 *>(hrow0 + 8 * g);
       br[st][1] = *reinterpret_cast<const float4 *>(hrow0 + 32 * LD + 8 * g);
     };
@@ -140,16 +149,43 @@ __global__ void __launch_bounds__(64 * sa3::WV) __attribute__((amdgpu_waves_per_
     };
 #pragma unroll
     for (int st = 0; st < NS - 1; ++st) fetch(st, st);
-    for (int g0 = 0; g0 < KG; g0 += NS) {
+    // issue order of a group: ONE memory instruction per gap between MFMAs.  A lone wave on a SIMD hides a few issue
+    // slots behind each 64-cycle MFMA but pays for a cluster: with the four weight loads and the two LDS reads of a
+    // group issued back to back the layer loops ran at 0.90 of the matrix floor (s_memtime probe).
+    auto issue_order = [&]() __attribute__((always_inline)) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);  // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // one weight load
+      }
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // one LDS operand read
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+    };
+    // full rounds: every group of the round requests the group NS - 1 ahead (no conditions inside the loop: the wait
+    // counters stay exact); the last groups are unrolled with compile-time conditions
+    constexpr int ROUNDS = (KG - NS + 1) / NS;
+    for (int r = 0; r < ROUNDS; ++r) {
 #pragma unroll
       for (int st = 0; st < NS; ++st) {
-        if (g0 + st < KG) {  // (uniform; false only in the last, partial round)
-          if (g0 + st + NS - 1 < KG) fetch((st + NS - 1) % NS, g0 + st + NS - 1);
-          asm volatile("" ::: "memory");
-          compute(st);
-        }
+        fetch((st + NS - 1) % NS, r * NS + st + NS - 1);
+        compute(st);
+        issue_order();
       }
     }
+    static_for<ROUNDS * NS, KG>([&](auto G) __attribute__((always_inline)) {
+      constexpr int g = decltype(G)::value;
+      if constexpr (g + NS - 1 < KG) {
+        fetch((g + NS - 1) % NS, g + NS - 1);
+        compute(g % NS);
+        issue_order();
+      } else {
+        compute(g % NS);
+      }
+    });
   };
   // accumulators of a flipped layer start at the bias: register 4 j + i of channel tile ot = channel 32 ot + 8 j + 4 half + i
   auto bias_init = [&](int boff_floats, f32x16 (&acc)[4][2]) __attribute__((always_inline)) {
@@ -179,6 +215,14 @@ __global__ void __launch_bounds__(64 * sa3::WV) __attribute__((amdgpu_waves_per_
         }
   };
 
+  int pi = 0;
+  auto stamp = [&]() __attribute__((always_inline)) {
+    if constexpr (PROBE) {
+      if (blockIdx.x == 300 && tid == 0) probe[pi] = (long long)__builtin_amdgcn_s_memtime();
+      ++pi;
+    }
+  };
+  stamp();
   for (int pass = 0; pass < ROWS / PR; ++pass) {
     // ---- the pass's 64 input rows -> LDS (coalesced 16-byte copies; the buffer is free: the previous pass's last layer
     // has been read by every wave -- barrier at the end of the pass)
@@ -188,19 +232,24 @@ __global__ void __launch_bounds__(64 * sa3::WV) __attribute__((amdgpu_waves_per_
       *reinterpret_cast<float4 *>(H + r * LD + 4 * c4) = *reinterpret_cast<const float4 *>(xr + (int64_t)r * ldx + 4 * c4);
     }
     __syncthreads();
+    stamp();
     f32x16 acc[4][2];
     // ---- layer 1: K1 -> C1
     bias_init((int)C::B1_OFF, acc);
     run(std::integral_constant<int, C::KG1>{}, std::true_type{}, (int)(C::W1_OFF * 4) + wave * C::KG1 * 4096, acc);
+    stamp();
     __syncthreads();  // every wave has read the input rows
     write_back(acc);
     __syncthreads();
+    stamp();
     // ---- layer 2: C1 -> C2
     bias_init((int)C::B2_OFF, acc);
     run(std::integral_constant<int, C::KG2>{}, std::true_type{}, (int)(C::W2_OFF * 4) + wave * C::KG2 * 4096, acc);
+    stamp();
     __syncthreads();
     write_back(acc);
     __syncthreads();
+    stamp();
     // ---- layer 3: C2 -> C3 in two halves of this wave's 256 channels; roles flipped; pooled over the pass's rows
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
@@ -216,8 +265,10 @@ __global__ void __launch_bounds__(64 * sa3::WV) __attribute__((amdgpu_waves_per_
         for (int r = 1; r < 16; ++r) m = fmaxf(m, fmaxf(acc[ot][0][r], acc[ot][1][r]));
         pool[hf][ot] = fmaxf(pool[hf][ot], m);
       }
+      stamp();
     }
     __syncthreads();  // the last layer's operand rows are dead: the next pass may overwrite them
+    stamp();
   }
   // ---- pooled row: the two lane halves hold disjoint rows; bias + ReLU after the max
   const float *b3 = pack + C::B3_OFF;
@@ -260,6 +311,17 @@ MPX_EXPORT int mpx_sa3_pack_weights(const float *w1, int k1_real, const float *b
 #undef CALL
 }
 
+// measurement only (not in the header): the same launch with s_memtime stamps of workgroup 300, wave 0 at the phase
+// boundaries -> probe[0..16] (tools/probes/sa3_phase_probe.py)
+MPX_EXPORT int mpx_sa3_chain_probe(const float *x, int ldx, int B, const float *pack, float *out, int ldo, long long *probe,
+                                   mpx_stream_t stream) {
+  using C = sa3::Cfg<272, 512, 512, 1024>;
+  MPX_LDS_LIMIT_ONCE((sa3_chain_kernel<272, 512, 512, 1024, true>), C::LDS_BYTES, "mpx_sa3_chain_probe");
+  hipLaunchKernelGGL((sa3_chain_kernel<272, 512, 512, 1024, true>), dim3((unsigned)B), dim3(64 * sa3::WV), C::LDS_BYTES,
+                     mpx_s(stream), x, ldx, pack, out, ldo, probe);
+  MPX_LAUNCH_CHECK("mpx_sa3_chain_probe");
+}
+
 MPX_EXPORT int mpx_sa3_chain(const float *x, int ldx, int B, int rows, const float *pack, int K1, int c1, int c2, int c3,
                              float *out, int ldo, mpx_stream_t stream) {
   MPX_REQUIRE(B >= 0 && x && pack && out, "mpx_sa3_chain: bad operand");
@@ -272,7 +334,7 @@ MPX_EXPORT int mpx_sa3_chain(const float *x, int ldx, int B, int rows, const flo
     using C = sa3::Cfg<a, b, c, d>;                                                                                 \
     MPX_LDS_LIMIT_ONCE((sa3_chain_kernel<a, b, c, d>), C::LDS_BYTES, "mpx_sa3_chain");                              \
     hipLaunchKernelGGL((sa3_chain_kernel<a, b, c, d>), dim3((unsigned)B), dim3(64 * sa3::WV), C::LDS_BYTES,        \
-                       mpx_s(stream), x, ldx, pack, out, ldo);                                                      \
+                       mpx_s(stream), x, ldx, pack, out, ldo, (long long *)nullptr);                                \
     MPX_LAUNCH_CHECK("mpx_sa3_chain");                                                                              \
   } while (0)
   SA3_DISPATCH(CALL)

@@ -31,6 +31,9 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define PAD_CH (-1)
+#ifndef MPX_SA_SPREAD
+#define MPX_SA_SPREAD 1
+#endif
 
 template <int CF, int C1, int C2, int C3>
 struct SaCfg {
@@ -448,6 +451,23 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CF == 1
     }
   };
 
+  // a quarter of the factored gather (4 of the 16 float4 of this lane-half's row): issued chunk by chunk
+  auto gather_part = [&](int qi, int k, int part) __attribute__((always_inline)) {
+    if constexpr (FACT) {
+      const int64_t b = __shfl(my_env, qi);
+      const float *pa = pre_rows + (b * N + k) * (int64_t)C1 + 4 * half;
+#pragma unroll
+      for (int i = 4 * part; i < 4 * part + 4; ++i) {
+        if (i < C1 / 8) {
+          const float4 v = *reinterpret_cast<const float4 *>(pa + 8 * i);
+          raw_f[4 * i + 0] = v.x;
+          raw_f[4 * i + 1] = v.y;
+          raw_f[4 * i + 2] = v.z;
+          raw_f[4 * i + 3] = v.w;
+        }
+      }
+    }
+  };
   // gather pipeline: the neighbour index of the next tile is fetched at tile start, its data during layer 3
   int q_cur, q_next = 0, k_next = 0;
   {
@@ -465,6 +485,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CF == 1
   // layer is requested while the previous layer still feeds the matrix pipe, and the last chunk of a tile already
   // prefetches the first chunk of the next tile (same addresses).  Only the very first chunk of a wave is exposed.
   constexpr int G1 = FACT ? 0 : Cfg::S1 / 4, G2 = Cfg::S2 / 4, G3 = Cfg::S3 / 4, GT = G1 + G2 + G3;
+  constexpr bool LAZY = FACT && MPX_SA_SPREAD;  // (the factored wide module; C1 / 8 = 16 float4 per gathered row half)
   constexpr int CH = 4, NC0 = (GT + CH - 1) / CH, NC = NC0 + (NC0 & 1);  // even: the ring parity repeats per tile
   constexpr int GPT = Cfg::KS2 / 4;                                      // weight groups per layer-3 output tile
   float4 ring[2][CH];
@@ -561,13 +582,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CF == 1
           a2[ot] = mfma32(comp(w, u), a1[t >> 4][t & 15], a2[ot]);
         }
         if (gg == G2 - 1) {
+          if constexpr (!LAZY) {
 #pragma unroll
-          for (int ot = 0; ot < Cfg::OT2; ++ot)
+            for (int ot = 0; ot < Cfg::OT2; ++ot)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) a2[ot][r] = fmaxf(a2[ot][r], 0.0f);
-          // the next tile's rows are fetched now: layer 3 is long enough to cover the latency and layer 1/2's
-          // inputs (the register peak) are gone
-          if (rt + 32 < total) gather(q_gather, k_gather);
+              for (int r = 0; r < 16; ++r) a2[ot][r] = fmaxf(a2[ot][r], 0.0f);
+            // the next tile's rows are fetched now: layer 3 is long enough to cover the latency and layer 1/2's
+            // inputs (the register peak) are gone
+            if (rt + 32 < total) gather(q_gather, k_gather);
+          }
         }
       } else {
         // ---- layer 3 (roles flipped), pooled per query as each output tile completes.  A lane holds, for its
@@ -576,6 +599,20 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CF == 1
         // whenever the (wave-uniform) query changes.
         const int g3 = g - G1 - G2, ot = g3 / GPT, gg = g3 % GPT;
         if (gg == 0) a3 = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if constexpr (LAZY) {
+          // LAZY (the wide module): the ReLU of layer 2's result is applied register by register just ahead of its first
+          // use (the first output tile's k-steps) and the next tile's rows are requested at the start of the SECOND
+          // output tile, four loads per chunk -- neither a 64-instruction VALU block nor 16 loads back to back stand
+          // in front of the matrix stream
+          if (ot == 0) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int t = 4 * gg + u;
+              a2[t >> 4][t & 15] = fmaxf(a2[t >> 4][t & 15], 0.0f);
+            }
+          }
+          if (ot == 1 && gg < 4 && rt + 32 < total) gather_part(q_gather, k_gather, gg);
+        }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int t = 4 * gg + u;
@@ -611,6 +648,26 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CF == 1
 #pragma unroll
       for (int u = 0; u < CH; ++u)
         if (c * CH + u < GT) step(c * CH + u, ring[c & 1][u]);
+      // issue order of the chunk: its weight loads ONE at a time between MFMAs instead of back to back in front of them
+      // (a cluster of memory instructions costs matrix-pipe time even with other waves on the SIMD: measured on the
+      // group-all kernel, sa3_chain.hip, 0.90 -> 0.98 of the matrix floor inside the layer loops)
+      // (the narrow first module, four waves per SIMD, did not gain: 10.8 -> 11.0 ms; it keeps the compiler's order)
+      if constexpr (MPX_SA_SPREAD && CF != 1) {
+        constexpr int c_ot1 = (G1 + G2 + GPT) / CH;  // first chunk of the second output tile of layer 3
+        if (LAZY && c >= c_ot1 && c < c_ot1 + 4) {   // these chunks also carry a quarter of the next tile's gather
+#pragma unroll
+          for (int u = 0; u < 2 * CH; ++u) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);  // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // one load
+          }
+        } else {
+#pragma unroll
+          for (int u = 0; u < CH; ++u) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);  // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // one weight load
+          }
+        }
+      }
     }
     cur = gq(7);
   }
