@@ -123,8 +123,10 @@ def stage_table(prof, steps, B, sa1_ms, sa1_exec, sa2_ms, sa2_exec, col_flops):
     HBM traffic, the 100 KB slab read once, is negligible)."""
     ms = lambda k: float(np.sum(prof[k])) / steps
     lin_ms = ms("mpx_linear") + ms("mpx_linear_ws") + ms("mpx_linear_rowmax")
+    sa3_ms = ms("mpx_sa3_chain")  # the group-all module as one kernel (B >= 256); 0 when it ran layer by layer
+    sa3_flops = 2.0 * B * 128 * (272 * 512 + 512 * 512 + 512 * 1024)  # (272 = 259 padded to whole slabs: executed work)
     lin_flops = 2.0 * B * (512 * 68 * 128 + 128 * 4 * 128            # SA2 first layer, per point / per query
-                           + 128 * (260 * 512 + 512 * 512 + 512 * 1024)  # group-all module
+                           + (0 if sa3_ms > 0 else 128 * (260 * 512 + 512 * 512 + 512 * 1024))  # group-all module
                            + 1024 * 4096 + 4096 * 2048 + 2048 * 2048    # fc head
                            + 8 * 32 + 32 * 64 + 64 * 128 + 128 * 128 + 128 * 64  # q encoder
                            + 2112 * 512 + 512 * 256 + 256 * 128 + 128 * 7)       # decoder
@@ -147,7 +149,11 @@ def stage_table(prof, steps, B, sa1_ms, sa1_exec, sa2_ms, sa2_exec, col_flops):
         "ball_query": {"bound": "valu", "ms": ms("mpx_ball_query"),
                        "achieved": bq_pairs / (ms("mpx_ball_query") * 1e-3) / 1e9, "unit": "G point-pair tests/s"},
         "sa1_grouped_mlp": mf(sa1_exec, sa1_ms), "sa2_grouped_mlp": mf(sa2_exec, sa2_ms),
-        "dense_layers": dict(mf(lin_flops, lin_ms), note="SA2 layer 1 (factored) + group-all module + heads"),
+        "sa3_group_all_chain": (dict(mf(sa3_flops, sa3_ms), note="mpx_sa3_chain: 3 layers + max-pool of the group-all module in "
+                                     "one kernel, activations in LDS; nothing between the input rows and the pooled row in HBM")
+                                if sa3_ms > 0 else None),
+        "dense_layers": dict(mf(lin_flops, lin_ms), note="SA2 layer 1 (factored) + heads" +
+                             ("" if sa3_ms > 0 else " + group-all module (layer by layer)")),
         "scene_cloud_rerender": dict(hbm(B * 4096 * 12.0, ms("mpx_scene_cloud")),
                                      note="49,152 B written per env; selection (Philox keys + radix select + counting sort in LDS, one workgroup per env) is the long pole, not HBM"),
         "groupnorm_leaky": {"bound": "hbm", "ms": ms("mpx_groupnorm_leaky")},
@@ -262,7 +268,8 @@ def main():
     torch.cuda.synchronize()
     shard.barrier()
     _lib.profile_start("mpx_sa_mlp", "mpx_sa_mlp_factored", "mpx_fps", "mpx_ball_query", "mpx_linear", "mpx_linear_ws", "mpx_linear_rowmax",
-                        "mpx_franka_cloud", "mpx_franka_collision", "mpx_joint_step", "mpx_groupnorm_leaky", "mpx_scene_cloud")
+                        "mpx_franka_cloud", "mpx_franka_collision", "mpx_joint_step", "mpx_groupnorm_leaky", "mpx_scene_cloud",
+                        "mpx_sa3_chain")
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -442,7 +449,8 @@ def main():
         eng_s.step()
         torch.cuda.synchronize()
         shard.barrier()
-        names_s = ("mpx_sa_mlp", "mpx_sa_mlp_factored", "mpx_fps", "mpx_ball_query", "mpx_linear", "mpx_linear_ws", "mpx_linear_rowmax")
+        names_s = ("mpx_sa_mlp", "mpx_sa_mlp_factored", "mpx_fps", "mpx_ball_query", "mpx_linear", "mpx_linear_ws", "mpx_linear_rowmax",
+                   "mpx_sa3_chain")
         _lib.profile_start(*names_s)
         ts0 = time.perf_counter()
         for _ in range(args.static_steps):
@@ -583,6 +591,7 @@ def main():
                 "fps": float(np.sum(prof["mpx_fps"])) / args.steps,
                 "ball_query": float(np.sum(prof["mpx_ball_query"])) / args.steps,
                 "linear_all": float(np.sum(prof["mpx_linear"]) + np.sum(prof["mpx_linear_ws"]) + np.sum(prof["mpx_linear_rowmax"])) / args.steps,
+                "sa3_chain": float(np.sum(prof["mpx_sa3_chain"])) / args.steps,
             },
             # per-stage achieved / peak with the ALGORITHMIC work of SURVEY.md section 8(d) (per env-step, x B envs)
             "stages": stage_table(prof, args.steps, B, sa1_ms, sa1_exec, sa2_ms, sa2_exec,
