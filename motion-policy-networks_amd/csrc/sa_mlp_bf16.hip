@@ -900,6 +900,13 @@ __global__ void __launch_bounds__(64 * v2::WV) __attribute__((amdgpu_waves_per_e
 #pragma unroll
     for (int k = 0; k < 4; ++k) ring[n % RS][k] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff + 1024 * k, base, 0);
   };
+  // ... one block of a stage (round 3): the four loads of a stage go out ONE per MFMA gap, not back to back -- a cluster
+  // of memory instructions in front of a lone wave's MFMAs costs matrix-pipe time (sa3_chain.hip: 0.90 -> 0.98 of the floor)
+  auto fetch2_part = [&](int n, int k) __attribute__((always_inline)) {
+    const int pair = n >> 3, s = n & 7;
+    const int base = W2_OFF + (s * 4 + 2 * pair) * TILE_BYTES;
+    ring[n % RS][k] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, wvoff + 1024 * k, base, 0);
+  };
   auto as_bf = [](const u32x4 &v) __attribute__((always_inline)) { return __builtin_bit_cast(bf16x8, v); };
 #pragma unroll
   for (int n = 0; n < RD; ++n) fetch2(n);
@@ -994,6 +1001,11 @@ __global__ void __launch_bounds__(64 * v2::WV) __attribute__((amdgpu_waves_per_e
         raw_pre[4 * i + 0] = v.x, raw_pre[4 * i + 1] = v.y, raw_pre[4 * i + 2] = v.z, raw_pre[4 * i + 3] = v.w;
       }
     };
+    auto gather_part = [&](int env, int k, int i) __attribute__((always_inline)) {  // one of the row's 16 float4
+      const float *pa = pre_rows + ((int64_t)env * N + k) * (int64_t)C1 + 4 * half;
+      const float4 v = *reinterpret_cast<const float4 *>(pa + 8 * i);
+      raw_pre[4 * i + 0] = v.x, raw_pre[4 * i + 1] = v.y, raw_pre[4 * i + 2] = v.z, raw_pre[4 * i + 3] = v.w;
+    };
     float run[Cfg::OT3];
 #pragma unroll
     for (int ot = 0; ot < Cfg::OT3; ++ot) run[ot] = -__builtin_inff();
@@ -1067,7 +1079,7 @@ __global__ void __launch_bounds__(64 * v2::WV) __attribute__((amdgpu_waves_per_e
 #pragma unroll
       for (int m = 0; m < 96; ++m) {
         const int pair = m / 48, mm = m % 48, s = mm / 6, pass = (mm % 6) / 2, o = mm % 2, n = pair * 8 + s;
-        if (mm % 6 == 0 && n + RD < 16) fetch2(n + RD);  // (the ring never holds more than RS = RD + 1 steps)
+        if (mm % 6 < 4 && n + RD < 16) fetch2_part(n + RD, mm % 6);  // (the ring never holds more than RS = RD + 1 steps)
         a2[2 * pair + o] = mfma_bf16(as_bf(ring[n % RS][2 * o + (pass == 1 ? 1 : 0)]),
                                      pass == 2 ? l1[s >> 1][s & 1] : h1[s >> 1][s & 1], a2[2 * pair + o]);
         // pair A's accumulators are final after MFMA 47: their relu + split rides behind pair B's MFMAs (16 quanta)
@@ -1076,7 +1088,7 @@ __global__ void __launch_bounds__(64 * v2::WV) __attribute__((amdgpu_waves_per_e
       }
       // the next tile's rows are requested now: layer 3 reads LDS only, so these slower loads are not in front of
       // anything the matrix stream waits for; they are consumed from output pair 2 on (~3000 cycles from here)
-      gather(env_gather, k_gather);
+      // (round 3: one gather load per MFMA gap behind the first 16 MFMAs of layer 3, not 16 back to back here)
       V2_FENCE();
       // ---- layer 3 (roles flipped: activations are A, weights B), output tiles in pairs, weights from LDS ------------
       bf16x8 w3r[3][4];  // operand stages: running step n3 = pr * 8 + s lives in stage n3 % 3, read two steps ahead
@@ -1088,6 +1100,11 @@ __global__ void __launch_bounds__(64 * v2::WV) __attribute__((amdgpu_waves_per_e
           w3r[n3 % 3][2 * o] = *reinterpret_cast<const bf16x8 *>(p);
           w3r[n3 % 3][2 * o + 1] = *reinterpret_cast<const bf16x8 *>(p + 1024);
         }
+      };
+      auto load3_part = [&](int n3, int j) __attribute__((always_inline)) {  // one of the step's four LDS reads
+        const int pr = n3 >> 3, s = n3 & 7, o = j >> 1;
+        const unsigned char *p = w3_lane + ((2 * pr + o) * 8 + s) * TILE_BYTES + (j & 1) * 1024;
+        w3r[n3 % 3][j] = *reinterpret_cast<const bf16x8 *>(p);
       };
       load3(0);
       load3(1);
@@ -1117,9 +1134,8 @@ __global__ void __launch_bounds__(64 * v2::WV) __attribute__((amdgpu_waves_per_e
 #pragma unroll
       for (int m = 0; m < 192; ++m) {
         const int pr = m / 48, mm = m % 48, s = mm / 6, pass = (mm % 6) / 2, o = mm % 2, n3 = pr * 8 + s;
-        if (mm % 6 == 0) {
-          if (n3 + 2 < 32) load3(n3 + 2);
-        }
+        if (mm % 6 < 4 && n3 + 2 < 32) load3_part(n3 + 2, mm % 6);
+        if (m >= 4 && m < 4 + 2 * (C1 / 8) && (m & 1) == 0) gather_part(env_gather, k_gather, (m - 4) >> 1);  // the next tile's rows
         {
           const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
           const bf16x8 x = pass == 2 ? l2[s >> 1][s & 1] : h2[s >> 1][s & 1];
@@ -1138,10 +1154,8 @@ __global__ void __launch_bounds__(64 * v2::WV) __attribute__((amdgpu_waves_per_e
           // layer 2)
           if (pr >= 2 && mm % 3 == 1) form_q(cq_next, (pr - 2) * 16 + mm / 3);
         }
-        if (m == 191) {  // the first layer-2 stages of the NEXT tile (the weights never change)
-#pragma unroll
-          for (int n = 0; n < RD; ++n) fetch2(n);
-        }
+        // the first layer-2 stages of the NEXT tile (the weights never change): one block per gap over the last MFMAs
+        if (m >= 192 - 4 * RD) fetch2_part((m - (192 - 4 * RD)) >> 2, (m - (192 - 4 * RD)) & 3);
         V2_FENCE();
       }
       pool(3, 0);
