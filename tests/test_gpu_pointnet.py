@@ -229,3 +229,48 @@ def test_ball_query_bucketed_ragged_query_counts(oracle, N, npoint, nsample):
     np.testing.assert_array_equal(cnt.cpu().numpy(), rcnt)
     np.testing.assert_array_equal(idx.cpu().numpy(), ridx)
     assert rcnt.max() == nsample and rcnt.min() >= 1
+
+
+def test_contraction_order_ab_on_the_device(oracle, tmp_path):
+    """Both sides of the contraction-order A/B are real: the library built with -DMPX_SQDIST_XFIRST (the order rounds 1-2
+    assumed; csrc/Makefile target `xfirst`, loaded in a subprocess through MPX_LIB_PATH) equals the oracle in ITS order 1
+    bit for bit, like the product library equals the oracle in order 0 -- and the two libraries disagree on exactly the
+    clouds on which the two oracle orders disagree."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    alt = os.path.join(root, "motion-policy-networks_amd", "mpinets_amd", "libmpinets_hip_xfirst.so")
+    if not os.path.exists(alt):
+        pytest.skip("libmpinets_hip_xfirst.so not built (make -C csrc xfirst)")
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_oracle_pointnet import _bench_like_clouds
+
+    n = 256
+    x = _bench_like_clouds(n, 23)
+    np.save(tmp_path / "x.npy", x)
+    code = ("import sys, numpy as np, torch; sys.path[:0] = [%r, %r]; from mpinets_amd.pointnet2 import furthest_point_sample, "
+            "ball_query; x = torch.from_numpy(np.load(%r)).cuda(); i, c = furthest_point_sample(x, 512, return_xyz=True); "
+            "b = ball_query(0.05, 128, x, c[:, :128].contiguous()); np.save(%r, i.cpu().numpy()); np.save(%r, b.cpu().numpy())")
+    out = {}
+    for tag, lib in (("product", None), ("xfirst", alt)):
+        env = dict(os.environ)
+        env.pop("MPX_LIB_PATH", None)
+        if lib:
+            env["MPX_LIB_PATH"] = lib
+        fi, fb = str(tmp_path / f"{tag}_i.npy"), str(tmp_path / f"{tag}_b.npy")
+        r = subprocess.run([sys.executable, "-c", code % (root, os.path.join(root, "motion-policy-networks_amd"),
+                                                           str(tmp_path / "x.npy"), fi, fb)], env=env, capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[tag] = (np.load(fi), np.load(fb))
+    for tag, order in (("product", 0), ("xfirst", 1)):
+        oracle.set_sqdist_order(order)
+        try:
+            ref_i = oracle.fps(x, 512)
+            ref_b = oracle.ball_query(oracle.gather_points(x, ref_i)[:, :128], x, 0.05, 128)
+        finally:
+            oracle.set_sqdist_order(0)
+        np.testing.assert_array_equal(out[tag][0], ref_i, err_msg=tag)
+        np.testing.assert_array_equal(out[tag][1], ref_b, err_msg=tag)
