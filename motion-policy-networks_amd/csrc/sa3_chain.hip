@@ -226,10 +226,23 @@ __global__ void __launch_bounds__(64 * sa3::WV) __attribute__((amdgpu_waves_per_
   for (int pass = 0; pass < ROWS / PR; ++pass) {
     // ---- the pass's 64 input rows -> LDS (coalesced 16-byte copies; the buffer is free: the previous pass's last layer
     // has been read by every wave -- barrier at the end of the pass)
+    // (all of a thread's 17 loads are in flight before the first LDS store: as a rolled load -> wait -> store loop the
+    // staging took 20 k cycles per pass, 4 % of the kernel -- s_memtime probe)
     const float *xr = x + (env * ROWS + pass * PR) * (int64_t)ldx;
-    for (int i = tid; i < PR * (K1 / 4); i += 64 * WV) {
-      const int r = i / (K1 / 4), c4 = i - r * (K1 / 4);
-      *reinterpret_cast<float4 *>(H + r * LD + 4 * c4) = *reinterpret_cast<const float4 *>(xr + (int64_t)r * ldx + 4 * c4);
+    constexpr int NX = PR * (K1 / 4) / (64 * WV);
+    static_assert(NX * 64 * WV == PR * (K1 / 4), "the input rows split evenly over the threads");
+    {
+      float4 xb[NX];
+#pragma unroll
+      for (int j = 0; j < NX; ++j) {
+        const int i = tid + j * 64 * WV, r = i / (K1 / 4), c4 = i - r * (K1 / 4);
+        xb[j] = *reinterpret_cast<const float4 *>(xr + (int64_t)r * ldx + 4 * c4);
+      }
+#pragma unroll
+      for (int j = 0; j < NX; ++j) {
+        const int i = tid + j * 64 * WV, r = i / (K1 / 4), c4 = i - r * (K1 / 4);
+        *reinterpret_cast<float4 *>(H + r * LD + 4 * c4) = xb[j];
+      }
     }
     __syncthreads();
     stamp();
