@@ -298,6 +298,8 @@ __device__ __forceinline__ unsigned writelane_u32(unsigned s, int lane, unsigned
   switch (lane) {
     MPX_WL(0) MPX_WL(1) MPX_WL(2) MPX_WL(3) MPX_WL(4) MPX_WL(5) MPX_WL(6) MPX_WL(7)
     MPX_WL(8) MPX_WL(9) MPX_WL(10) MPX_WL(11) MPX_WL(12) MPX_WL(13) MPX_WL(14) MPX_WL(15)
+    MPX_WL(16) MPX_WL(17) MPX_WL(18) MPX_WL(19) MPX_WL(20) MPX_WL(21) MPX_WL(22) MPX_WL(23)
+    MPX_WL(24) MPX_WL(25) MPX_WL(26) MPX_WL(27) MPX_WL(28) MPX_WL(29) MPX_WL(30) MPX_WL(31)
     default: break;
   }
 #undef MPX_WL
@@ -356,17 +358,22 @@ constexpr int FPSC_CELLS = 4096;
 // dynamic LDS: [0,256) reduction slots, [256,768) scalars (position of point 0, cloud bounding box exchange), then the
 // cloud in sorted order sx | sy | sz (3 N floats); the prologue's histogram (16 KB) and position -> index map (2 N bytes)
 // live in the same area before the coordinates are written
-__host__ __device__ constexpr size_t fpsc_lds_bytes(int N) {
-  const size_t cloud = (size_t)3 * N * 4, pro = (size_t)FPSC_CELLS * 4 + (((size_t)N * 2 + 15) & ~(size_t)15);
+__host__ __device__ constexpr size_t fpsc_lds_bytes(int N, bool nocloud = false) {
+  const size_t cloud = nocloud ? 0 : (size_t)3 * N * 4, pro = (size_t)FPSC_CELLS * 4 + (((size_t)N * 2 + 15) & ~(size_t)15);
   return 768 + (cloud > pro ? cloud : pro);
 }
 template <int PTS, int FPSC_WAVES>
-__global__ void __launch_bounds__(64 * FPSC_WAVES) __attribute__((amdgpu_waves_per_eu(FPSC_WAVES / 2, FPSC_WAVES / 2)))
+__global__ void __launch_bounds__(64 * FPSC_WAVES)
+    __attribute__((amdgpu_waves_per_eu(FPSC_WAVES == 4 ? 3 : FPSC_WAVES / 2, FPSC_WAVES == 4 ? 3 : FPSC_WAVES / 2)))
     fps_cull_kernel(const float *__restrict__ xyz, int N, int stride, int npoint, int32_t *__restrict__ idx,
                     float *__restrict__ new_xyz, int new_stride) {
-  static_assert(PTS >= 2 && PTS <= 16, "slots per lane");
-  static_assert(FPSC_WAVES == 8 || FPSC_WAVES == 16, "8 waves x 13 points or 16 waves x 7 points");
+  static_assert(PTS >= 2 && PTS <= 32, "slots per lane");
+  static_assert(FPSC_WAVES == 4 || FPSC_WAVES == 8 || FPSC_WAVES == 16, "4 x 25, 8 x 13 or 16 x 7 points per lane");
   constexpr int FPSC_THREADS = 64 * FPSC_WAVES, CPT = FPSC_CELLS / FPSC_THREADS;  // cells per thread in the scan
+  // NOCLOUD (the 4-wave form): no sorted copy of the cloud in LDS; the coordinates of a pick are fetched from the cloud
+  // in memory by a wave-uniform (scalar) load.  LDS = the prologue's sort scratch (29 KB) instead of 76 KB: three
+  // workgroups per CU.
+  constexpr bool NOCLOUD = FPSC_WAVES == 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   u64 *slots = reinterpret_cast<u64 *>(smem);                    // [2][16]
   int *scal = reinterpret_cast<int *>(smem + 256);               // [0]: sorted position of point 0
@@ -491,9 +498,11 @@ __global__ void __launch_bounds__(64 * FPSC_WAVES) __attribute__((amdgpu_waves_p
       x[i] = pts[(size_t)k * stride + 0];
       y[i] = pts[(size_t)k * stride + 1];
       z[i] = pts[(size_t)k * stride + 2];
-      sx[pos] = x[i];
-      sy[pos] = y[i];
-      sz[pos] = z[i];
+      if constexpr (!NOCLOUD) {
+        sx[pos] = x[i];
+        sy[pos] = y[i];
+        sz[pos] = z[i];
+      }
       const float mag = mpx_sqdist(x[i], y[i], z[i]);
       if (!((double)mag <= 1e-3)) {  // (see fps_kernel)
         // tie order of the reference: smaller (bitrev(k mod 512), k / 512) wins -> larger key wins
@@ -509,7 +518,21 @@ __global__ void __launch_bounds__(64 * FPSC_WAVES) __attribute__((amdgpu_waves_p
   // lane i < PTS walks ITS chunk's 64 points in LDS: no cross-lane traffic (positions past the end of the cloud are
   // clamped to its last point: a repeated point changes neither the box nor `any`; a chunk wholly past the end keeps
   // the inverted box and cub = 0)
-  if (lane < PTS) {
+  if constexpr (NOCLOUD) {
+    // chunk i of this wave = register slot i of its 64 lanes: the box is six wave reductions per slot, parked in lane i
+    static_for<0, PTS>([&](auto I) {
+      constexpr int i = decltype(I)::value;
+      const bool real = (wave + FPSC_WAVES * i) * 64 + lane < N;  // (lanes past the end of the cloud hold no point)
+      const float mnx_ = wave_red_f32<false>(real ? x[i] : INF), mny_ = wave_red_f32<false>(real ? y[i] : INF),
+                  mnz_ = wave_red_f32<false>(real ? z[i] : INF), mxx_ = wave_red_f32<true>(real ? x[i] : -INF),
+                  mxy_ = wave_red_f32<true>(real ? y[i] : -INF), mxz_ = wave_red_f32<true>(real ? z[i] : -INF);
+      const bool any = __builtin_amdgcn_ballot_w64(key[i] != 0) != 0;
+      if (lane == i) {
+        bnx = mnx_, bny = mny_, bnz = mnz_, bxx = mxx_, bxy = mxy_, bxz = mxz_;
+        cub = any ? 1e10f : 0.0f;
+      }
+    });
+  } else if (lane < PTS) {
     const int p0 = (wave + FPSC_WAVES * lane) * 64;
     if (p0 < N) {
       bool any = false;
@@ -527,8 +550,15 @@ __global__ void __launch_bounds__(64 * FPSC_WAVES) __attribute__((amdgpu_waves_p
   }
 
   int old = 0, pos_old = pos0;
+  // NOCLOUD: the coordinates of the current pick travel in wave-uniform registers (first pick: point 0 itself)
+  float cx1 = pts[0], cy1 = pts[1], cz1 = pts[2];
   for (int j = 1; j < npoint; ++j) {
-    const float x1 = sx[pos_old], y1 = sy[pos_old], z1 = sz[pos_old];
+    float x1, y1, z1;
+    if constexpr (NOCLOUD) {
+      x1 = cx1, y1 = cy1, z1 = cz1;
+    } else {
+      x1 = sx[pos_old], y1 = sy[pos_old], z1 = sz[pos_old];
+    }
     if (tid == 0) {
       out[j - 1] = old;
       if (nxyz) {
@@ -581,13 +611,17 @@ __global__ void __launch_bounds__(64 * FPSC_WAVES) __attribute__((amdgpu_waves_p
       old = (int)((((rank >> 18) & 0x1Fu) << 9) | __brev(rank & 0xFF800000u));
       pos_old = (int)(rank & 0x1FFFu);
     }
+    if constexpr (NOCLOUD) {  // the pick's coordinates: a wave-uniform (scalar) load of its row -- the cloud is L2-hot
+      const float *pp = pts + (size_t)old * stride;
+      cx1 = pp[0], cy1 = pp[1], cz1 = pp[2];
+    }
   }
   if (tid == 0 && npoint > 0) {
     out[npoint - 1] = old;
     if (nxyz) {
-      nxyz[(size_t)(npoint - 1) * new_stride + 0] = sx[pos_old];
-      nxyz[(size_t)(npoint - 1) * new_stride + 1] = sy[pos_old];
-      nxyz[(size_t)(npoint - 1) * new_stride + 2] = sz[pos_old];
+      nxyz[(size_t)(npoint - 1) * new_stride + 0] = NOCLOUD ? cx1 : sx[pos_old];
+      nxyz[(size_t)(npoint - 1) * new_stride + 1] = NOCLOUD ? cy1 : sy[pos_old];
+      nxyz[(size_t)(npoint - 1) * new_stride + 2] = NOCLOUD ? cz1 : sz[pos_old];
     }
   }
 }
@@ -638,11 +672,13 @@ MPX_EXPORT int mpx_fps(const float *xyz, int B, int N, int stride, int npoint, i
     MPX_LAUNCH_CHECK("mpx_fps");
   }
   if (fast && N > 512) {  // (log2bs == 9 here: the key layout of fps_cull_kernel assumes it)
-    const size_t lds_c = fpsc_lds_bytes(N);
-    // (a 1024-thread form -- 16 waves x 7 points per lane, 64 VGPRs, eight waves per SIMD -- was measured in round 3:
-    // 8.31 ms against 6.41 ms at 8192 environments; the cross-wave reduction over 16 slots and the wider barrier
-    // cost more than the shorter per-wave pass saves.  The kernel stays templated on the wave count.)
-    constexpr int waves = 8;
+    // large clouds (the first module's 6272 points): the 4-wave form without the LDS copy of the cloud -- three
+    // workgroups per CU instead of two (6.45 -> 6.11 ms at 8192 environments; with the LDS copy, two per CU: 7.10 ms)
+    const int waves = N > 16 * 256 ? 4 : 8;
+    const size_t lds_c = fpsc_lds_bytes(N, waves == 4);
+    // (wave counts measured in round 3 at 8192 environments x 6272 points: 16 waves x 7 points per lane 8.31 ms, 8 x 13
+    // 6.41 ms, 4 x 25 with the LDS cloud copy 7.10 ms, 4 x 25 without it 6.11 ms: the cross-wave reduction and the
+    // barrier get cheaper with fewer waves, the per-wave pass longer; what pays is the third workgroup per CU.)
     dim3 gc(B), tc(64 * waves);
 #define FPS_CULL(P, W)                                                                                           \
   do {                                                                                                           \
@@ -651,7 +687,11 @@ MPX_EXPORT int mpx_fps(const float *xyz, int B, int N, int stride, int npoint, i
                        new_stride);                                                                              \
   } while (0)
     const int pts_c = (N + 64 * waves - 1) / (64 * waves);
-    if (pts_c <= 2) FPS_CULL(2, 8);
+    if (waves == 4) {
+      if (pts_c <= 20) FPS_CULL(20, 4);
+      else if (pts_c <= 25) FPS_CULL(25, 4);
+      else FPS_CULL(32, 4);
+    } else if (pts_c <= 2) FPS_CULL(2, 8);
     else if (pts_c <= 4) FPS_CULL(4, 8);
     else if (pts_c <= 6) FPS_CULL(6, 8);
     else if (pts_c <= 8) FPS_CULL(8, 8);
