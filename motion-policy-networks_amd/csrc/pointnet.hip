@@ -674,7 +674,9 @@ MPX_EXPORT int mpx_fps(const float *xyz, int B, int N, int stride, int npoint, i
   if (fast && N > 512) {  // (log2bs == 9 here: the key layout of fps_cull_kernel assumes it)
     // large clouds (the first module's 6272 points): the 4-wave form without the LDS copy of the cloud -- three
     // workgroups per CU instead of two (6.45 -> 6.11 ms at 8192 environments; with the LDS copy, two per CU: 7.10 ms)
-    const int waves = N > 16 * 256 ? 4 : 8;
+    // (a few hundred environments or fewer are latency-bound, not throughput-bound: they keep the 8-wave form, whose pick
+    // chain is shorter -- one planning problem: 0.69 vs 0.80 ms per step.  Same indices either way.)
+    const int waves = (N > 16 * 256 && B >= 768) ? 4 : 8;
     const size_t lds_c = fpsc_lds_bytes(N, waves == 4);
     // (wave counts measured in round 3 at 8192 environments x 6272 points: 16 waves x 7 points per lane 8.31 ms, 8 x 13
     // 6.41 ms, 4 x 25 with the LDS cloud copy 7.10 ms, 4 x 25 without it 6.11 ms: the cross-wave reduction and the
