@@ -296,6 +296,13 @@ int mpx_ball_query(const float *new_xyz, int new_stride, const float *xyz, int s
                    int N, int npoint, float radius, int nsample, int32_t *idx, int32_t *cnt,
                    mpx_stream_t stream);
 
+/* The same search, writing the HIT slots only: idx[b, j, 0 .. max(cnt, 1)) (an empty row still gets its slot 0 = 0); the
+ * padding slots are left untouched.  For consumers that take `cnt` and never look past it (mpx_sa_mlp / _factored /
+ * _bf16x3 with counts): most of a row is padding, so most of the index writes go away.  cnt is required.             */
+int mpx_ball_query_hits(const float *new_xyz, int new_stride, const float *xyz, int stride, int B,
+                        int N, int npoint, float radius, int nsample, int32_t *idx, int32_t *cnt,
+                        mpx_stream_t stream);
+
 /* order[i] = query ids (0..n-1) sorted by DEcreasing number of rows they contribute to the packed
  * SA kernels, 4*ceil(clamp(cnt,1,nsample)/4) (ties in unspecified order).  scratch: int32[128]
  * device words (zeroed by the call).  Gives the lockstep waves of mpx_sa_mlp_bf16x3 equal work. */

@@ -204,7 +204,7 @@ MPX_EXPORT int mpx_policy_forward(const mpx_policy_weights *w, const float *xyz,
     hipLaunchKernelGGL(zero_tail_kernel, dim3(cdiv((int64_t)B * NP2 * (K3 - 3 - C2 + 1), 256)), dim3(256), 0, mpx_s(s2), bu.sa3_in,
                        (int64_t)B * NP2);
     MPX_TRY(mpx_fps(bu.xyz1, B, NP1, 3, NP2, bu.idx2, bu.sa3_in, K3, s2));
-    MPX_TRY(mpx_ball_query(bu.sa3_in, K3, bu.xyz1, 3, B, NP1, NP2, R2, NS, bu.nbr2, bu.cnt2, s2));
+    MPX_TRY(mpx_ball_query_hits(bu.sa3_in, K3, bu.xyz1, 3, B, NP1, NP2, R2, NS, bu.nbr2, bu.cnt2, s2));  // (hit slots only)
     // joint encoder 7 -> 32 -> 64 -> 128 -> 128 -> 64, into the right part of the decoder's input rows
     // (no layer here has K >= 256: none of them touches the split-K area the other stream may be using)
     hipLaunchKernelGGL(pad_q_kernel, dim3(cdiv((int64_t)B * 8, 256)), dim3(256), 0, mpx_s(s2), q, B, bu.q8);
@@ -216,7 +216,7 @@ MPX_EXPORT int mpx_policy_forward(const mpx_policy_weights *w, const float *xyz,
     return 0;
   };
   auto module_sa1 = [&]() -> int {  // neighbours within 5 cm, grouped MLP over [p - c ; label] rows
-    MPX_TRY(mpx_ball_query(bu.xyz1, 3, xyz, 4, B, N, NP1, R1, NS, bu.nbr1, bu.cnt1, stream));
+    MPX_TRY(mpx_ball_query_hits(bu.xyz1, 3, xyz, 4, B, N, NP1, R1, NS, bu.nbr1, bu.cnt1, stream));
     // (its rows come out as [f1 | xyz1 | 0]: the operand of SA2's per-point first-layer GEMM)
     MPX_TRY(mpx_sa_mlp(xyz, 4, bu.xyz1, 3, xyz + 3, 4, 1, bu.nbr1, bu.cnt1, B, N, NP1, NS, w->sa1_pack, 64, 64, C1, bu.f1,
                        F1, 1, stream));

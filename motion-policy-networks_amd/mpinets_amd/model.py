@@ -274,13 +274,19 @@ class MPiNetsPointNet(nn.Module):
         nbr2 = torch.empty((B, sa2.npoint, sa2.nsample), dtype=torch.int32, device=dev)
         cnt2 = torch.empty((B, sa2.npoint), dtype=torch.int32, device=dev)
 
+        # the fused grouped-MLP kernels take the hit counts and never look past them: the ball queries then write the hit
+        # slots only (most of a 128-slot row is padding).  With `aux` (callers that want the reference's full index rows)
+        # or with padding elision off, the rows are padded like pointnet2_ops pads them.
+        bq1 = "mpx_ball_query_hits" if (aux is None and sa1.elide_padding) else "mpx_ball_query"
+        bq2 = "mpx_ball_query_hits" if (aux is None and sa2.elide_padding) else "mpx_ball_query"
+
         def sample_sa2():  # needs only xyz1
             lib.call("mpx_fps", lib.ptr(xyz1), B, sa1.npoint, 3, sa2.npoint, lib.ptr(idx2), lib.ptr(sa3_in), K3)
-            lib.call("mpx_ball_query", lib.ptr(sa3_in), K3, lib.ptr(xyz1), 3, B, sa1.npoint, sa2.npoint,
+            lib.call(bq2, lib.ptr(sa3_in), K3, lib.ptr(xyz1), 3, B, sa1.npoint, sa2.npoint,
                      float(sa2.radius), sa2.nsample, lib.ptr(nbr2), lib.ptr(cnt2))
 
         def module_sa1():
-            lib.call("mpx_ball_query", lib.ptr(xyz1), 3, lib.ptr(pc), 4, B, N, sa1.npoint, float(sa1.radius),
+            lib.call(bq1, lib.ptr(xyz1), 3, lib.ptr(pc), 4, B, N, sa1.npoint, float(sa1.radius),
                      sa1.nsample, lib.ptr(nbr1), lib.ptr(cnt1))
             if self.after_sampling is not None:  # (PipelinedRollout: the next share may start its own sampling now)
                 self.after_sampling()

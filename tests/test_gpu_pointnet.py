@@ -274,3 +274,33 @@ def test_contraction_order_ab_on_the_device(oracle, tmp_path):
             oracle.set_sqdist_order(0)
         np.testing.assert_array_equal(out[tag][0], ref_i, err_msg=tag)
         np.testing.assert_array_equal(out[tag][1], ref_b, err_msg=tag)
+
+
+@pytest.mark.parametrize("N,npoint,radius,nsample,stride", [(6272, 512, 0.05, 128, 4), (512, 128, 0.3, 128, 3), (2047, 128, 0.05, 128, 4),
+                                                            (3000, 1000, 0.08, 64, 3), (300, 70, 0.5, 16, 4)])
+def test_ball_query_hits_only_entry_point(oracle, N, npoint, radius, nsample, stride):
+    """mpx_ball_query_hits writes the hit slots of every row and nothing else: slots [0, max(cnt, 1)) and the counts equal
+    the oracle's (an empty row holds index 0 in slot 0), the remaining slots keep the sentinel the buffer was filled
+    with.  The fused grouped-MLP kernels read exactly those slots."""
+    from mpinets_amd import _lib
+
+    rng = np.random.default_rng(N + nsample)
+    B = 3
+    x = np.zeros((B, N, stride), np.float32)
+    x[..., :3] = rng.uniform(-0.5, 0.5, (B, N, 3))
+    x[:, 50:50 + 2 * nsample, :3] = np.float32([0.1, 0.2, -0.1]) + rng.normal(scale=radius * 0.2, size=(B, 2 * nsample, 3))
+    centres = np.ascontiguousarray(x[:, rng.permutation(N)[:npoint], :3]).copy()
+    centres[:, 0] = [0.1, 0.2, -0.1]   # more than nsample hits
+    centres[:, 1] = 50.0               # none
+    xd, cd = T(x), T(centres)
+    idx = torch.full((B, npoint, nsample), -7, dtype=torch.int32, device=dev())
+    cnt = torch.full((B, npoint), -7, dtype=torch.int32, device=dev())
+    _lib.call("mpx_ball_query_hits", _lib.ptr(cd), 3, _lib.ptr(xd), stride, B, N, npoint, float(radius), nsample, _lib.ptr(idx),
+              _lib.ptr(cnt), _lib.stream_ptr())
+    ref, rcnt = oracle.ball_query(centres, x, radius, nsample, return_counts=True)
+    got, gcnt = idx.cpu().numpy(), cnt.cpu().numpy()
+    np.testing.assert_array_equal(gcnt, rcnt)
+    assert rcnt[:, 0].min() == nsample and rcnt[:, 1].max() == 0
+    live = np.arange(nsample)[None, None, :] < np.maximum(rcnt, 1)[..., None]
+    np.testing.assert_array_equal(got[live], ref[live])
+    assert (got[~live] == -7).all()

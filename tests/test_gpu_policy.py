@@ -323,6 +323,27 @@ def test_padding_elision_is_bit_identical(precision):
     assert c1.min() >= 1 and c2.max() <= 128
 
 
+@pytest.mark.parametrize("precision,factored", [("fp32", True), ("fp32", False), ("bf16x3", True), ("bf16x3", False)])
+def test_hits_only_ball_query_rows_do_not_change_the_forward(precision, factored):
+    """Without ``aux`` the forward's ball queries write the hit slots only (mpx_ball_query_hits); with ``aux`` they pad the
+    rows the way pointnet2_ops does.  The grouped-MLP kernels never read past the counts: same output bits, also when the
+    index rows held a wrong index in every slot before the call (a poisoned caching-allocator block)."""
+    from mpinets_amd.model import MotionPolicyNetwork
+    from mpinets_amd.scenes import make_problem_batch
+
+    torch.manual_seed(8)
+    mdl = MotionPolicyNetwork().to(dev()).eval().set_precision(precision).set_factored(factored)
+    prob = make_problem_batch(6, seed=21, device=dev(), kinds=("tabletop", "cubby", "dresser"), M1=40, device_clouds=True)
+    with torch.no_grad():
+        padded = mdl(prob["xyz"], prob["q_norm"], aux={})
+        torch.cuda.synchronize()
+        for _ in range(3):  # blocks of the sizes the forward takes, released full of a valid but wrong point index
+            junk = [torch.full((6, n, 128), 5, dtype=torch.int32, device=dev()) for n in (512, 128)]
+            del junk
+            hits = mdl(prob["xyz"], prob["q_norm"])
+            assert torch.equal(padded, hits)
+
+
 @pytest.mark.parametrize("factored", [True, False])
 def test_small_batch_launch_shape_is_bit_identical(factored):
     """A single problem runs the grouped-MLP kernels with fewer queries per wave than a large batch (more waves,
