@@ -301,7 +301,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CF == 1
                          const int32_t *__restrict__ idx, const int32_t *__restrict__ cnt, int64_t n_query, int N,
                          int npoint, int nsample, const float *__restrict__ wpack, float *__restrict__ out,
                          int out_stride, int bpe, const float *__restrict__ pre_rows, const float *__restrict__ ctr,
-                         int append_centre) {
+                         int append_centre, unsigned int *__restrict__ queue) {
   using Cfg = SaCfg<CF, C1, C2, C3>;
   __shared__ float ctr_s[FACT ? Q * C1 : 1];
   // biases in LDS: they initialise the accumulators at every tile and are added at every flush -- as global loads
@@ -313,10 +313,69 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CF == 1
   // XCD-aware order: hardware dispatches workgroup h to XCD h % 8 (observed, used for speed only).  All
   // workgroups of one environment are given to one XCD so its cloud / feature rows are fetched into ONE L2
   // instead of eight (bpe = workgroups per environment; falls back to the natural order for ragged grids).
-  int64_t wg = blockIdx.x;
-  if (bpe > 0) {
-    const int64_t xcd = wg & 7, slot = wg >> 3;
-    wg = ((slot / bpe) * 8 + xcd) * bpe + slot % bpe;
+  // PERSISTENT launch (queue != nullptr; one workgroup per wave slot of the chip): the units -- Q consecutive queries --
+  // are handed out by a device-side queue, one counter per XCD (an environment's units stay on one XCD, in order), the
+  // next one requested when the current one starts.  Units differ 1 : 30 in rows: as one workgroup per unit the wave
+  // slots stood empty 13 % of the kernel (SQ_WAVE_CYCLES: 6.97 of 8 waves per CU resident), and the matrix pipes with them.
+  const int64_t n_units = (n_query + Q - 1) / Q;
+  const int xcd = blockIdx.x & 7;
+  const int64_t j_end = bpe > 0 ? n_units / 8 : n_units;  // units of this workgroup's queue
+  int steal = 0;  // queues beyond the own one this wave has moved on to (an XCD that runs dry helps the next one out:
+                  // the environments' row counts differ, and so do the sums over an XCD's share of them)
+  auto next_unit = [&]() __attribute__((always_inline)) {
+    unsigned int v = 0;
+    if (lane == 0) v = atomicAdd(queue + (bpe > 0 ? ((xcd + steal) & 7) : 0), 1u);
+    return (int64_t)(unsigned int)__builtin_amdgcn_readfirstlane((int)v);
+  };
+  const __amdgpu_buffer_rsrc_t wrsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(wpack), 0, (int)(Cfg::TOTAL * 4), 0x00020000);
+  const int wvoff = lane * 16;
+  for (int i = threadIdx.x; i < C1; i += 64) b1_s[i] = wpack[Cfg::B1_OFF + i];
+  for (int i = threadIdx.x; i < C2; i += 64) b2_s[i] = wpack[Cfg::B2_OFF + i];
+  for (int i = threadIdx.x; i < C3; i += 64) b3_s[i] = wpack[Cfg::B3_OFF + i];
+  // The weights of the layers this kernel evaluates are ONE contiguous stream of 16-byte-per-lane groups (4 MFMA
+  // steps each) in wpack: it is walked through a two-deep register ring that never drains -- the first chunk of a
+  // layer is requested while the previous layer still feeds the matrix pipe, and the last chunk of a tile already
+  // prefetches the first chunk of the next tile (same addresses; also across units).  Only the very first chunk of a
+  // wave is exposed.
+  constexpr int G1 = FACT ? 0 : Cfg::S1 / 4, G2 = Cfg::S2 / 4, G3 = Cfg::S3 / 4, GT = G1 + G2 + G3;
+  constexpr bool LAZY = FACT && MPX_SA_SPREAD;  // (the factored wide module; C1 / 8 = 16 float4 per gathered row half)
+  constexpr int CH = 4, NC0 = (GT + CH - 1) / CH, NC = NC0 + (NC0 & 1);  // even: the ring parity repeats per tile
+  constexpr int GPT = Cfg::KS2 / 4;                                      // weight groups per layer-3 output tile
+  float4 ring[2][CH];
+  auto fetch = [&](int c, int base) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < CH; ++u)
+      if (c * CH + u < GT) ring[c & 1][u] = bload16(wrsrc, wvoff, base + (c * CH + u) * 1024);
+  };
+  {
+    int wb = (int)(FACT ? Cfg::W2_OFF : Cfg::W1_OFF) * 4;
+    asm volatile("" : "+s"(wb));
+    fetch(0, wb);
+  }
+  int64_t j_next = queue ? next_unit() : 0;
+  for (bool first = true;; first = false) {
+  int64_t wg;
+  if (queue) {
+    int64_t j = j_next;
+    bool dry = false;
+    while (j >= j_end) {
+      if (bpe == 0 || ++steal == 8) {
+        dry = true;
+        break;
+      }
+      j = next_unit();
+    }
+    if (dry) break;
+    j_next = next_unit();
+    wg = bpe > 0 ? ((j / bpe) * 8 + ((xcd + steal) & 7)) * bpe + j % bpe : j;
+  } else {
+    if (!first) break;
+    wg = blockIdx.x;
+    if (bpe > 0) {
+      const int64_t slot = wg >> 3;
+      wg = ((slot / bpe) * 8 + xcd) * bpe + slot % bpe;
+    }
   }
   const int64_t q0 = wg * Q;
   const int nq = (int)min((int64_t)Q, n_query - q0);
@@ -354,13 +413,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CF == 1
     s_cnt[i] = __builtin_amdgcn_readlane(my_cnt, i);
   }
 
-  const __amdgpu_buffer_rsrc_t wrsrc =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(wpack), 0, (int)(Cfg::TOTAL * 4), 0x00020000);
-  const int wvoff = lane * 16;
-  for (int i = threadIdx.x; i < C1; i += 64) b1_s[i] = wpack[Cfg::B1_OFF + i];
-  for (int i = threadIdx.x; i < C2; i += 64) b2_s[i] = wpack[Cfg::B2_OFF + i];
-  for (int i = threadIdx.x; i < C3; i += 64) b3_s[i] = wpack[Cfg::B3_OFF + i];
-  __syncthreads();
+  __syncthreads();  // (biases / query terms visible; a one-wave workgroup: no more than the LDS wait)
   // register r of a tile holds channel ot*32 + (r&3) + 8*(r>>2) + 4*half
   auto bias_lds = [&](const float *bs, int ot) __attribute__((always_inline)) {
     f32x16 v;
@@ -478,26 +531,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CF == 1
       map_row(32 + col, q_next, off);
       k_next = idx[(q0 + q_next) * nsample + off];
     }
-  }
-
-  // The weights of the layers this kernel evaluates are ONE contiguous stream of 16-byte-per-lane groups (4 MFMA
-  // steps each) in wpack: it is walked through a two-deep register ring that never drains -- the first chunk of a
-  // layer is requested while the previous layer still feeds the matrix pipe, and the last chunk of a tile already
-  // prefetches the first chunk of the next tile (same addresses).  Only the very first chunk of a wave is exposed.
-  constexpr int G1 = FACT ? 0 : Cfg::S1 / 4, G2 = Cfg::S2 / 4, G3 = Cfg::S3 / 4, GT = G1 + G2 + G3;
-  constexpr bool LAZY = FACT && MPX_SA_SPREAD;  // (the factored wide module; C1 / 8 = 16 float4 per gathered row half)
-  constexpr int CH = 4, NC0 = (GT + CH - 1) / CH, NC = NC0 + (NC0 & 1);  // even: the ring parity repeats per tile
-  constexpr int GPT = Cfg::KS2 / 4;                                      // weight groups per layer-3 output tile
-  float4 ring[2][CH];
-  auto fetch = [&](int c, int base) __attribute__((always_inline)) {
-#pragma unroll
-    for (int u = 0; u < CH; ++u)
-      if (c * CH + u < GT) ring[c & 1][u] = bload16(wrsrc, wvoff, base + (c * CH + u) * 1024);
-  };
-  {
-    int wb = (int)(FACT ? Cfg::W2_OFF : Cfg::W1_OFF) * 4;
-    asm volatile("" : "+s"(wb));
-    fetch(0, wb);
   }
 
   for (int rt = 0; rt < total; rt += 32) {
@@ -673,9 +706,23 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CF == 1
   }
 #pragma unroll
   for (int ot = 0; ot < Cfg::OT3; ++ot) flush(ot, cur);
+  }  // units
 }
 
 // ---- host entry points -----------------------------------------------------------------------------------
+// wave slots of the current device for a one-wave workgroup at `per_cu` waves per CU (the persistent launches' grid;
+// a multiple of 8: the hardware deals workgroups to the XCDs round-robin)
+static int64_t sa_wave_slots(int per_cu) {
+  static std::atomic<int> cus[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  int n = cus[dev & 63].load(std::memory_order_relaxed);
+  if (n == 0) {
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return 0;
+    cus[dev & 63].store(n, std::memory_order_relaxed);
+  }
+  return ((int64_t)n * per_cu) & ~(int64_t)7;
+}
 template <int CF, int C1, int C2, int C3>
 static int launch_sa(const float *xyz, int stride, const float *new_xyz, int new_stride, const float *feat,
                      int feat_stride, const int32_t *idx, const int32_t *cnt, int B, int N, int npoint, int nsample,
@@ -689,17 +736,30 @@ static int launch_sa(const float *xyz, int stride, const float *new_xyz, int new
     // dozen) would leave most CUs idle at that size, so it runs QS queries per wave instead: same rows, same
     // arithmetic per row (bit-identical results), 4x the waves and a quarter of the latency.
     constexpr int QL = CF == 1 ? 16 : 8, QS = CF == 1 ? 4 : 2;
+    int rc = 0;
     auto go = [&](auto qtag) {
       constexpr int Q = decltype(qtag)::value;
-      const int64_t nw = (nq + Q - 1) / Q;
+      int64_t nw = (nq + Q - 1) / Q;
       // whole environments per XCD when the grid is regular (npoint % Q == 0, B % 8 == 0)
       const int bpe = (npoint % Q == 0 && B % 8 == 0) ? npoint / Q : 0;
+      unsigned int *queue = nullptr;
+      const int64_t slots = sa_wave_slots(CF == 1 ? 16 : 8);
+      if (slots > 0 && nw >= 4 * slots) {  // many units per wave slot: one workgroup per slot, units from the device-side queue
+        queue = mpx_unit_queue_for(mpx_s(stream));
+        if (!queue) {
+          mpx_set_error("mpx_sa_mlp: cannot reset the unit queue");
+          rc = 1;
+          return;
+        }
+        nw = slots;
+      }
       hipLaunchKernelGGL((sa_mlp_packed_kernel<CF, C1, C2, C3, Q, false>), dim3((unsigned)nw), dim3(64), 0,
                          mpx_s(stream), xyz, stride, new_xyz, new_stride, feat, feat_stride, idx, cnt, nq, N, npoint,
-                         nsample, wpack, out, out_stride, bpe, nullptr, nullptr, append_centre);
+                         nsample, wpack, out, out_stride, bpe, nullptr, nullptr, append_centre, queue);
     };
     if (nq >= 1024 * QL) go(std::integral_constant<int, QL>{});
     else go(std::integral_constant<int, QS>{});
+    if (rc) return rc;
   } else {
     hipLaunchKernelGGL((sa_mlp_kernel<CF, C1, C2, C3>), dim3((unsigned)((nq + 3) / 4)), dim3(256), 0,
                        mpx_s(stream), xyz, stride, new_xyz, new_stride, feat, feat_stride, idx, nq, N, npoint,
@@ -746,17 +806,30 @@ MPX_EXPORT int mpx_sa_mlp_factored(const float *pre, const float *ctr, const int
   if (B == 0 || npoint == 0) return 0;
   const int64_t nq = (int64_t)B * npoint;
   MPX_REQUIRE(nq / 4 + 1 < ((int64_t)1 << 31), "mpx_sa_mlp_factored: too many query points");
+  int rc = 0;
   auto go = [&](auto qtag) {  // queries per wave: 8, or 2 / 1 for small batches (see launch_sa)
     constexpr int Q = decltype(qtag)::value;
-    const int64_t nw = (nq + Q - 1) / Q;
+    int64_t nw = (nq + Q - 1) / Q;
     const int bpe = (npoint % Q == 0 && B % 8 == 0) ? npoint / Q : 0;
+    unsigned int *queue = nullptr;
+    const int64_t slots = sa_wave_slots(8);
+    if (slots > 0 && nw >= 4 * slots) {  // (see launch_sa)
+      queue = mpx_unit_queue_for(mpx_s(stream));
+      if (!queue) {
+        mpx_set_error("mpx_sa_mlp_factored: cannot reset the unit queue");
+        rc = 1;
+        return;
+      }
+      nw = slots;
+    }
     hipLaunchKernelGGL((sa_mlp_packed_kernel<64, 128, 128, 256, Q, true>), dim3((unsigned)nw), dim3(64), 0,
                        mpx_s(stream), nullptr, 0, nullptr, 0, nullptr, 0, idx, cnt, nq, N, npoint, nsample, wpack, out,
-                       out_stride, bpe, pre, ctr, 0);
+                       out_stride, bpe, pre, ctr, 0, queue);
   };
   if (nq >= 1024 * 8) go(std::integral_constant<int, 8>{});
   else if (nq >= 1024) go(std::integral_constant<int, 2>{});
   else go(std::integral_constant<int, 1>{});  // a handful of problems: one query (1-2 tiles) per wave
+  if (rc) return rc;
   MPX_LAUNCH_CHECK("mpx_sa_mlp_factored");
 }
 

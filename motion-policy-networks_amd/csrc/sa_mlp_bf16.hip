@@ -834,7 +834,7 @@ static_assert(Cfg::ST2 == 32 && Cfg::ST3 == 64 && Cfg::KS1 == 8 && Cfg::KS2 == 8
 // 256 distinct streams per process use distinct slots (later ones share by hash); a captured graph bakes its capture
 // stream's slot in, so two graphs captured on the SAME stream must not be replayed concurrently on different streams.
 __device__ unsigned int sa2_unit_queues[256 * 8];
-static unsigned int *unit_queue_for(hipStream_t stream) {
+unsigned int *mpx_unit_queue_for(hipStream_t stream) {
   static std::mutex mu;
   static std::unordered_map<unsigned long long, int> slot_of;  // (device << 56) ^ stream handle -> slot
   static unsigned int *base[64];
@@ -930,17 +930,27 @@ __global__ void __launch_bounds__(64 * v2::WV) __attribute__((amdgpu_waves_per_e
   const int upe = npoint / Q;  // units per environment (xcd_aware only)
   const int xcd = xcd_aware ? (blockIdx.x & 7) : 0;
   const int64_t j_end = xcd_aware ? (n_query / npoint / 8) * upe : n_units;  // units of this queue
+  int steal = 0;  // queues beyond the own one this wave has moved on to (an XCD that runs dry helps the next one out:
+                  // the sums of the row counts over an XCD's share of the environments differ by a few per cent)
   auto next_unit = [&]() __attribute__((always_inline)) {
     unsigned int v = 0;
-    if (lane == 0) v = atomicAdd(queue + xcd, 1u);
+    if (lane == 0) v = atomicAdd(queue + ((xcd + steal) & 7), 1u);
     return (int64_t)(unsigned int)__builtin_amdgcn_readfirstlane((int)v);
   };
   int64_t j_next = next_unit();
   while (true) {
-    const int64_t j = j_next;
-    if (j >= j_end) break;
+    int64_t j = j_next;
+    bool dry = false;
+    while (j >= j_end) {
+      if (!xcd_aware || ++steal == 8) {
+        dry = true;
+        break;
+      }
+      j = next_unit();
+    }
+    if (dry) break;
     j_next = next_unit();
-    const int64_t unit = xcd_aware ? ((j / upe) * 8 + xcd) * upe + j % upe : j;
+    const int64_t unit = xcd_aware ? ((j / upe) * 8 + ((xcd + steal) & 7)) * upe + j % upe : j;
     const int64_t q0 = unit * Q;
     const int nq = (int)min((int64_t)Q, n_query - q0);
     int my_cnt = 1, my_rows = 0, my_env = 0;
@@ -1248,7 +1258,7 @@ MPX_EXPORT int mpx_sa_mlp_bf16x3_factored(const float *pre, const float *ctr, co
   const int grid = cus[dev & 63];
   const int xcd_aware = (B % 8 == 0 && grid % 8 == 0 && npoint % v2::Q == 0) ? 1 : 0;
   MPX_LDS_LIMIT_ONCE(sa2_bf16x3_persistent_kernel, v2::LDS_BYTES, "mpx_sa_mlp_bf16x3_factored");
-  unsigned int *queue = unit_queue_for(mpx_s(stream));
+  unsigned int *queue = mpx_unit_queue_for(mpx_s(stream));
   MPX_REQUIRE(queue != nullptr, "mpx_sa_mlp_bf16x3_factored: cannot reset the unit queue");
   hipLaunchKernelGGL(sa2_bf16x3_persistent_kernel, dim3(grid), dim3(64 * v2::WV), v2::LDS_BYTES, mpx_s(stream), idx, cnt, nq, N,
                      npoint, nsample, static_cast<const unsigned char *>(wpack), out, out_stride, pre, ctr, xcd_aware, queue);

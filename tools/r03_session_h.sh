@@ -1,0 +1,19 @@
+#!/bin/bash
+# A/B builds: SA2 weight ring geometry (groups per chunk x chunks in flight)
+mkdir -p gpurun_out/r03h
+export PYTHONUNBUFFERED=1
+REPO=$(pwd); O=$REPO/gpurun_out/r03h
+run() {
+  MPX_LIB_PATH=$2 timeout 300 python bench.py --steps 5 --warmup 1 --cpu-envs 0 --extra 0 --fast-steps 0 --pipeline-steps 0 --all-slots-steps 0 > $O/bench_$1.log 2>&1
+  python - "$1" "$O/bench_$1.log" <<'PY'
+import json, sys
+l = [x for x in open(sys.argv[2]) if x.startswith("{")]
+if not l:
+    print(sys.argv[1], "NO LINE"); sys.exit(0)
+d = json.loads(l[-1]); k = d["kernels_ms"]
+print("%-8s step %.2f ms  sa1 %.3f  sa2 %.3f  fps %.3f  bq %.3f  chain %.3f" % (sys.argv[1], d["ms_per_step"], k["sa1_mlp"], k["sa2_mlp"], k["fps"], k["ball_query"], k["sa3_chain"]))
+PY
+}
+run base ""
+for v in "$@"; do run $v $REPO/build_ab/libmpinets_hip_$v.so; done
+run base2 ""
