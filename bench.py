@@ -526,11 +526,11 @@ def main():
         # the FLOPs of the 32-row MFMA tiles actually issued (counts of the last timed step), not the nominal
         # 128 slots per neighbourhood.
 
-        def tiles(c, q):  # fp32 kernel: q consecutive queries per wave, rows packed at 4-row granularity
-            rows4 = (c.clamp(1, 128) + 3) // 4 * 4
-            return int(((rows4.reshape(-1, q).sum(1) + 31) // 32).sum().item())
+        def tiles(c, q, gr):  # fp32 kernel: q consecutive queries per wave, rows packed at gr-row granularity (csrc/sa_mlp.hip: GR)
+            rows = (c.clamp(1, 128) + gr - 1) // gr * gr
+            return int(((rows.reshape(-1, q).sum(1) + 31) // 32).sum().item())
 
-        t1, t2 = tiles(cnt1, 16), tiles(cnt2, 8)
+        t1, t2 = tiles(cnt1, 16, 2), tiles(cnt2, 8, 4)
         sa1_exec, sa2_exec = t1 * 32 * 8448 * 2, t2 * 32 * SA2_ROW_MACS * 2
         achieved = sa2_exec / (sa2_ms * 1e-3) / 1e12
         total_envsteps = B * n_gpus * args.steps

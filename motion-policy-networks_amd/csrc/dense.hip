@@ -329,6 +329,85 @@ static void gemv_launch(const float *x, int ldx, const float *w, const float *bi
 #undef GEMV_GO
 }
 
+// ---- a row per lane: y[M, 128] = x[M, K] . w[128, K]^T for a SHORT K (the second module's per-point first layer: 4.2 M
+// rows of [f | xyz | 0], K = 68) ------------------------------------------------------------------------------------
+// The tiled kernel above spends that launch on its prologue / epilogue: 5 slabs of K per 128 x 128 tile, a 64 KB tile
+// written per 35 KB read -- 1.15 ms for 3.3 GB of traffic.  Here the layer is evaluated the way the fused grouped-MLP
+// kernels evaluate theirs (H^T = W . X^T, sa_mlp.hip): a lane owns ONE row, reads its half of it (K / 2 consecutive floats:
+// lanes 0-31 the first half of rows 0-31, lanes 32-63 the second) straight into the registers that are the B operands of the
+// k-steps, W sits in registers for the whole kernel (K / 2 x 4 values per lane), nothing goes through LDS and there is no
+// barrier.  One wave per SIMD, a static stride of 32-row tiles per wave, the next tile's rows requested before the current
+// tile's 2 K matrix instructions.  The k-order of a row's sum is (k, k + K / 2) pairs in ascending k -- a different rounding
+// order than the tiled kernel's, the same for every M.
+template <int KH>
+#ifndef MPX_ROWLANE_WAVES
+#define MPX_ROWLANE_WAVES 1  // (two waves per SIMD: 1.11 ms instead of 0.71 -- the register budget halves and the row buffers spill)
+#endif
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MPX_ROWLANE_WAVES, MPX_ROWLANE_WAVES)))
+    linear_rowlane_kernel(const float *__restrict__ x, int ldx, const float *__restrict__ w, int64_t M, float *__restrict__ y,
+                          int ldy) {
+  constexpr int K = 2 * KH, NT = 4;  // 4 output tiles of 32 channels
+  static_assert(KH % 2 == 0, "a lane reads its half row as 8-byte pieces");
+  const int lane = threadIdx.x, half = lane >> 5, col = lane & 31;
+  const int64_t tiles = (M + 31) / 32;
+  // W: A operand of k-step s, output tile ot = w[32 ot + col][KH half + s]
+  float wr[KH][NT];
+#pragma unroll
+  for (int ot = 0; ot < NT; ++ot) {
+    const float2 *src = reinterpret_cast<const float2 *>(w + (size_t)(32 * ot + col) * K + KH * half);
+#pragma unroll
+    for (int s = 0; s < KH / 2; ++s) {
+      const float2 v = src[s];
+      wr[2 * s][ot] = v.x;
+      wr[2 * s + 1][ot] = v.y;
+    }
+  }
+  float cur[KH], nxt[KH];
+  auto load_rows = [&](int64_t t, float (&dst)[KH]) __attribute__((always_inline)) {
+    int64_t row = t * 32 + col;
+    row = row < M ? row : M - 1;  // (rows past the end: a valid row's data, never stored)
+    const float2 *src = reinterpret_cast<const float2 *>(x + row * ldx + KH * half);
+#pragma unroll
+    for (int s = 0; s < KH / 2; ++s) {
+      const float2 v = src[s];
+      dst[2 * s] = v.x;
+      dst[2 * s + 1] = v.y;
+    }
+  };
+  int64_t t = blockIdx.x;
+  if (t < tiles) load_rows(t, cur);
+  for (; t < tiles; t += gridDim.x) {
+    const int64_t tn = t + gridDim.x;
+    if (tn < tiles) load_rows(tn, nxt);
+    f32x16 acc[NT];
+#pragma unroll
+    for (int ot = 0; ot < NT; ++ot) acc[ot] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int s = 0; s < KH; ++s)
+#pragma unroll
+      for (int ot = 0; ot < NT; ++ot) acc[ot] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[s][ot], cur[s], acc[ot], 0, 0, 0);
+    // register r of tile ot = channel 32 ot + 8 (r >> 2) + 4 half + (r & 3) of row `col`: four 16-byte pieces per tile
+    const int64_t row = t * 32 + col;
+    if (row < M) {
+      float *dst = y + row * ldy + 4 * half;
+#pragma unroll
+      for (int ot = 0; ot < NT; ++ot)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<float4 *>(dst + 32 * ot + 8 * g) =
+              make_float4(acc[ot][4 * g], acc[ot][4 * g + 1], acc[ot][4 * g + 2], acc[ot][4 * g + 3]);
+    }
+    if (tn < tiles) {
+#pragma unroll
+      for (int s = 0; s < KH; ++s) cur[s] = nxt[s];
+    }
+  }
+}
+static bool rowlane_ok(const float *x, int ldx, const float *w, const float *bias, int N, int K, int act, const float *y, int ldy) {
+  return N == 128 && K == 68 && bias == nullptr && act == MPX_ACT_NONE && ldx % 2 == 0 && ldy % 4 == 0 &&
+         (((uintptr_t)x | (uintptr_t)w) & 7) == 0 && ((uintptr_t)y & 15) == 0;
+}
+
 MPX_EXPORT int mpx_linear(const float *x, int ldx, const float *w, const float *bias, int M, int N, int K,
                           int act, float *y, int ldy, mpx_stream_t stream) {
   MPX_REQUIRE(M >= 0 && N >= 1 && K >= 1, "mpx_linear: bad size");
@@ -339,6 +418,15 @@ MPX_EXPORT int mpx_linear(const float *x, int ldx, const float *w, const float *
   if (M == 0) return 0;
   if (gemv_fits(M, K)) {
     gemv_launch(x, ldx, w, bias, M, N, K, act, y, ldy, stream);
+    MPX_LAUNCH_CHECK("mpx_linear");
+  }
+  if (rowlane_ok(x, ldx, w, bias, N, K, act, y, ldy)) {  // short K, 128 outputs: a row per lane, W in registers (every M: one rounding order)
+    int cus = 0, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+      cus = 256;
+    const int64_t tiles = ((int64_t)M + 31) / 32, waves = (int64_t)cus * 4 * MPX_ROWLANE_WAVES;
+    hipLaunchKernelGGL((linear_rowlane_kernel<34>), dim3((unsigned)(tiles < waves ? tiles : waves)), dim3(64), 0, mpx_s(stream), x,
+                       ldx, w, (int64_t)M, y, ldy);
     MPX_LAUNCH_CHECK("mpx_linear");
   }
   if (const int64_t slab = mpx_row_slab(BM, (int64_t)ldx * 4); M > slab) {  // more rows than one launch covers

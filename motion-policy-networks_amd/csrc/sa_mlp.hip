@@ -31,6 +31,9 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define PAD_CH (-1)
+#ifndef MPX_SA1_GR
+#define MPX_SA1_GR 2
+#endif
 #ifndef MPX_SA_SPREAD
 #define MPX_SA_SPREAD 1
 #endif
@@ -281,13 +284,14 @@ __global__ void __launch_bounds__(256, 2)
 // ---- packed variant: only distinct neighbours are evaluated ---------------------------------------------
 // Slots [cnt, nsample) of a neighbourhood repeat its first member (ball-query padding).  The MLP is per
 // point and max-pooling is idempotent, so evaluating each distinct neighbour once gives a bit-identical
-// result.  A wave takes Q consecutive queries, rounds each neighbourhood up to a multiple of 4 rows
-// (repeating the first neighbour) and packs them back to back into 32-row MFMA tiles.  After the last
-// layer a lane holds, per output channel, four groups of 4 consecutive rows; every group belongs to one
-// query, so pooling is a max over each group followed by a merge of the groups in row order that flushes
-// the running maximum to the output row whenever the (wave-uniform) query changes.
+// result.  A wave takes Q consecutive queries, rounds each neighbourhood up to a multiple of GR rows (4 for the
+// wide module, 2 for the narrow one; repeating the first neighbour) and packs them back to back into 32-row MFMA
+// tiles.  After the last layer a lane holds, per output channel, 16 / GR groups of GR consecutive rows; every group
+// belongs to one query, so pooling is a max over each group followed by a merge of the groups in row order that
+// flushes the running maximum to the output row whenever the (wave-uniform) query changes.
 // One wave per workgroup: waves carry different numbers of tiles, and a multi-wave workgroup would hold
-// its SIMD slots until its slowest wave retires.
+// its SIMD slots until its slowest wave retires.  Large launches are persistent (one workgroup per wave slot of the
+// chip, units from a device-side queue -- below).
 //
 // FACT (factored first layer): W1.[p_j - c_i ; f_j] + b1 = (W1.[p_j ; f_j]) - (W1x.c_i - b1) is linear, so the
 // caller evaluates the first term once per POINT (`pre` [B*N, C1], a plain GEMM over the points) and the second
@@ -303,6 +307,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CF == 1
                          int out_stride, int bpe, const float *__restrict__ pre_rows, const float *__restrict__ ctr,
                          int append_centre, unsigned int *__restrict__ queue) {
   using Cfg = SaCfg<CF, C1, C2, C3>;
+  // rows of a neighbourhood are rounded up to GR (repeating its first member): 4 for the wide module (62 rows per query on
+  // the bench scenes: 2 % of padding, eight pooling groups per tile), 2 for the narrow one (15 rows per query: the padding
+  // was 9 % of its matrix work; sixteen pooling groups per tile instead of eight cost less than that)
+  constexpr int GR = CF == 1 ? MPX_SA1_GR : 4, NGRP = 32 / GR;
+  static_assert(GR == 2 || GR == 4, "pooling groups of 2 or 4 rows");
   __shared__ float ctr_s[FACT ? Q * C1 : 1];
   // biases in LDS: they initialise the accumulators at every tile and are added at every flush -- as global loads
   // their latency sits on the critical path of each tile
@@ -346,7 +355,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CF == 1
   auto fetch = [&](int c, int base) __attribute__((always_inline)) {
 #pragma unroll
     for (int u = 0; u < CH; ++u)
-      if (c * CH + u < GT) ring[c & 1][u] = bload16(wrsrc, wvoff, base + (c * CH + u) * 1024);
+      if (c * CH + u < GT) ring[c & 1][u] = bload16(wrsrc, wvoff + u * 1024, base + c * CH * 1024);  // (one scalar offset per chunk: the group's 1 KB step rides in the instruction's immediate)
   };
   {
     int wb = (int)(FACT ? Cfg::W2_OFF : Cfg::W1_OFF) * 4;
@@ -389,12 +398,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CF == 1
     __syncthreads();
   }
 
-  // lane i < nq: distinct-neighbour count of query q0+i, its row count (multiple of 4) and row offset
+  // lane i < nq: distinct-neighbour count of query q0+i, its row count (multiple of GR) and row offset
   int my_cnt = 0, my_rows = 0;
   if (lane < nq) {
     const int c = cnt[q0 + lane];
     my_cnt = c <= 0 ? 1 : (c > nsample ? nsample : c);  // no hit: the zero-initialised row = point 0
-    my_rows = (my_cnt + 3) & ~3;
+    my_rows = (my_cnt + GR - 1) & ~(GR - 1);
   }
   int pre = my_rows;  // inclusive prefix sum over lanes 0..Q-1
 #pragma unroll
@@ -561,17 +570,17 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CF == 1
       }
     }
     const int q_tile = q_cur;  // which query this lane's row of the current tile belongs to
-    // ... per 4-row group, wave-uniform (non-decreasing).  Read once per tile when 8 output tiles share them; the
+    // ... per GR-row group, wave-uniform (non-decreasing).  Read once per tile when 8 output tiles share them; the
     // narrow module (2 output tiles, 16 queries' offsets already in SGPRs) reads them where they are used.
     constexpr bool HOIST = Cfg::OT3 > 2;
     int gq_s[HOIST ? 8 : 1];
     if constexpr (HOIST) {
 #pragma unroll
-      for (int grp = 0; grp < 8; ++grp) gq_s[grp] = __builtin_amdgcn_readlane(q_tile, 4 * grp);
+      for (int grp = 0; grp < 8; ++grp) gq_s[grp] = __builtin_amdgcn_readlane(q_tile, 4 * grp);  // (HOIST: GR == 4)
     }
     auto gq = [&](int grp) __attribute__((always_inline)) {
       if constexpr (HOIST) return gq_s[grp];
-      else return __builtin_amdgcn_readlane(q_tile, 4 * grp);
+      else return __builtin_amdgcn_readlane(q_tile, GR * grp);
     };
     const int cur0 = cur;
     const int q_gather = q_next, k_gather = k_next;
@@ -652,23 +661,36 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CF == 1
           a3 = mfma32(a2[t >> 4][t & 15], comp(w, u), a3);
         }
         if (gg == GPT - 1) {
-          float gm[4];
+          // this lane's group maxima: register 4 j + i holds row 8 j + 4 half + i, so group g (rows GR g ...) lives in the
+          // lanes of half (GR g >> 2) & 1 as gm[2 j + (i >> 1)] (GR == 2) or gm[j] (GR == 4)
+          float gm[16 / GR];
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
-            gm[j] = fmaxf(fmaxf(a3[4 * j], a3[4 * j + 1]), fmaxf(a3[4 * j + 2], a3[4 * j + 3]));
-          if (gq(7) == cur0) {  // the whole tile belongs to the query being merged (the common case): no flush
-            run[ot] = fmaxf(run[ot], fmaxf(fmaxf(gm[0], gm[1]), fmaxf(gm[2], gm[3])));
+          for (int j = 0; j < 4; ++j) {
+            if constexpr (GR == 4) {
+              gm[j] = fmaxf(fmaxf(a3[4 * j], a3[4 * j + 1]), fmaxf(a3[4 * j + 2], a3[4 * j + 3]));
+            } else {
+              gm[2 * j] = fmaxf(a3[4 * j], a3[4 * j + 1]);
+              gm[2 * j + 1] = fmaxf(a3[4 * j + 2], a3[4 * j + 3]);
+            }
+          }
+          if (gq(NGRP - 1) == cur0) {  // the whole tile belongs to the query being merged (the wide module's common case): no flush
+            float m = gm[0];
+#pragma unroll
+            for (int j = 1; j < 16 / GR; ++j) m = fmaxf(m, gm[j]);
+            run[ot] = fmaxf(run[ot], m);
           } else {
             int c = cur0;
 #pragma unroll
-            for (int grp = 0; grp < 8; ++grp) {
+            for (int grp = 0; grp < NGRP; ++grp) {
               const int g_q = gq(grp);
               if (g_q != c) {
                 flush(ot, c);
                 c = g_q;
               }
               // (a select, not a branch)
-              run[ot] = fmaxf(run[ot], ((grp & 1) == half) ? gm[grp >> 1] : -__builtin_inff());
+              const int row0 = GR * grp;  // first row of the group: rows 8 j + 4 h + i
+              const float mine = GR == 4 ? gm[row0 >> 3] : gm[2 * (row0 >> 3) + ((row0 & 3) >> 1)];
+              run[ot] = fmaxf(run[ot], (((row0 >> 2) & 1) == half) ? mine : -__builtin_inff());
             }
           }
         }
@@ -702,7 +724,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CF == 1
         }
       }
     }
-    cur = gq(7);
+    cur = gq(NGRP - 1);
   }
 #pragma unroll
   for (int ot = 0; ot < Cfg::OT3; ++ot) flush(ot, cur);
