@@ -324,7 +324,10 @@ int mpx_group_points(const float *xyz, int stride, const float *new_xyz, int new
  * cnt (optional, from mpx_ball_query): only the DISTINCT neighbours are evaluated -- slots
  * [cnt, nsample) repeat the first neighbour, the MLP is per point and max-pooling is idempotent,
  * so the output is bit-identical to walking all nsample slots (cnt == NULL).  Several queries
- * share a wave and their rows are packed at 4-row granularity into the 32-row MFMA tiles.
+ * share a wave and their rows are packed (rounded up to 2 rows per query for the narrow module, 4 for the
+ * wide one) into the 32-row MFMA tiles.  Large launches with cnt are PERSISTENT: one workgroup per wave slot
+ * of the chip takes units of consecutive queries from the device-side queue described at
+ * mpx_sa_mlp_bf16x3_factored_wants_order below (same per-(device, stream) counters, same hipGraph note).
  * append_centre != 0 (needs cnt, out_stride >= c3 + 4): columns [c3, c3+3) of every output row also receive the
  * query point's coordinates and column c3+3 a zero -- the rows are then the operand [f | xyz | 0] of the next
  * module's per-point first-layer GEMM (mpx_sa_mlp_factored), model.py:404-407's torch.cat without a second pass. */
@@ -338,7 +341,7 @@ int mpx_sa_mlp(const float *xyz, int stride, const float *new_xyz, int new_strid
  * both plain mpx_linear calls by the caller.  The kernel gathers pre rows, subtracts the query row,
  * applies ReLU and continues with layers 2-3 and the max-pool as above (wpack unchanged; its layer-1
  * block is not read).  15 % less matrix work for the (64,128,128,256) module; equal to mpx_sa_mlp
- * up to the rounding of that one re-associated sum.  cnt is required.                              */
+ * up to the rounding of that one re-associated sum.  cnt is required.  (Persistent for large launches, as above.) */
 int mpx_sa_mlp_factored(const float *pre, const float *ctr, const int32_t *idx, const int32_t *cnt, int B,
                         int N, int npoint, int nsample, const float *wpack, int C, int c1, int c2, int c3,
                         float *out, int out_stride, mpx_stream_t stream);

@@ -31,6 +31,7 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define PAD_CH (-1)
+constexpr int SA_MAX_NSAMPLE = 256;  // slots per neighbourhood the packed kernels index their row map for
 #ifndef MPX_SA1_GR
 #define MPX_SA1_GR 2
 #endif
@@ -313,6 +314,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CF == 1
   constexpr int GR = CF == 1 ? MPX_SA1_GR : 4, NGRP = 32 / GR;
   static_assert(GR == 2 || GR == 4, "pooling groups of 2 or 4 rows");
   __shared__ float ctr_s[FACT ? Q * C1 : 1];
+  __shared__ unsigned char qmap_s[Q * SA_MAX_NSAMPLE / GR + 32];  // (row group -> query; rows per query <= nsample <= 256)
   // biases in LDS: they initialise the accumulators at every tile and are added at every flush -- as global loads
   // their latency sits on the critical path of each tile
   __shared__ __attribute__((aligned(16))) float b1_s[C1], b2_s[C2], b3_s[C3];
@@ -415,12 +417,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CF == 1
   // environment of this wave's query `lane` (the 64-bit division happens once, here, not per tile)
   const int my_env = (int)((q0 + (lane < Q ? lane : 0)) / npoint);
   pre -= my_rows;  // exclusive
-  int s_pre[Q], s_cnt[Q];
-#pragma unroll
-  for (int i = 0; i < Q; ++i) {
-    s_pre[i] = __builtin_amdgcn_readlane(pre, i);
-    s_cnt[i] = __builtin_amdgcn_readlane(my_cnt, i);
+  // row group -> query of this wave: one byte per GR rows, written by the queries' own lanes; the groups behind the last
+  // row (the tail of the last tile) belong to the last query.  (A row's query used to be found by a compare / select
+  // chain over the Q row offsets: ~105 VALU instructions per tile for 16 queries, each costing matrix-pipe time.)
+  if (lane < nq) {
+    const int g1 = (pre + my_rows) / GR;
+    for (int g = pre / GR; g < g1; ++g) qmap_s[g] = (unsigned char)lane;
   }
+  if (lane < 32 / GR) qmap_s[total / GR + lane] = (unsigned char)(nq - 1);
 
   __syncthreads();  // (biases / query terms visible; a one-wave workgroup: no more than the LDS wait)
   // register r of a tile holds channel ot*32 + (r&3) + 8*(r>>2) + 4*half
@@ -461,15 +465,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CF == 1
   };
   // row -> (query of this wave, neighbour slot); rows past the end repeat the last query's first slot
   auto map_row = [&](int p, int &qi, int &off) __attribute__((always_inline)) {
-    int qpre = 0, qcnt = s_cnt[0];
-    qi = 0;
-#pragma unroll
-    for (int i = 1; i < Q; ++i) {
-      const bool ge = i < nq && p >= s_pre[i];
-      qi = ge ? i : qi;
-      qpre = ge ? s_pre[i] : qpre;
-      qcnt = ge ? s_cnt[i] : qcnt;
-    }
+    qi = qmap_s[p / GR];
+    const int qpre = __builtin_amdgcn_ds_bpermute(4 * qi, pre), qcnt = __builtin_amdgcn_ds_bpermute(4 * qi, my_cnt);
     const int slot = p - qpre;
     off = slot < qcnt ? slot : 0;
   };
@@ -753,7 +750,8 @@ static int launch_sa(const float *xyz, int stride, const float *new_xyz, int new
   MPX_REQUIRE(nq / 4 + 1 < ((int64_t)1 << 31), "mpx_sa_mlp: too many query points");
   MPX_REQUIRE(!append_centre || (cnt && out_stride >= C3 + 4),
               "mpx_sa_mlp: append_centre needs the hit counts and out_stride >= c3 + 4");
-  if (cnt) {
+  MPX_REQUIRE(!append_centre || nsample <= SA_MAX_NSAMPLE, "mpx_sa_mlp: append_centre needs nsample <= %d", SA_MAX_NSAMPLE);
+  if (cnt && nsample <= SA_MAX_NSAMPLE) {  // (more slots than the row map holds: every slot is walked -- the same result)
     // queries per wave: 6-9 tiles of work on typical scenes.  A small batch (a single planning problem up to a few
     // dozen) would leave most CUs idle at that size, so it runs QS queries per wave instead: same rows, same
     // arithmetic per row (bit-identical results), 4x the waves and a quarter of the latency.
@@ -820,7 +818,8 @@ MPX_EXPORT int mpx_sa_mlp_factored(const float *pre, const float *ctr, const int
                                    float *out, int out_stride, mpx_stream_t stream) {
   MPX_REQUIRE(C == 64 && c1 == 128 && c2 == 128 && c3 == 256,
               "mpx_sa_mlp_factored: built for the (64+3, 128, 128, 256) module (C=%d, %d, %d, %d)", C, c1, c2, c3);
-  MPX_REQUIRE(B >= 0 && N >= 1 && npoint >= 0 && nsample > 0, "mpx_sa_mlp_factored: bad size");
+  MPX_REQUIRE(B >= 0 && N >= 1 && npoint >= 0 && nsample > 0 && nsample <= SA_MAX_NSAMPLE,
+              "mpx_sa_mlp_factored: bad size (nsample 1..%d)", SA_MAX_NSAMPLE);
   MPX_REQUIRE(pre && ctr && idx && cnt, "mpx_sa_mlp_factored: NULL operand (hit counts are required)");
   MPX_REQUIRE(out_stride >= c3, "mpx_sa_mlp_factored: bad stride");
   MPX_REQUIRE((((uintptr_t)wpack | (uintptr_t)pre | (uintptr_t)ctr) & 15) == 0,

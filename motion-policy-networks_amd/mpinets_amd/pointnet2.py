@@ -261,7 +261,8 @@ def sa_mlp_factored(point_rows: torch.Tensor, centre_rows: torch.Tensor, idx: to
     wp, wc, nb1 = packed.factored(convs, C)
     c1, c2, c3 = (c.out_channels for c in convs)
     if precision == "bf16x3":
-        pre = linear_x3(point_rows, wp, None, 0, split, source=convs[0].weight)
+        # (K = 68: HBM-bound either way -- the fp32 row-per-lane kernel is the faster one, 0.71 vs 0.79 ms, and exact)
+        pre = linear(point_rows, wp, None)
         ctr = linear(centre_rows, wc, nb1)  # K = 4: not worth the matrix cores
         # (the factored kernel is persistent and takes its units from a device-side queue: no sorting pass, order = NULL)
         _lib.call("mpx_sa_mlp_bf16x3_factored", _lib.ptr(pre), _lib.ptr(ctr), _lib.ptr(idx), _lib.ptr(cnt), None,

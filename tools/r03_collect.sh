@@ -4,7 +4,7 @@ set -e
 S=gpurun_out/r03ev; P=profiles
 tail -1 $S/bench.log > $P/r03_bench_n1.json
 cp $S/stats_head_kernel_stats.csv $P/r03_bench_kernel_stats.csv
-for i in 1 2 3 4; do cp $S/pmc_head$i.csv $P/r03_pmc_pass${i}_envs8192.csv; done
+for i in 1 2 3 4 5; do cp $S/pmc_head$i.csv $P/r03_pmc_pass${i}_envs8192.csv; done
 T=$(mktemp -d); for i in 1 2 3; do cp $S/pmc_head$i.csv $T/pass${i}_summary.csv; done
 python tools/pmc_traffic.py $T 8192 $P/r03_traffic.json > /dev/null
 for i in 1 2 3 4 5; do cp $S/pmc_fast$i.csv $P/r03_fast_pmc_pass$i.csv; done

@@ -29,6 +29,7 @@ pmc head1 "FETCH_SIZE" bench.py $PARGS
 pmc head2 "WRITE_SIZE" bench.py $PARGS
 pmc head3 "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE" bench.py $PARGS
 pmc head4 "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY" bench.py $PARGS
+pmc head5 "SQ_INSTS_VALU SQ_INSTS_VMEM SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_ANY SQ_WAIT_ANY" bench.py $PARGS
 pmc fast1 "FETCH_SIZE" tools/fast_timing.py 8192 2 noref
 pmc fast2 "WRITE_SIZE" tools/fast_timing.py 8192 2 noref
 pmc fast3 "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE" tools/fast_timing.py 8192 2 noref
