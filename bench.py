@@ -530,7 +530,7 @@ def main():
             rows = (c.clamp(1, 128) + gr - 1) // gr * gr
             return int(((rows.reshape(-1, q).sum(1) + 31) // 32).sum().item())
 
-        t1, t2 = tiles(cnt1, 16, 2), tiles(cnt2, 8, 4)
+        t1, t2 = tiles(cnt1, 32, 2), tiles(cnt2, 8, 4)  # (csrc/sa_mlp.hip: MPX_SA1_Q, MPX_SA2_Q)
         sa1_exec, sa2_exec = t1 * 32 * 8448 * 2, t2 * 32 * SA2_ROW_MACS * 2
         achieved = sa2_exec / (sa2_ms * 1e-3) / 1e12
         total_envsteps = B * n_gpus * args.steps

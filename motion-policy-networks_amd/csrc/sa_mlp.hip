@@ -32,6 +32,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define PAD_CH (-1)
 constexpr int SA_MAX_NSAMPLE = 256;  // slots per neighbourhood the packed kernels index their row map for
+// queries per unit of the large launches (A/B builds: narrow module 16 / 32: 10.38 / 10.14 ms -- the tail of a unit's last
+// tile is 2.7 instead of 5.5 % of its rows; wide module 8 / 16: 46.6 / 46.8 ms -- its units are already 16 tiles)
+#ifndef MPX_SA1_Q
+#define MPX_SA1_Q 32
+#endif
+#ifndef MPX_SA2_Q
+#define MPX_SA2_Q 8
+#endif
 #ifndef MPX_SA1_GR
 #define MPX_SA1_GR 2
 #endif
@@ -752,10 +760,10 @@ static int launch_sa(const float *xyz, int stride, const float *new_xyz, int new
               "mpx_sa_mlp: append_centre needs the hit counts and out_stride >= c3 + 4");
   MPX_REQUIRE(!append_centre || nsample <= SA_MAX_NSAMPLE, "mpx_sa_mlp: append_centre needs nsample <= %d", SA_MAX_NSAMPLE);
   if (cnt && nsample <= SA_MAX_NSAMPLE) {  // (more slots than the row map holds: every slot is walked -- the same result)
-    // queries per wave: 6-9 tiles of work on typical scenes.  A small batch (a single planning problem up to a few
+    // queries per wave: 8-16 tiles of work on typical scenes.  A small batch (a single planning problem up to a few
     // dozen) would leave most CUs idle at that size, so it runs QS queries per wave instead: same rows, same
     // arithmetic per row (bit-identical results), 4x the waves and a quarter of the latency.
-    constexpr int QL = CF == 1 ? 16 : 8, QS = CF == 1 ? 4 : 2;
+    constexpr int QL = CF == 1 ? MPX_SA1_Q : 8, QS = CF == 1 ? 4 : 2;
     int rc = 0;
     auto go = [&](auto qtag) {
       constexpr int Q = decltype(qtag)::value;
@@ -847,7 +855,7 @@ MPX_EXPORT int mpx_sa_mlp_factored(const float *pre, const float *ctr, const int
                        mpx_s(stream), nullptr, 0, nullptr, 0, nullptr, 0, idx, cnt, nq, N, npoint, nsample, wpack, out,
                        out_stride, bpe, pre, ctr, 0, queue);
   };
-  if (nq >= 1024 * 8) go(std::integral_constant<int, 8>{});
+  if (nq >= 1024 * MPX_SA2_Q) go(std::integral_constant<int, MPX_SA2_Q>{});
   else if (nq >= 1024) go(std::integral_constant<int, 2>{});
   else go(std::integral_constant<int, 1>{});  // a handful of problems: one query (1-2 tiles) per wave
   if (rc) return rc;
