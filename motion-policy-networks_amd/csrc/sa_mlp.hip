@@ -453,9 +453,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CF == 1
   if constexpr (!FACT) {
     // columns [C3, C3+4) of this wave's output rows <- [centre xyz | 0]: the rows become the operand [f | xyz | 0] of
     // the next module's per-point first-layer GEMM (mpx_sa_mlp_factored) without a separate pass over them
-    if (append_centre && lane < 4 * nq) {
-      const int qi = lane >> 2, c = lane & 3;
-      out[(int64_t)(qbase + qi) * out_stride + C3 + c] = c < 3 ? new_xyz[(int64_t)(qbase + qi) * new_stride + c] : 0.0f;
+    if (append_centre) {
+#pragma unroll
+      for (int e = lane; e < 4 * Q; e += 64) {  // (16 queries per pass of the wave)
+        const int qi = e >> 2, c = e & 3;
+        if (qi < nq)
+          out[(int64_t)(qbase + qi) * out_stride + C3 + c] = c < 3 ? new_xyz[(int64_t)(qbase + qi) * new_stride + c] : 0.0f;
+      }
     }
   }
   float run[Cfg::OT3];  // running max of the query being merged, per output tile (this lane's half of the rows)
