@@ -530,7 +530,10 @@ def main():
             rows = (c.clamp(1, 128) + gr - 1) // gr * gr
             return int(((rows.reshape(-1, q).sum(1) + 31) // 32).sum().item())
 
-        t1, t2 = tiles(cnt1, 32, 2), tiles(cnt2, 8, 4)  # (csrc/sa_mlp.hip: MPX_SA1_Q, MPX_SA2_Q)
+        # queries per unit as the launchers choose them (csrc/sa_mlp.hip: launch_sa / mpx_sa_mlp_factored)
+        q1 = 32 if cnt1.numel() >= 1024 * 32 else 4
+        q2 = 8 if cnt2.numel() >= 1024 * 8 else (2 if cnt2.numel() >= 1024 else 1)
+        t1, t2 = tiles(cnt1, q1, 2), tiles(cnt2, q2, 4)
         sa1_exec, sa2_exec = t1 * 32 * 8448 * 2, t2 * 32 * SA2_ROW_MACS * 2
         achieved = sa2_exec / (sa2_ms * 1e-3) / 1e12
         total_envsteps = B * n_gpus * args.steps
