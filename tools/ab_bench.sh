@@ -1,8 +1,9 @@
 #!/bin/bash
-# A/B builds: SA2 weight ring geometry (groups per chunk x chunks in flight)
-mkdir -p gpurun_out/r03h
+# Headline step with the default library and with each A/B build named on the command line (tools/ab_build.sh <name> ...):
+# usage (on the GPU box): bash tools/ab_bench.sh <name> [<name> ...]   -> one line per build: step and per-kernel ms
+mkdir -p gpurun_out/ab
 export PYTHONUNBUFFERED=1
-REPO=$(pwd); O=$REPO/gpurun_out/r03h
+REPO=$(pwd); O=$REPO/gpurun_out/ab
 run() {
   MPX_LIB_PATH=$2 timeout 300 python bench.py --steps 5 --warmup 1 --cpu-envs 0 --extra 0 --fast-steps 0 --pipeline-steps 0 --all-slots-steps 0 > $O/bench_$1.log 2>&1
   python - "$1" "$O/bench_$1.log" <<'PY'
