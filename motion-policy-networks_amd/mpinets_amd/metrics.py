@@ -17,9 +17,13 @@ under the reference's names:
 ``correct_final_region``           ``check_final_region`` (metrics.py:363-384) with SDF volumes
 ``success``                        position < 1 cm, orientation < 15 deg, region ok, no violation
                                    (metrics.py:514-519)
+``config_smoothness``              ``calculate_smoothness`` (metrics.py:387-409): SPARC of the joint-space and of the
+``eff_smoothness``                 end-effector speed profile (``smoothness.py``: one batched FFT per FFT length;
+                                   pinned to the reference's own ``third_party/sparc.py``), when ``dt`` is given
 =================================  ==============================================================
 
-SPARC smoothness (an FFT of a <= 150-sample series) stays on the host and is not part of this module.
+``BatchedEvaluator.metrics`` folds such a result into the summary of ``Evaluator.metrics`` (metrics.py:566-664) under
+the reference's keys -- those that need neither wall-clock times nor PyBullet penetration depths.
 """
 from __future__ import annotations
 
@@ -62,7 +66,7 @@ class BatchedEvaluator:
     @torch.no_grad()
     def evaluate_trajectories(self, trajectories: torch.Tensor, target_poses: torch.Tensor,
                               lengths: Optional[torch.Tensor] = None, cuboids=None, cylinders=None,
-                              target_volume=None, negative_volumes=None) -> Dict[str, torch.Tensor]:
+                              target_volume=None, negative_volumes=None, dt: Optional[float] = None) -> Dict[str, torch.Tensor]:
         """:param trajectories: [B,T,7] joint angles (rows past ``lengths[b]`` are ignored; they must still be
             valid configurations, e.g. the final one repeated, for the collision sweep)
         :param target_poses: [B,4,4] ``right_gripper`` targets
@@ -71,6 +75,8 @@ class BatchedEvaluator:
         :param negative_volumes: optional primitive set; the final position must be outside all of them -- except
             those that contain the TARGET position, which the reference drops first ("Sometimes the target is inside a
             negative volume. This is obviously a bad negative volume", metrics.py:507-512)
+        :param dt: time between waypoints; when given (and T >= 2) the result also carries ``config_smoothness`` and
+            ``eff_smoothness`` (SPARC, metrics.py:387-409, 495-497; the reference evaluates at dt = 0.12 s)
         """
         _lib.require_cuda(trajectories, target_poses)
         B, T, _ = trajectories.shape
@@ -101,8 +107,47 @@ class BatchedEvaluator:
                 region &= ~((_per_primitive_sdf(negative_volumes, final.contiguous()) <= 0) & keep).any(dim=1)
         jl, sc = jl != 0, sc != 0
         violation = collision | jl | sc
-        return {"position_error": pos, "orientation_error": ori, "eff_position_path_length": pp,
-                "eff_orientation_path_length": po, "joint_limit_violation": jl, "self_collision": sc,
-                "collision": collision, "physical_violations": violation, "correct_final_region": region,
-                "success": (pos < 1) & (ori < 15) & region & ~violation,
-                "num_steps": ln if ln is not None else torch.full((B,), T, dtype=torch.int32, device=dev)}
+        res = {"position_error": pos, "orientation_error": ori, "eff_position_path_length": pp,
+               "eff_orientation_path_length": po, "joint_limit_violation": jl, "self_collision": sc,
+               "collision": collision, "physical_violations": violation, "correct_final_region": region,
+               "success": (pos < 1) & (ori < 15) & region & ~violation,
+               "num_steps": ln if ln is not None else torch.full((B,), T, dtype=torch.int32, device=dev)}
+        if dt is not None and T >= 2:
+            res["config_smoothness"], res["eff_smoothness"] = self.smoothness(tr, ln, dt)
+        return res
+
+    @torch.no_grad()
+    def smoothness(self, trajectories: torch.Tensor, lengths: Optional[torch.Tensor], dt: float):
+        """SPARC of the joint-space and of the ``right_gripper`` speed profile of every trajectory [B,T,7]
+        (``calculate_smoothness``, metrics.py:387-409) -> (config_sparc [B], eff_sparc [B]) float64."""
+        from .robot import franka_fk
+        from .smoothness import trajectory_smoothness
+
+        B, T, _ = trajectories.shape
+        tr = _lib.f32c(trajectories)
+        eff = franka_fk(tr.reshape(B * T, 7), self.finger)[:, ft.LINK_ID["right_gripper"], 9:].reshape(B, T, 3)
+        return trajectory_smoothness(tr, eff, lengths, dt)
+
+    @staticmethod
+    def metrics(results: Dict[str, torch.Tensor]) -> Dict[str, object]:
+        """``Evaluator.metrics`` (metrics.py:566-664) over a result of ``evaluate_trajectories``: percentages and means
+        under the reference's keys.  Not reproduced: ``time`` / ``step time`` (the caller's clock), the collision depths
+        (PyBullet penetration queries) and ``skips`` (the reference's planner-failure bookkeeping)."""
+        pct = lambda t: 100.0 * float(t.double().mean().item())  # percent_true (metrics.py:50-62)
+        ok = results["success"]
+        out = {"success": pct(ok), "total": int(ok.numel()),
+               "env collision": pct(results["collision"]), "self collision": pct(results["self_collision"]),
+               "joint violation": pct(results["joint_limit_violation"]),
+               "physical violations": pct(results["physical_violations"]),
+               "1 cm": pct(results["position_error"] < 1), "5 cm": pct(results["position_error"] < 5),
+               "15 deg": pct(results["orientation_error"] < 15), "30 deg": pct(results["orientation_error"] < 30),
+               "165 deg": pct(results["orientation_error"] > 165)}
+        for key, name in (("eff_position_path_length", "eff position path length"),
+                          ("eff_orientation_path_length", "eff orientation path length")):
+            v = results[key][ok].double()  # (successful trajectories only, metrics.py:609-622; numpy's population std)
+            out[name] = (float(v.mean().item()), float(v.std(unbiased=False).item())) if v.numel() else (float("nan"), float("nan"))
+        if "config_smoothness" in results:
+            cs, es = results["config_smoothness"], results["eff_smoothness"]
+            out["is smooth"] = pct((cs < -1.6) & (es < -1.6))
+            out["average config sparc"], out["average eff sparc"] = float(cs.mean().item()), float(es.mean().item())
+        return out

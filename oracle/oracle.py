@@ -213,6 +213,51 @@ def trajectory_metrics(traj, lengths, targets, limits, finger: float = 0.025) ->
     return out
 
 
+def sparc(movement, fs: float, padlevel: int = 4, fc: float = 10.0, amp_th: float = 0.05) -> float:
+    """Spectral arc length of ONE speed profile, restating ``mpinets/third_party/sparc.py:52-128`` step by step
+    (PINNED: ``tests/golden/sparc_golden.npz`` holds that function's own results, incl. its docstring's known answer).
+
+    1. a profile that is all (numerically) zero scores 0 (sparc.py:93-95);
+    2. magnitude spectrum of the profile zero-padded to ``2^(ceil(log2 n) + padlevel)`` bins, scaled to a maximum of 1,
+       on the frequency axis ``k * fs / nfft`` (sparc.py:97-103) -- the FULL axis up to fs, so with fs < fc the mirrored
+       half of the spectrum is part of the curve, as it is for the reference at run_inference's 1 / 0.12 s;
+    3. keep the bins with f <= fc (sparc.py:111-113), then the span from the first to the last bin whose magnitude is
+       >= amp_th (sparc.py:118-121);
+    4. minus the length of the curve (f / (f_last - f_first), magnitude) over that span (sparc.py:124-128)."""
+    m = np.asarray(movement, dtype=np.float64)
+    if np.allclose(m, 0):
+        return 0.0
+    nfft = int(2 ** (np.ceil(np.log2(len(m))) + padlevel))
+    freq = np.arange(0, fs, fs / nfft)
+    mag = np.abs(np.fft.fft(m, nfft))
+    mag = mag / mag.max()
+    low = np.flatnonzero(freq <= fc)
+    freq, mag = freq[low], mag[low]
+    loud = np.flatnonzero(mag >= amp_th)
+    freq, mag = freq[loud[0]:loud[-1] + 1], mag[loud[0]:loud[-1] + 1]
+    steps_f = np.diff(freq) / (freq[-1] - freq[0]) if len(freq) > 1 else np.zeros(0)
+    return float(-np.sum(np.sqrt(steps_f ** 2 + np.diff(mag) ** 2)))
+
+
+def trajectory_smoothness(traj, lengths, dt: float, finger: float = 0.025):
+    """``Evaluator.calculate_smoothness`` (mpinets/metrics.py:387-409) for trajectories [B,T,7] with ``lengths`` valid
+    waypoints each: SPARC of the joint-space speed profile and of the ``right_gripper`` position's (FK: this oracle's,
+    parity unpinned like every FK-derived number).  -> (config_sparc [B], eff_sparc [B]) float64."""
+    x = np.asarray(traj, dtype=np.float64)
+    B, T = x.shape[:2]
+    ln = np.full(B, T, np.int64) if lengths is None else np.asarray(lengths, dtype=np.int64)
+    from mpinets_amd import franka_tables as _ft  # (link order of the FK frames: data, not engine code)
+
+    cfg, eff = np.zeros(B), np.zeros(B)
+    for b in range(B):
+        q = x[b, :ln[b]]
+        cfg[b] = sparc(np.linalg.norm(np.diff(q, 1, axis=0) / dt, axis=1), 1.0 / dt)
+        frames = franka_fk(q.astype(np.float32), finger)  # [n, links, 12] rows of [R | t]
+        pos = frames[:, _ft.LINK_ID["right_gripper"], 9:].astype(np.float64)
+        eff[b] = sparc(np.linalg.norm(np.diff(pos, 1, axis=0) / dt, axis=1), 1.0 / dt)
+    return cfg, eff
+
+
 # ---------------------------------------------------------------- depth-camera clouds (row N4)
 def depth_render(cam_poses, intr, W, H, cub, cyl, sph_centers=None, sph_radii=None, far_clip: float = 10.0):
     """cam_poses [B,4,4] world-from-camera (OpenGL axes); intr = (fx, fy, cx, cy); cub = (centers, dims, quats),

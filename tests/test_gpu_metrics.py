@@ -101,3 +101,40 @@ def test_final_region_check():
     mixed2 = TorchCuboids(cc2, torch.full((2, 2, 3), 0.2, device=dev()), ident.repeat(1, 2, 1))
     r = ev.evaluate_trajectories(q, tgt, negative_volumes=mixed2)["correct_final_region"].cpu().numpy()
     assert r.tolist() == [False, True]
+
+
+def test_smoothness_on_the_device_matches_the_oracle(oracle):
+    """config / end-effector SPARC of a ragged batch through BatchedEvaluator (one batched FFT per FFT length, on the GPU)
+    vs the oracle's per-trajectory numpy form (pinned to the reference's third_party/sparc.py, tests/test_smoothness.py).
+    Minimum-jerk reaches: no spectral bin sits at the amplitude threshold, so the fp32 FK of the two sides cannot flip one."""
+    from mpinets_amd import franka_tables as ft
+    from mpinets_amd.metrics import BatchedEvaluator
+    from mpinets_amd.robot import franka_fk, frames_to_matrix
+    from mpinets_amd.scenes import random_configurations
+
+    B, Tn, dt = 24, 150, 0.12
+    rng = np.random.default_rng(3)
+    lengths = rng.integers(2, Tn + 1, B).astype(np.int32)
+    lengths[0], lengths[1], lengths[2] = Tn, 2, 33
+    a, b = random_configurations(B, 5), random_configurations(B, 6)
+    traj = np.zeros((B, Tn, 7), np.float32)
+    for i in range(B):
+        t = np.linspace(0.0, 1.0, lengths[i])
+        s = 10 * t ** 3 - 15 * t ** 4 + 6 * t ** 5
+        traj[i, :lengths[i]] = a[i] + s[:, None] * (b[i] - a[i]) * 0.5
+        traj[i, lengths[i]:] = traj[i, lengths[i] - 1]
+    traj[5] = traj[5, 0]  # an arm that never moves: 0, like the reference
+    tt, ln = torch.from_numpy(traj).to(dev()), torch.from_numpy(lengths).to(dev())
+    targets = frames_to_matrix(franka_fk(tt[:, -1])[:, ft.LINK_ID["right_gripper"]]).contiguous()
+    ev = BatchedEvaluator(dev())
+    got = ev.evaluate_trajectories(tt, targets, ln, dt=dt)
+    cfg, eff = oracle.trajectory_smoothness(traj, lengths, dt)
+    assert got["config_smoothness"].dtype == torch.float64 and got["config_smoothness"].is_cuda
+    np.testing.assert_allclose(got["config_smoothness"].cpu().numpy(), cfg, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(got["eff_smoothness"].cpu().numpy(), eff, rtol=0, atol=1e-3)
+    assert got["config_smoothness"][5].item() == 0.0 and got["eff_smoothness"][5].item() == 0.0
+    assert (cfg[[i for i in range(B) if i != 5]] < 0).all()
+    m = BatchedEvaluator.metrics(got)
+    assert 0.0 <= m["is smooth"] <= 100.0 and m["total"] == B and "average eff sparc" in m
+    # without dt the result carries no smoothness (and the summary no smoothness lines)
+    assert "is smooth" not in BatchedEvaluator.metrics(ev.evaluate_trajectories(tt, targets, ln))
