@@ -334,7 +334,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CF == 1
   // instead of eight (bpe = workgroups per environment; falls back to the natural order for ragged grids).
   // PERSISTENT launch (queue != nullptr; one workgroup per wave slot of the chip): the units -- Q consecutive queries --
   // are handed out by a device-side queue, one counter per XCD (an environment's units stay on one XCD, in order), the
-  // next one requested when the current one starts.  Units differ 1 : 30 in rows: as one workgroup per unit the wave
+  // next one requested when the current one's last tile starts.  Units differ 1 : 30 in rows: as one workgroup per unit the wave
   // slots stood empty 13 % of the kernel (SQ_WAVE_CYCLES: 6.97 of 8 waves per CU resident), and the matrix pipes with them.
   const int64_t n_units = (n_query + Q - 1) / Q;
   const int xcd = blockIdx.x & 7;
@@ -386,7 +386,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CF == 1
       j = next_unit();
     }
     if (dry) break;
-    j_next = next_unit();
     wg = bpe > 0 ? ((j / bpe) * 8 + ((xcd + steal) & 7)) * bpe + j % bpe : j;
   } else {
     if (!first) break;
@@ -552,6 +551,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CF == 1
   }
 
   for (int rt = 0; rt < total; rt += 32) {
+    // the next unit is claimed when the LAST tile of this one starts (the counter's round trip hides behind the tile).
+    // Claimed at the start of the unit -- a whole unit ahead -- the units in flight under one L2 spanned twice as many
+    // environments (the fetch of this kernel doubled: section 5 of DESIGN.md)
+    if (queue && rt + 32 >= total) j_next = next_unit();
     int wb = (int)(FACT ? Cfg::W2_OFF : Cfg::W1_OFF) * 4;
     asm volatile("" : "+s"(wb));
 
