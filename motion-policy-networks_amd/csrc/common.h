@@ -52,7 +52,9 @@ void mpx_set_error(const char *fmt, ...);
 static inline hipStream_t mpx_s(mpx_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 // The 8 unit-queue counters (one per XCD) of `stream` on the current device, zeroed on that stream in front of the launch
 // that uses them (sa_mlp_bf16.hip; nullptr on failure).  Persistent grouped-MLP kernels take their work units from it.
-unsigned int *mpx_unit_queue_for(hipStream_t stream);
+unsigned int *mpx_unit_queue_for(hipStream_t stream, int *exhausted);
+int mpx_unit_queue_slots();
+void mpx_unit_queue_set_slots(int n);
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // ---- launch slabs ----------------------------------------------------------------------------------------------------

@@ -780,13 +780,14 @@ static int launch_sa(const float *xyz, int stride, const float *new_xyz, int new
       unsigned int *queue = nullptr;
       const int64_t slots = sa_wave_slots(CF == 1 ? 16 : 8);
       if (slots > 0 && nw >= 4 * slots) {  // many units per wave slot: one workgroup per slot, units from the device-side queue
-        queue = mpx_unit_queue_for(mpx_s(stream));
-        if (!queue) {
+        int exhausted = 0;
+        queue = mpx_unit_queue_for(mpx_s(stream), &exhausted);
+        if (!queue && !exhausted) {
           mpx_set_error("mpx_sa_mlp: cannot reset the unit queue");
           rc = 1;
           return;
         }
-        nw = slots;
+        if (queue) nw = slots;  // (no private slot left for this stream: one unit per wave, no queue)
       }
       hipLaunchKernelGGL((sa_mlp_packed_kernel<CF, C1, C2, C3, Q, false>), dim3((unsigned)nw), dim3(64), 0,
                          mpx_s(stream), xyz, stride, new_xyz, new_stride, feat, feat_stride, idx, cnt, nq, N, npoint,
@@ -850,13 +851,14 @@ MPX_EXPORT int mpx_sa_mlp_factored(const float *pre, const float *ctr, const int
     unsigned int *queue = nullptr;
     const int64_t slots = sa_wave_slots(8);
     if (slots > 0 && nw >= 4 * slots) {  // (see launch_sa)
-      queue = mpx_unit_queue_for(mpx_s(stream));
-      if (!queue) {
+      int exhausted = 0;
+      queue = mpx_unit_queue_for(mpx_s(stream), &exhausted);
+      if (!queue && !exhausted) {
         mpx_set_error("mpx_sa_mlp_factored: cannot reset the unit queue");
         rc = 1;
         return;
       }
-      nw = slots;
+      if (queue) nw = slots;  // (no private slot left for this stream: one unit per wave, no queue)
     }
     hipLaunchKernelGGL((sa_mlp_packed_kernel<64, 128, 128, 256, Q, true>), dim3((unsigned)nw), dim3(64), 0,
                        mpx_s(stream), nullptr, 0, nullptr, 0, nullptr, 0, idx, cnt, nq, N, npoint, nsample, wpack, out,

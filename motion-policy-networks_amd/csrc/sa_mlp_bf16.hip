@@ -831,13 +831,17 @@ static_assert(Cfg::ST2 == 32 && Cfg::ST3 == 64 && Cfg::KS1 == 8 && Cfg::KS2 == 8
 // kernel, memset, kernel, ...), so they can share a slot, and launches on different streams never alias -- two engines
 // that share a model on two streams (rollout.PipelinedRollout) each get their own counters.  The slot is zeroed on the
 // launch stream in front of the kernel (stream-ordered, hipGraph-capturable).  Limits, stated in include/mpinets_hip.h:
-// 256 distinct streams per process use distinct slots (later ones share by hash); a captured graph bakes its capture
-// stream's slot in, so two graphs captured on the SAME stream must not be replayed concurrently on different streams.
+// 256 distinct (device, stream) handles per process get a slot; a later handle gets NONE (`*exhausted` = 1, nullptr):
+// slots are never shared between streams -- two persistent kernels on one set of counters would each skip the units
+// the other claimed and leave output rows unwritten -- so the fp32 launchers fall back to their one-unit-per-wave
+// grids and the bf16x3 launcher reports an error.  A captured graph bakes its capture stream's slot in, so two graphs
+// captured on the SAME stream must not be replayed concurrently on different streams.
 __device__ unsigned int sa2_unit_queues[256 * 8];
-unsigned int *mpx_unit_queue_for(hipStream_t stream) {
+unsigned int *mpx_unit_queue_for(hipStream_t stream, int *exhausted) {
   static std::mutex mu;
   static std::unordered_map<unsigned long long, int> slot_of;  // (device << 56) ^ stream handle -> slot
   static unsigned int *base[64];
+  if (exhausted) *exhausted = 0;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return nullptr;
   unsigned int *q;
@@ -852,15 +856,21 @@ unsigned int *mpx_unit_queue_for(hipStream_t stream) {
     const unsigned long long key = ((unsigned long long)(dev & 63) << 56) ^ (unsigned long long)(uintptr_t)stream;
     auto it = slot_of.find(key);
     if (it == slot_of.end()) {
-      const int n = (int)slot_of.size();
-      const int slot = n < 256 ? n : (int)((key * 0x9E3779B97F4A7C15ull) >> 56);
-      it = slot_of.emplace(key, slot).first;
+      if (slot_of.size() >= (size_t)mpx_unit_queue_slots()) {
+        if (exhausted) *exhausted = 1;
+        return nullptr;
+      }
+      it = slot_of.emplace(key, (int)slot_of.size()).first;
     }
     q = b + 8 * it->second;
   }
   if (hipMemsetAsync(q, 0, 8 * sizeof(unsigned int), stream) != hipSuccess) return nullptr;
   return q;
 }
+// (verification hook: tests shrink the slot count to reach the exhausted path without creating 256 streams)
+static std::atomic<int> unit_queue_slots{256};
+int mpx_unit_queue_slots() { return unit_queue_slots.load(); }
+void mpx_unit_queue_set_slots(int n) { unit_queue_slots.store(n < 0 ? 0 : n > 256 ? 256 : n); }
 
 __global__ void __launch_bounds__(64 * v2::WV) __attribute__((amdgpu_waves_per_eu(1, 1)))
     sa2_bf16x3_persistent_kernel(const int32_t *__restrict__ idx, const int32_t *__restrict__ cnt, int64_t n_query, int N,
@@ -1258,8 +1268,11 @@ MPX_EXPORT int mpx_sa_mlp_bf16x3_factored(const float *pre, const float *ctr, co
   const int grid = cus[dev & 63];
   const int xcd_aware = (B % 8 == 0 && grid % 8 == 0 && npoint % v2::Q == 0) ? 1 : 0;
   MPX_LDS_LIMIT_ONCE(sa2_bf16x3_persistent_kernel, v2::LDS_BYTES, "mpx_sa_mlp_bf16x3_factored");
-  unsigned int *queue = mpx_unit_queue_for(mpx_s(stream));
-  MPX_REQUIRE(queue != nullptr, "mpx_sa_mlp_bf16x3_factored: cannot reset the unit queue");
+  int exhausted = 0;
+  unsigned int *queue = mpx_unit_queue_for(mpx_s(stream), &exhausted);
+  MPX_REQUIRE(queue != nullptr, exhausted ? "mpx_sa_mlp_bf16x3_factored: no unit-queue slot left for this stream (256 "
+                                            "distinct streams per process; reuse streams)"
+                                          : "mpx_sa_mlp_bf16x3_factored: cannot reset the unit queue");
   hipLaunchKernelGGL(sa2_bf16x3_persistent_kernel, dim3(grid), dim3(64 * v2::WV), v2::LDS_BYTES, mpx_s(stream), idx, cnt, nq, N,
                      npoint, nsample, static_cast<const unsigned char *>(wpack), out, out_stride, pre, ctr, xcd_aware, queue);
   MPX_LAUNCH_CHECK("mpx_sa_mlp_bf16x3_factored");

@@ -553,26 +553,32 @@ class MotionPolicyNetwork(nn.Module):
 
             return mlp(self.decoder, torch.cat((pc_encoding, mlp(self.feature_encoder, _lib.f32c(q))), dim=1))
         cat = torch.empty((B, 2048 + 64), dtype=torch.float32, device=dev)
-        fe = self.feature_encoder
-
-        def encode_q():
-            q8 = torch.zeros((B, 8), dtype=torch.float32, device=dev)
-            q8[:, :7] = q
-            h1 = linear(q8, self._q_first_weight(), fe[0].bias, ACT_LEAKY)
-            h2 = linear(h1, fe[2].weight, fe[2].bias, ACT_LEAKY)
-            h3 = linear(h2, fe[4].weight, fe[4].bias, ACT_LEAKY)
-            h4 = linear(h3, fe[6].weight, fe[6].bias, ACT_LEAKY)
-            linear(h4, fe[8].weight, fe[8].bias, ACT_NONE, out=cat[:, 2048:])
-            return q8, h1, h2, h3, h4
-
         # (small batches: beside the point-cloud encoder, on its second stream -- see OVERLAP_MAX_BATCH)
-        self.point_cloud_encoder(xyz, out=cat[:, :2048], aux=aux, side_work=encode_q)
+        self.point_cloud_encoder(xyz, out=cat[:, :2048], aux=aux, side_work=lambda: self.encode_configuration(q, out=cat[:, 2048:]))
+        if aux is not None:
+            aux["encoding"] = cat[:, :2048]
+        return self.decode(cat)
+
+    def encode_configuration(self, q: torch.Tensor, out: Optional[torch.Tensor] = None):
+        """``feature_encoder`` (model.py:45-55): q [B,7] -> [B,64], written to ``out`` when given.  Returns the output
+        followed by the temporaries (callers on a side stream keep them referenced until the streams have joined)."""
+        fe = self.feature_encoder
+        B, dev = q.size(0), q.device
+        q8 = torch.zeros((B, 8), dtype=torch.float32, device=dev)
+        q8[:, :7] = q
+        h1 = linear(q8, self._q_first_weight(), fe[0].bias, ACT_LEAKY)
+        h2 = linear(h1, fe[2].weight, fe[2].bias, ACT_LEAKY)
+        h3 = linear(h2, fe[4].weight, fe[4].bias, ACT_LEAKY)
+        h4 = linear(h3, fe[6].weight, fe[6].bias, ACT_LEAKY)
+        y = linear(h4, fe[8].weight, fe[8].bias, ACT_NONE, out=out)
+        return y, q8, h1, h2, h3, h4
+
+    def decode(self, cat: torch.Tensor) -> torch.Tensor:
+        """``decoder`` (model.py:56-64) on ``[pc_encoding (2048) | feature_encoding (64)]`` rows -> [B,7]."""
         de = self.decoder
         h = self.point_cloud_encoder._lin(cat, de[0].weight, de[0].bias, ACT_LEAKY)
         h = linear(h, de[2].weight, de[2].bias, ACT_LEAKY)
         h = linear(h, de[4].weight, de[4].bias, ACT_LEAKY)
-        if aux is not None:
-            aux["encoding"] = cat[:, :2048]
         return linear(h, de[6].weight, de[6].bias, ACT_NONE)
 
 

@@ -131,6 +131,9 @@ def sincos(x) -> Tuple[np.ndarray, np.ndarray]:
     return s, c
 
 
+RIGHT_GRIPPER_FRAME = 14  # last of the 15 frames orc_franka_fk writes (mpn_oracle.c)
+
+
 def franka_fk(q, finger: float = 0.025) -> np.ndarray:
     """q [B,7] -> frames [B,15,12] (R row-major, t)."""
     q = _f(q).reshape(-1, 7)
@@ -539,24 +542,32 @@ def _sa_layers(sd: Dict[str, np.ndarray], i: int):
              sd[f"point_cloud_encoder.SA_modules.{i}.mlps.0.{k}.bias"]) for k in (0, 2, 4)]
 
 
+def break_up_pc(pc) -> Tuple[np.ndarray, np.ndarray]:
+    """MPiNetsPointNet._break_up_pc (model.py:395-407): [B,N,M>3] -> xyz [B,N,3], features [B,M-3,N], both contiguous."""
+    pc = _f(pc)
+    return np.ascontiguousarray(pc[..., 0:3]), np.ascontiguousarray(np.transpose(pc[..., 3:], (0, 2, 1)))
+
+
+def fc_layer(sd: Dict[str, np.ndarray], x) -> np.ndarray:
+    """MPiNetsPointNet.fc_layer (model.py:385-393): Linear, GroupNorm(16), LeakyReLU, Linear, GroupNorm(16), LeakyReLU,
+    Linear.  x [B,1024] -> [B,2048]."""
+    p = "point_cloud_encoder.fc_layer."
+    x = _linear(_f(x), sd[p + "0.weight"], sd[p + "0.bias"])
+    x = _leaky(_group_norm(x, 16, sd[p + "1.weight"], sd[p + "1.bias"]))
+    x = _linear(x, sd[p + "3.weight"], sd[p + "3.bias"])
+    x = _leaky(_group_norm(x, 16, sd[p + "4.weight"], sd[p + "4.bias"]))
+    return _linear(x, sd[p + "6.weight"], sd[p + "6.bias"])
+
+
 def pointnet_encoder(sd: Dict[str, np.ndarray], pc) -> Tuple[np.ndarray, dict]:
     """MPiNetsPointNet.forward (model.py:409-426).  pc [B,N,4] -> [B,2048]."""
-    pc = _f(pc)
-    xyz = np.ascontiguousarray(pc[..., :3])
-    feat = np.ascontiguousarray(np.transpose(pc[..., 3:], (0, 2, 1)))
+    xyz, feat = break_up_pc(pc)
     aux = {}
     xyz1, f1, a1 = sa_module(xyz, feat, 512, 0.05, 128, _sa_layers(sd, 0))
     xyz2, f2, a2 = sa_module(xyz1, f1, 128, 0.3, 128, _sa_layers(sd, 1))
     _, f3, _ = sa_module(xyz2, f2, None, None, None, _sa_layers(sd, 2))
     aux.update(sa1=a1, sa2=a2, xyz1=xyz1, f1=f1, xyz2=xyz2, f2=f2, f3=f3)
-    x = f3[:, :, 0]
-    p = "point_cloud_encoder.fc_layer."
-    x = _linear(x, sd[p + "0.weight"], sd[p + "0.bias"])
-    x = _leaky(_group_norm(x, 16, sd[p + "1.weight"], sd[p + "1.bias"]))
-    x = _linear(x, sd[p + "3.weight"], sd[p + "3.bias"])
-    x = _leaky(_group_norm(x, 16, sd[p + "4.weight"], sd[p + "4.bias"]))
-    x = _linear(x, sd[p + "6.weight"], sd[p + "6.bias"])
-    return x, aux
+    return fc_layer(sd, f3[:, :, 0]), aux
 
 
 def policy_forward(sd: Dict[str, np.ndarray], pc, q) -> Tuple[np.ndarray, dict]:
@@ -626,6 +637,40 @@ def policy_forward_torch(sd, pc, q):
         if k != 6:
             x = F.leaky_relu(x)
     return x
+
+
+def rollout(sd, xyz, q, steps: int, sampler, limits, unnormalize_out: bool = False):
+    """TrainingMotionPolicyNetwork.rollout (model.py:128-183): ``q = clamp(q + f(xyz, q), -1, 1)``; unnormalise; resample
+    the robot cloud at the new configuration and overwrite ``xyz[:, :P, :3]`` IN PLACE.  ``sampler(q_unnorm, step)`` ->
+    [B,P,3].  Returns the list of steps+1 configurations (normalised, or joint angles when ``unnormalize_out``)."""
+    q = _f(q)
+    traj = [unnormalize(q, limits) if unnormalize_out else q]
+    for i in range(steps):
+        dq, _ = policy_forward(sd, xyz, q)
+        q = np.clip(q + dq, np.float32(-1), np.float32(1)).astype(np.float32)
+        qu = unnormalize(q, limits)
+        traj.append(qu if unnormalize_out else q)
+        samples = sampler(qu, i)
+        xyz[:, : samples.shape[1], :3] = samples
+    return traj
+
+
+def validation_reduce(traj, target_position, sphere_table, cub, cyl, finger: float = 0.025):
+    """The tail of validation_step (model.py:274-318) for a given unnormalised rollout ``traj`` [B,T,7]: final
+    end-effector position error per environment, has_collision [B] by the radius-group reduce (restated as one
+    ``sdf <= radius`` test per sphere -- the groups only batch equal radii), and the two averages it returns.
+    ``sphere_table`` = (centres, radii, link ids) of FrankaCollisionSampler(with_base_link=False)."""
+    traj = _f(traj)
+    B, T = traj.shape[:2]
+    centres, radii, links = sphere_table
+    frames = franka_fk(traj.reshape(-1, 7), finger)
+    c = transform_table(frames, centres, links).reshape(B, T, len(radii), 3)
+    flags, msdf = collision_flags(c, radii, cub, cyl)
+    eff = frames.reshape(B, T, frames.shape[1], 12)[:, -1, RIGHT_GRIPPER_FRAME, 9:]
+    err = np.linalg.norm(eff - _f(target_position), axis=1).astype(np.float32)
+    margin = (msdf - _f(radii)[None, None, :]).reshape(B, -1).min(axis=1)
+    return {"has_collision": flags, "position_error": err, "avg_target_error": np.float32(err.mean()),
+            "avg_collision_rate": np.float32(np.count_nonzero(flags) / B), "margin": margin}
 
 
 def unnormalize(q, limits) -> np.ndarray:

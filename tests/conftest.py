@@ -32,6 +32,13 @@ def loss_golden():
 
 
 @pytest.fixture(scope="session")
+def model_golden():
+    """Vectors made by running the reference's own model.py (tests/golden/gen_model_golden.py)."""
+    path = os.path.join(ROOT, "tests", "golden", "model_golden.npz")
+    return dict(np.load(path, allow_pickle=False))
+
+
+@pytest.fixture(scope="session")
 def oracle():
     from oracle import oracle as orc
 
