@@ -44,50 +44,67 @@ SA2_FLOPS = 16384 * 57728 * 2  # 128*128 rows x (67*128 + 128*128 + 128*256) MAC
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 
 
-def cpu_baseline(prob, model, n_env: int):
-    """Oracle (CPU port) timed on `n_env` env-steps of the same workload, host cores stated."""
-    from mpinets_amd import franka_tables as ft
-    from oracle import oracle as orc
-
-    try:
-        from threadpoolctl import threadpool_info
-
-        cores = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
-    except Exception:
-        cores = os.cpu_count() or 1
-    orc.build()
-    sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
-    xyz = prob["xyz"][:n_env].cpu().numpy()
-    qn = prob["q_norm"][:n_env].cpu().numpy()
-    prim = {k: prob[k][:n_env].cpu().numpy() for k in prob if k.startswith(("cuboid_", "cylinder_"))}
-    c, r, l, _ = ft.collision_sphere_table(False)
-    tp, tl = ft.link_point_table()
-    t0 = time.perf_counter()
+def cpu_step(orc, ft, sd, xyz, qn, prim, tables):
+    """One pass of the hot path over a batch on the host, by the oracle (a port, not the product)."""
+    (c, r, l), (tp, tl) = tables
     dq, _ = orc.policy_forward(sd, xyz, qn)
     q = np.clip(qn + dq, -1, 1).astype(np.float32)
     qu = orc.unnormalize(q, ft.JOINT_LIMITS_REAL)
     T = orc.franka_fk(qu)
-    cloud = orc.transform_table(T, tp, tl, np.arange(2048, dtype=np.int32))
+    orc.transform_table(T, tp, tl, np.arange(2048, dtype=np.int32))
     centres = orc.transform_table(T, c, l)
     orc.collision_flags(centres[:, None], r, (prim["cuboid_centers"], prim["cuboid_dims"], prim["cuboid_quats"]),
                         (prim["cylinder_centers"], prim["cylinder_radii"], prim["cylinder_heights"],
                          prim["cylinder_quats"]))
+
+
+def cpu_baseline(prob, model, n_env: int):
+    """Oracle (CPU port) timed on `n_env` env-steps of the same workload on ALL host cores: the C parts
+    (FPS, ball query, grouping, FK, SDF) are OpenMP-parallel over environments, the numpy float64 matrix products use
+    the BLAS pool; `cores` = the threads actually used by both.  `scalar_1t`: the same step on 8 environments with the C
+    parts on ONE thread (what rounds 1-3 reported)."""
+    from mpinets_amd import franka_tables as ft
+    from oracle import oracle as orc
+
+    orc.build()
+    host = int(os.cpu_count() or 1)
+    try:
+        from threadpoolctl import threadpool_info
+
+        blas = max([p.get("num_threads", 1) for p in threadpool_info() if p.get("user_api") == "blas"] + [1])
+    except Exception:
+        blas = host
+    sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+    tables = (ft.collision_sphere_table(False)[:3], ft.link_point_table())
+
+    def sample(n):
+        return (prob["xyz"][:n].cpu().numpy(), prob["q_norm"][:n].cpu().numpy(),
+                {k: prob[k][:n].cpu().numpy() for k in prob if k.startswith(("cuboid_", "cylinder_"))})
+
+    n1 = min(8, n_env)
+    orc.set_threads(1)
+    xyz, qn, prim = sample(n1)
+    t0 = time.perf_counter()
+    cpu_step(orc, ft, sd, xyz, qn, prim, tables)
+    dt1 = time.perf_counter() - t0
+    omp = orc.set_threads(host)
+    xyz, qn, prim = sample(n_env)
+    t0 = time.perf_counter()
+    cpu_step(orc, ft, sd, xyz, qn, prim, tables)
     dt = time.perf_counter() - t0
-    del cloud
-    # `cores`: the port is NOT parallel throughout -- the C parts (FPS, ball query, grouping, FK, SDF) run on ONE thread,
-    # only the numpy float64 matrix products use the BLAS pool.  Both numbers are stated; `cores` is the BLAS pool
-    # (where most of the sample's time goes), `host_cores` what the box has.
-    return {"value": n_env / dt, "unit": "env-steps/s", "cores": int(cores), "blas_threads": int(cores),
-            "scalar_threads": 1, "host_cores": int(os.cpu_count() or 1), "kind": "port",
-            "sample": f"{n_env} env-steps of the same step (oracle/: C FPS+ball-query+FK+SDF on ONE thread, "
-                      f"numpy float64 MLPs on {cores} BLAS threads), {dt:.1f} s"}
+    return {"value": n_env / dt, "unit": "env-steps/s", "cores": int(min(omp, host)), "omp_threads": int(omp),
+            "blas_threads": int(blas), "host_cores": host, "kind": "port",
+            "scalar_1t": {"value": n1 / dt1, "unit": "env-steps/s", "cores": 1,
+                          "sample": f"{n1} env-steps, C parts on one thread, {dt1:.1f} s"},
+            "sample": f"{n_env} env-steps of the same step (oracle/: C FPS + ball query + grouping + FK + SDF OpenMP-parallel "
+                      f"over environments on {omp} threads, numpy float64 MLPs on {blas} BLAS threads), {dt:.1f} s"}
 
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector peak (64 FLOP / clk / SIMD)
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak at 2.4 GHz
-TRAFFIC_RECORD = "r03_traffic.json"  # written by tools/pmc_traffic.py from the PMC passes of this round
-FAST_RECORD = "r03_fast_traffic.json"  # the same for the bf16x3 kernels (tools/pmc_fast.py)
+TRAFFIC_RECORD = "r04_traffic.json"  # written by tools/pmc_traffic.py from the PMC passes of this round
+FAST_RECORD = "r04_fast_traffic.json"  # the same for the bf16x3 kernels (tools/pmc_fast.py)
 
 # FLOPs per (collision sphere, unmasked primitive) pair, counted from csrc/sdf_device.h (one fma = 2): cuboid =
 # projection 18 + 3 abs-sub + 3 max + 5 (norm) + sqrt + 3 (max3, min) + 2 (add, min-select) = 35; cylinder = 18 + 4 (rho)
@@ -188,6 +205,9 @@ def fast_roofline(B, live_ms, live_flops):
 # multiply-adds per (query, neighbour) row of SA2 inside the fused kernel: layers 2 and 3 (128x128 + 128x256);
 # layer 1 (67x128) runs once per point / per query as plain GEMMs (mpx_sa_mlp_factored)
 SA2_ROW_MACS = 128 * 128 + 128 * 256
+# multiply-adds per environment of the fc head, the joint encoder and the decoder (model.py:41-66, 385-393)
+HEAD_MACS = (1024 * 4096 + 4096 * 2048 + 2048 * 2048 + 7 * 32 + 32 * 64 + 64 * 128 + 128 * 128 + 128 * 64
+             + 2112 * 512 + 512 * 256 + 256 * 128 + 128 * 7)
 
 
 def spawn_ranks_if_needed(args) -> bool:
@@ -229,6 +249,10 @@ def main():
     ap.add_argument("--whole-batch-steps", type=int, default=0, help="opt-in extra: steps of the whole 65 536-environment configs[4] batch on this one GPU (0 = skip; needs ~90 GB)")
     ap.add_argument("--pipeline-steps", type=int, default=3, help="steps of the two-stream pipelined measurement of the headline workload (0 = skip)")
     ap.add_argument("--cpu-envs", type=int, default=64, help="env-steps in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak (default): --envs environments per GPU; strong: --global-envs environments split evenly over the GPUs")
+    ap.add_argument("--global-envs", type=int, default=8192, help="total environments of a --scaling strong run")
+    ap.add_argument("--train-steps", type=int, default=3, help="steps of the row-N1 training-step extra (0 = skip)")
     ap.add_argument("--scene-pool", type=int, default=1024, help="distinct host-generated primitive sets tiled over the batch (clouds are drawn per env on the device)")
     args = ap.parse_args()
     shared_devices = spawn_ranks_if_needed(args)
@@ -250,18 +274,25 @@ def main():
     n_gpus = ws
     _lib.load()
 
-    B = args.envs
+    # weak scaling (default): every rank owns --envs environments; strong: ONE fixed batch of --global-envs environments
+    # cut into contiguous near-equal ranges (shard.split_even)
+    strong = args.scaling == "strong"
+    envs = shard.split_even(args.global_envs, n_gpus)[rank] if strong else shard.env_range(rank, n_gpus, args.envs)
+    B = len(envs)
+    global_envs = args.global_envs if strong else args.envs * n_gpus
+    assert B > 0, f"--scaling strong: {args.global_envs} environments cannot feed {n_gpus} ranks"
     torch.manual_seed(0)  # identical random-init weights on every rank (replicated, like a checkpoint)
     model = MotionPolicyNetwork().to(dev).eval()
-    envs = shard.env_range(rank, n_gpus, B)
     # ONE global batch of n_gpus * B problems that depends on the seed only; this rank owns rows `envs` of it and every
     # random draw (scene clouds at set-up and at every re-render) is keyed by the GLOBAL environment id, so the
     # gathered result of an N-rank run equals a single-rank run over the same environments bit for bit
     # (tests/test_gpu_shard.py)
     prob = make_problem_batch(B, seed=1000, device=dev, kinds=("tabletop", "cubby", "dresser"), M1=40, M2=16,
                               scene_pool=args.scene_pool, device_clouds=True, env_offset=envs.start,
-                              total_envs=B * n_gpus)
-    eng = RolloutEngine(model, prob, rerender_scene=True, scene_seed=17)
+                              total_envs=global_envs)
+    # the reference's loop (model.py:170-181, run_inference.py:188-189): the robot cloud's column subset is redrawn at
+    # EVERY step, one draw for the batch -- on the device here (mpx_draw_subset), the same on every rank
+    eng = RolloutEngine(model, prob, rerender_scene=True, scene_seed=17, resample_subset=True, subset_seed=23)
 
     for _ in range(args.warmup):
         eng.step()
@@ -269,7 +300,7 @@ def main():
     shard.barrier()
     _lib.profile_start("mpx_sa_mlp", "mpx_sa_mlp_factored", "mpx_fps", "mpx_ball_query", "mpx_linear", "mpx_linear_ws", "mpx_linear_rowmax",
                         "mpx_franka_cloud", "mpx_franka_collision", "mpx_joint_step", "mpx_groupnorm_leaky", "mpx_scene_cloud",
-                        "mpx_sa3_chain")
+                        "mpx_sa3_chain", "mpx_draw_subset")
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -315,14 +346,19 @@ def main():
     q_all = shard.gather_to_rank0(eng.q)
     f_all = shard.gather_to_rank0(eng.flags)
 
-    # ---- extra: BASELINE configs 2 and 4 (FK + swept-sphere SDF collision validation only) on this rank's envs
-    extra = None
-    if rank == 0 and args.extra and not shared_devices:  # rank 0's GPU only; the other ranks idle at the next barrier
+    # ---- extra: BASELINE configs 3 and 1 ("8192 envs x 50-waypoint expert-trajectory collision validation, sharded" and
+    # "1024 envs FK + swept-sphere SDF") -- EVERY rank on its own shard, inside barriers: config 3's 8192 trajectories are
+    # split evenly over the ranks (its definition is a fixed global batch), config 1 runs 1024 environments per rank
+    extra = {}
+    collision = None
+    if args.extra:
+        from mpinets_amd.geometry import TorchCuboids, TorchCylinders
         from mpinets_amd.scenes import linear_trajectories, random_configurations
 
         def timed(fn, n=20):
             fn()
             torch.cuda.synchronize()
+            shard.barrier()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(n):
@@ -331,86 +367,25 @@ def main():
             torch.cuda.synchronize()
             return e0.elapsed_time(e1) / n
 
-        traj = torch.from_numpy(linear_trajectories(B, 50, 5)).to(dev)
-        q1k = torch.from_numpy(random_configurations(1024, 6)).to(dev)
+        C4_ENVS = 8192
+        mine4 = shard.split_even(C4_ENVS, n_gpus)[rank]
+        n4 = min(len(mine4), B)  # (a development run with a small --envs validates what it has scenes for)
+        n2 = min(1024, B)
+        traj = torch.from_numpy(linear_trajectories(C4_ENVS, 50, 5)[mine4.start:mine4.start + n4]).to(dev)
+        q1k = torch.from_numpy(random_configurations(1024 * n_gpus, 6)[rank * 1024:rank * 1024 + n2]).to(dev)
         sub = lambda t, n: t[:n].contiguous()
-        from mpinets_amd.geometry import TorchCuboids, TorchCylinders
-        cub1k = TorchCuboids(sub(prob["cuboid_centers"], 1024), sub(prob["cuboid_dims"], 1024), sub(prob["cuboid_quats"], 1024))
-        cyl1k = TorchCylinders(sub(prob["cylinder_centers"], 1024), sub(prob["cylinder_radii"], 1024),
-                               sub(prob["cylinder_heights"], 1024), sub(prob["cylinder_quats"], 1024))
-        c4_ms = timed(lambda: eng.collision.check(traj, eng.cuboids, eng.cylinders))
-        c2_ms = timed(lambda: eng.collision.check(q1k, cub1k, cyl1k, return_sdf=True))
-        c2_cpu = None
-        if args.cpu_envs > 0:  # the same config-2 work on the host: oracle port, single thread
-            from mpinets_amd import franka_tables as ft
-            from oracle import oracle as orc
-
-            orc.build()
-            c_, r_, l_, _ = ft.collision_sphere_table(False)
-            qh = q1k.cpu().numpy()
-            ph = {k: prob[k][:1024].cpu().numpy() for k in prob if k.startswith(("cuboid_", "cylinder_"))}
-            th = time.perf_counter()
-            ctr = orc.transform_table(orc.franka_fk(qh), c_, l_)
-            orc.collision_flags(ctr[:, None], r_, (ph["cuboid_centers"], ph["cuboid_dims"], ph["cuboid_quats"]),
-                                (ph["cylinder_centers"], ph["cylinder_radii"], ph["cylinder_heights"], ph["cylinder_quats"]))
-            c2_cpu = 1024 / (time.perf_counter() - th)
-        c4_cpu = None
-        if args.cpu_envs > 0:  # config-4 work on the host: 32 trajectories x 50 waypoints, oracle port, single thread
-            th = time.perf_counter()
-            tj = traj[:32].cpu().numpy()
-            ctr4 = orc.transform_table(orc.franka_fk(tj.reshape(-1, 7)), c_, l_).reshape(32, 50, -1, 3)
-            p4 = {k: prob[k][:32].cpu().numpy() for k in prob if k.startswith(("cuboid_", "cylinder_"))}
-            orc.collision_flags(ctr4, r_, (p4["cuboid_centers"], p4["cuboid_dims"], p4["cuboid_quats"]),
-                                (p4["cylinder_centers"], p4["cylinder_radii"], p4["cylinder_heights"], p4["cylinder_quats"]))
-            c4_cpu = 32 * 50 / (time.perf_counter() - th)
-        # configs 1 and 3: the same closed-loop step (static scene) for a single problem and for 256 problems x 50 steps
-        small = {}
-        for nb, nsteps, prec in ((1, 50, "fp32"), (256, 50, "fp32"), (256, 50, "bf16x3")):
-            ps = make_problem_batch(nb, seed=7000 + nb, device=dev, kinds=("tabletop",), M1=16, M2=16, scene_pool=64,
-                                    device_clouds=True)
-            model.set_precision(prec)
-            es = RolloutEngine(model, ps)
-            es.step()
-            torch.cuda.synchronize()
-            t_s = time.perf_counter()
-            for _ in range(nsteps):
-                es.step()
-            torch.cuda.synchronize()
-            small[nb if prec == "fp32" else "256x3"] = (time.perf_counter() - t_s) * 1e3
-            del es, ps
-        model.set_precision("fp32")
-        extra = {
-            "c1_single_problem": {"envs": 1, "steps": 50, "ms_per_step": small[1] / 50, "rollout_ms": small[1],
-                                  "what": "one tabletop problem, 50 closed-loop steps (the reference's deployed use; it "
-                                          "assumes 80 ms per step, run_inference.py:297)"},
-            "c3_rollout_256": {"envs": 256, "steps": 50, "ms_per_step": small[256] / 50, "rollout_ms": small[256],
-                               "env_steps_per_s": 256 * 50 / small[256] * 1e3, "dtype": "f32",
-                               "bf16x3_rollout_ms": small["256x3"], "bf16x3_env_steps_per_s": 256 * 50 / small["256x3"] * 1e3,
-                               "what": "256 tabletop problems, 50-step rollout (policy forward + joint update + FK cloud "
-                                       "refresh + collision check per step)",
-                               "precision_note": "BASELINE configs[2] names bf16 for the policy forward; plain bf16 products "
-                                                 "miss the north star's 1e-5 bar on the policy deltas (2.6e-4 simulated), so the "
-                                                 "bf16 matrix cores are offered only as 'bf16x3' (3 split products per fp32 "
-                                                 "product, fp32 accumulate; 2.6e-7 measured) -- the bf16x3_* fields are that mode, "
-                                                 "the headline fields exact fp32"},
-            "c4_collision_validation": {"envs": B, "waypoints": 50, "ms": c4_ms, "env_waypoints_per_s": B * 50 / c4_ms * 1e3,
-                                        "cpu_port_env_waypoints_per_s": c4_cpu, "cpu_cores": 1,
-                                        "roofline": {"bound": "valu", "achieved": collision_flops(prob, slice(None), 50) / (c4_ms * 1e-3) / 1e12,
-                                                     "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                                     "frac": collision_flops(prob, slice(None), 50) / (c4_ms * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS,
-                                                     "executed_gflop": collision_flops(prob, slice(None), 50) / 1e9,
-                                                     "note": "executed FLOPs: unmasked primitives only (35 per sphere-cuboid, 33 per "
-                                                             "sphere-cylinder pair, csrc/sdf_device.h); counters: profiles/r03_collision_pmc.md"},
-                                        "what": "FK + 56-sphere SDF vs 40 cuboids + 16 cylinders (zero-padded), has_collision[B] (model.py:293-314)"},
-            "c2_fk_sdf_1024": {"envs": 1024, "ms": c2_ms, "env_steps_per_s": 1024 / c2_ms * 1e3,
-                               "cpu_port_env_steps_per_s": c2_cpu, "cpu_cores": 1,
-                               "roofline": {"bound": "valu (launch / latency bound at this size)",
-                                            "achieved": collision_flops(prob, slice(0, 1024), 1) / (c2_ms * 1e-3) / 1e12,
-                                            "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                            "frac": collision_flops(prob, slice(0, 1024), 1) / (c2_ms * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS,
-                                            "note": "1024 one-wave workgroups of ~45 us: four per CU; a launch-latency-sized call"},
-                               "what": "FK + sphere SDF, flags + min-sdf [1024,56] written"},
-        }
+        prims = lambda n: (TorchCuboids(sub(prob["cuboid_centers"], n), sub(prob["cuboid_dims"], n), sub(prob["cuboid_quats"], n)),
+                           TorchCylinders(sub(prob["cylinder_centers"], n), sub(prob["cylinder_radii"], n),
+                                          sub(prob["cylinder_heights"], n), sub(prob["cylinder_quats"], n)))
+        cub4, cyl4 = prims(n4)
+        cub2, cyl2 = prims(n2)
+        c4_ms = timed(lambda: eng.collision.check(traj, cub4, cyl4))
+        c2_ms = timed(lambda: eng.collision.check(q1k, cub2, cyl2, return_sdf=True))
+        flags4 = shard.gather_to_rank0(eng.collision.check(traj, cub4, cyl4).to(torch.int32))  # (the final host gather of config 3)
+        col_recs = shard.gather_objects({"rank": rank, "c4_envs": n4, "c4_ms": c4_ms, "c4_gflop": collision_flops(prob, slice(0, n4), 50) / 1e9,
+                                         "c2_envs": n2, "c2_ms": c2_ms, "c2_gflop": collision_flops(prob, slice(0, n2), 1) / 1e9})
+        collision = {"records": col_recs, "c4_rate": None if flags4 is None else float((flags4 != 0).float().mean())}
+        del traj, q1k, cub4, cyl4, cub2, cyl2
 
     # ---- extra: the SAME headline workload with the batch cut into two shares on two HIP streams, one a stage behind
     # the other (PipelinedRollout): share B's sampling kernels run while share A is in its matrix kernels.  All ranks.
@@ -420,8 +395,8 @@ def main():
 
         prob_p = make_problem_batch(B, seed=1000, device=dev, kinds=("tabletop", "cubby", "dresser"), M1=40, M2=16,
                                     scene_pool=args.scene_pool, device_clouds=True, env_offset=envs.start,
-                                    total_envs=B * n_gpus)
-        pr = PipelinedRollout(model, prob_p, ways=2, rerender_scene=True, scene_seed=17)
+                                    total_envs=global_envs)
+        pr = PipelinedRollout(model, prob_p, ways=2, rerender_scene=True, scene_seed=17, resample_subset=True, subset_seed=23)
         pr.run(args.warmup + 1)
         torch.cuda.synchronize()
         shard.barrier()
@@ -431,7 +406,7 @@ def main():
         shard.barrier()
         el_p = shard.max_over_ranks(time.perf_counter() - tp0, dev)
         pipelined = {"ways": 2, "steps": args.pipeline_steps, "ms_per_step": el_p / args.pipeline_steps * 1e3,
-                     "env_steps_per_s": B * n_gpus * args.pipeline_steps / el_p, "dtype": "f32",
+                     "env_steps_per_s": global_envs * args.pipeline_steps / el_p, "dtype": "f32",
                      "what": "the headline workload with the batch in two shares on two HIP streams, one a stage behind "
                              "the other (mpinets_amd.rollout.PipelinedRollout); state bit-identical to the single-stream "
                              "run (tools/pipeline_timing.py).  The matrix kernels leave only 32 VGPRs per SIMD free, so a "
@@ -444,7 +419,7 @@ def main():
     if args.extra and args.static_steps > 0:
         prob_s = make_problem_batch(B, seed=5000, device=dev, kinds=("tabletop",), M1=16, M2=16,
                                     scene_pool=args.scene_pool, device_clouds=True, env_offset=envs.start,
-                                    total_envs=B * n_gpus)
+                                    total_envs=global_envs)
         eng_s = RolloutEngine(model, prob_s)
         eng_s.step()
         torch.cuda.synchronize()
@@ -460,16 +435,14 @@ def main():
         el_s = shard.max_over_ranks(time.perf_counter() - ts0, dev)
         prof_s = _lib.profile_stop()
         static = {"envs_per_gpu": B, "steps": args.static_steps, "ms_per_step": el_s / args.static_steps * 1e3,
-                  "env_steps_per_s": B * n_gpus * args.static_steps / el_s, "dtype": "f32",
+                  "env_steps_per_s": global_envs * args.static_steps / el_s, "dtype": "f32",
                   "collision_rate": float((eng_s.flags != 0).float().mean().item()),
                   "kernels_ms_per_step": {k[4:]: float(np.sum(v)) / args.static_steps for k, v in prof_s.items()},
                   "mean_distinct_neighbours": [float(c.float().mean().item()) for c in model.point_cloud_encoder.last_counts],
                   "what": "tabletop scenes (16 cuboids + 16 cylinders, zero-padded), static scene cloud; every step: policy "
                           "forward + joint update + FK cloud refresh + collision check"}
         del eng_s, prob_s
-        if rank == 0:
-            extra = extra if extra is not None else {}
-            extra["tabletop_static_scene"] = static
+        extra["tabletop_static_scene"] = static
 
     # ---- extra: the worst case of the headline -- the SAME workload with the padding elision switched off: every
     # neighbourhood walks its nominal 128 slots like the reference does (model.set_elide_padding(False))
@@ -487,15 +460,153 @@ def main():
         el_a = shard.max_over_ranks(time.perf_counter() - ta0, dev)
         model.set_elide_padding(True)
         all_slots = {"steps": args.all_slots_steps, "ms_per_step": el_a / args.all_slots_steps * 1e3,
-                     "env_steps_per_s": B * n_gpus * args.all_slots_steps / el_a, "dtype": "f32",
+                     "env_steps_per_s": global_envs * args.all_slots_steps / el_a, "dtype": "f32",
                      "what": "the headline workload with padding elision OFF: the grouped MLPs evaluate all 128 slots of every "
                              "neighbourhood (what the reference computes; same result bit for bit) -- the density-independent "
                              "floor of the headline number"}
 
+    # ---- extra: row N1, one optimisation step (forward + losses + backward + gradient all-reduce over RCCL + clip + Adam;
+    # model.py:185-240, run_training.py:71-77) at the reference's batch size per GPU (jobconfig.yaml: 10) and at 256 --
+    # every rank, data-parallel: the ONE collective of the code base
+    training = None
+    if args.extra and args.train_steps > 0:
+        from mpinets_amd.model import TrainingMotionPolicyNetwork
+        from mpinets_amd.training import train_step
+
+        scene_keys = ("cuboid_centers", "cuboid_dims", "cuboid_quats", "cylinder_centers", "cylinder_radii",
+                      "cylinder_heights", "cylinder_quats")
+        torch.manual_seed(0)
+        tm = TrainingMotionPolicyNetwork(2048, 1.0, 5.0).to(dev)  # (loss weights of jobconfig.yaml)
+        opt = tm.configure_optimizers()
+        training = {}
+        for tb in (10, 256):
+            nb = min(tb, B)
+            g = torch.Generator(device="cpu").manual_seed(100 + rank)
+            sup = torch.clamp(prob["q_norm"][:nb] + 0.05 * torch.randn(nb, 7, generator=g).to(dev), -1, 1)
+            batch = {"xyz": prob["xyz"][:nb].clone(), "configuration": prob["q_norm"][:nb].clone(), "supervision": sup,
+                     **{k: prob[k][:nb] for k in scene_keys}}
+            for _ in range(2):
+                train_step(tm, opt, batch)
+            torch.cuda.synchronize()
+            shard.barrier()
+            tt0 = time.perf_counter()
+            for _ in range(args.train_steps):
+                loss = train_step(tm, opt, batch)
+            torch.cuda.synchronize()
+            shard.barrier()
+            el_t = shard.max_over_ranks(time.perf_counter() - tt0, dev)
+            c1t, c2t = tm.point_cloud_encoder.last_counts
+            rows1, rows2 = int(c1t.clamp(min=1).sum()), int(c2t.clamp(min=1).sum())
+            # executed matrix work: forward over the hit rows only (the differentiable path packs them), backward = 2x
+            fwd = 2.0 * (rows1 * 8448 + rows2 * 57728 + nb * (128 * 919040 + HEAD_MACS))
+            training[f"batch_{tb}"] = {
+                "samples_per_gpu": nb, "steps": args.train_steps, "ms_per_step": el_t / args.train_steps * 1e3,
+                "samples_per_s": nb * n_gpus * args.train_steps / el_t, "loss": float(loss.item()),
+                "executed_tflops": 3 * fwd / (el_t / args.train_steps) / 1e12,
+                "frac_of_fp32_mfma_peak": 3 * fwd / (el_t / args.train_steps) / 1e12 / FP32_MFMA_PEAK_TFLOPS}
+        training["what"] = ("TrainingMotionPolicyNetwork.training_step + backward + bucketed gradient all-reduce + clip(1.0) + Adam "
+                            "(mpinets_amd.training.train_step), fp32; batch_10 = jobconfig.yaml's batch size per GPU; FLOPs = 3 x "
+                            "the forward's executed matrix work (hit rows only)")
+        training["allreduce_ranks"] = n_gpus if dist_backend is not None else 1
+        del tm, opt, batch
+        model.eval()
+        extra["n1_training_step"] = training
+
+    # ---- every cross-rank measurement is done: release the other ranks.  What follows runs on rank 0 alone (single-GPU
+    # configurations and the host-side CPU baseline) while nobody waits at a barrier.
+    shard.barrier()
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+    if rank != 0:
+        return
+
+    # ---- rank 0: BASELINE configs 0 and 2 -- the same closed-loop step (static scene) for a single problem and for
+    # 256 problems x 50 steps
+    if args.extra:
+        small = {}
+        for nb, nsteps, prec in ((1, 50, "fp32"), (256, 50, "fp32"), (256, 50, "bf16x3")):
+            ps = make_problem_batch(nb, seed=7000 + nb, device=dev, kinds=("tabletop",), M1=16, M2=16, scene_pool=64,
+                                    device_clouds=True)
+            model.set_precision(prec)
+            es = RolloutEngine(model, ps, resample_subset=True, subset_seed=23)
+            es.step()
+            torch.cuda.synchronize()
+            t_s = time.perf_counter()
+            for _ in range(nsteps):
+                es.step()
+            torch.cuda.synchronize()
+            small[nb if prec == "fp32" else "256x3"] = (time.perf_counter() - t_s) * 1e3
+            del es, ps
+        model.set_precision("fp32")
+        extra["c1_single_problem"] = {
+            "envs": 1, "steps": 50, "ms_per_step": small[1] / 50, "rollout_ms": small[1],
+            "what": "one tabletop problem, 50 closed-loop steps (the reference's deployed use; it assumes 80 ms per step, "
+                    "run_inference.py:297)"}
+        extra["c3_rollout_256"] = {
+            "envs": 256, "steps": 50, "ms_per_step": small[256] / 50, "rollout_ms": small[256],
+            "env_steps_per_s": 256 * 50 / small[256] * 1e3, "dtype": "f32",
+            "bf16x3_rollout_ms": small["256x3"], "bf16x3_env_steps_per_s": 256 * 50 / small["256x3"] * 1e3,
+            "what": "256 tabletop problems, 50-step rollout (policy forward + joint update + FK cloud refresh + collision "
+                    "check per step)",
+            "precision_note": "BASELINE configs[2] names bf16 for the policy forward; plain bf16 products miss the north "
+                              "star's 1e-5 bar on the policy deltas (2.6e-4 simulated), so the bf16 matrix cores are offered "
+                              "only as 'bf16x3' (3 split products per fp32 product, fp32 accumulate; 2.6e-7 measured) -- the "
+                              "bf16x3_* fields are that mode, the headline fields exact fp32"}
+    if collision is not None:
+        recs = collision["records"]
+        c4_envs, c4_ms = sum(r["c4_envs"] for r in recs), max(r["c4_ms"] for r in recs)
+        c2_envs, c2_ms = sum(r["c2_envs"] for r in recs), max(r["c2_ms"] for r in recs)
+        c4_flop, c2_flop = sum(r["c4_gflop"] for r in recs) * 1e9, sum(r["c2_gflop"] for r in recs) * 1e9
+        c2_cpu = c4_cpu = None
+        cpu_threads = 1
+        if args.cpu_envs > 0:  # the same work on the host: oracle port on all cores (OpenMP over environments)
+            from mpinets_amd import franka_tables as ft
+            from mpinets_amd.scenes import linear_trajectories, random_configurations
+            from oracle import oracle as orc
+
+            orc.build()
+            cpu_threads = orc.set_threads(int(os.cpu_count() or 1))
+            c_, r_, l_, _ = ft.collision_sphere_table(False)
+            host_prims = lambda n: {k: prob[k][:n].cpu().numpy() for k in prob if k.startswith(("cuboid_", "cylinder_"))}
+
+            def host_check(qh, T, ph):
+                n = ph["cuboid_centers"].shape[0]
+                ctr = orc.transform_table(orc.franka_fk(qh.reshape(-1, 7)), c_, l_).reshape(n, T, -1, 3)
+                orc.collision_flags(ctr, r_, (ph["cuboid_centers"], ph["cuboid_dims"], ph["cuboid_quats"]),
+                                    (ph["cylinder_centers"], ph["cylinder_radii"], ph["cylinder_heights"], ph["cylinder_quats"]))
+
+            n2h = min(1024, B)
+            th = time.perf_counter()
+            host_check(random_configurations(1024, 6)[:n2h], 1, host_prims(n2h))
+            c2_cpu = n2h / (time.perf_counter() - th)
+            n4h = min(512, B)
+            th = time.perf_counter()
+            host_check(linear_trajectories(8192, 50, 5)[:n4h], 50, host_prims(n4h))
+            c4_cpu = n4h * 50 / (time.perf_counter() - th)
+        extra["c4_collision_validation"] = {
+            "envs": c4_envs, "waypoints": 50, "sharding": f"{c4_envs} trajectories split evenly over {n_gpus} rank(s), no collective, one final gather of the flags",
+            "ms": c4_ms, "ms_per_rank": [r["c4_ms"] for r in recs], "envs_per_rank": [r["c4_envs"] for r in recs],
+            "env_waypoints_per_s": c4_envs * 50 / c4_ms * 1e3, "collision_rate": collision["c4_rate"],
+            "cpu_port_env_waypoints_per_s": c4_cpu, "cpu_cores": cpu_threads,
+            "roofline": {"bound": "valu", "achieved": c4_flop / (c4_ms * 1e-3) / 1e12, "peak": FP32_VALU_PEAK_TFLOPS * n_gpus,
+                         "unit": "TFLOP/s", "frac": c4_flop / (c4_ms * 1e-3) / 1e12 / (FP32_VALU_PEAK_TFLOPS * n_gpus),
+                         "executed_gflop": c4_flop / 1e9,
+                         "note": "executed FLOPs: unmasked primitives only (35 per sphere-cuboid, 33 per sphere-cylinder pair, "
+                                 "csrc/sdf_device.h) vs the fp32 VALU peak of all ranks; counters: profiles/r04_collision_pmc_pass*.csv"},
+            "what": "FK + 56-sphere SDF vs 40 cuboids + 16 cylinders (zero-padded), has_collision[B] (model.py:293-314)"}
+        extra["c2_fk_sdf_1024"] = {
+            "envs": c2_envs, "envs_per_rank": [r["c2_envs"] for r in recs], "ms": c2_ms, "ms_per_rank": [r["c2_ms"] for r in recs],
+            "env_steps_per_s": c2_envs / c2_ms * 1e3, "cpu_port_env_steps_per_s": c2_cpu, "cpu_cores": cpu_threads,
+            "roofline": {"bound": "valu (launch / latency bound at this size)", "achieved": c2_flop / (c2_ms * 1e-3) / 1e12,
+                         "peak": FP32_VALU_PEAK_TFLOPS * n_gpus, "unit": "TFLOP/s",
+                         "frac": c2_flop / (c2_ms * 1e-3) / 1e12 / (FP32_VALU_PEAK_TFLOPS * n_gpus),
+                         "note": "1024 environments per rank: a launch-latency-sized call"},
+            "what": "FK + sphere SDF, flags + min-sdf [1024,56] written; 1024 environments on every rank"}
+
     # ---- extra (opt-in, rank 0): the WHOLE of BASELINE configs[4] -- 65 536 environments -- resident on ONE GPU (the
     # launchers walk the batch in slabs past gridDim.y / 4 GB-per-operand limits; ~90 GB of the 288 GB)
     whole = None
-    if rank == 0 and args.whole_batch_steps > 0 and not shared_devices:
+    if args.whole_batch_steps > 0 and not shared_devices:
         del eng
         torch.cuda.empty_cache()
         BW = 65536
@@ -517,126 +628,133 @@ def main():
         del eng_w, prob_w
         torch.cuda.empty_cache()
 
-    if rank == 0:
-        # SA1 = mpx_sa_mlp; SA2 = mpx_sa_mlp_factored (first layer evaluated per point / per query by two
-        # mpx_linear calls, which are timed under linear_all)
-        sa1_ms, sa2_ms = float(np.mean(prof["mpx_sa_mlp"])), float(np.mean(prof["mpx_sa_mlp_factored"]))
-        # Executed work: only the DISTINCT neighbours of a ball-query neighbourhood are evaluated (its padding
-        # repeats the first neighbour; max-pooling is idempotent -> bit-identical output).  The roofline uses
-        # the FLOPs of the 32-row MFMA tiles actually issued (counts of the last timed step), not the nominal
-        # 128 slots per neighbourhood.
+    # ---- rank 0: the JSON line
+    # SA1 = mpx_sa_mlp; SA2 = mpx_sa_mlp_factored (first layer evaluated per point / per query by two
+    # mpx_linear calls, which are timed under linear_all)
+    sa1_ms, sa2_ms = float(np.mean(prof["mpx_sa_mlp"])), float(np.mean(prof["mpx_sa_mlp_factored"]))
+    # Executed work: only the DISTINCT neighbours of a ball-query neighbourhood are evaluated (its padding
+    # repeats the first neighbour; max-pooling is idempotent -> bit-identical output).  The roofline uses
+    # the FLOPs of the 32-row MFMA tiles actually issued (counts of the last timed step), not the nominal
+    # 128 slots per neighbourhood.
 
-        def tiles(c, q, gr):  # fp32 kernel: q consecutive queries per wave, rows packed at gr-row granularity (csrc/sa_mlp.hip: GR)
-            rows = (c.clamp(1, 128) + gr - 1) // gr * gr
-            return int(((rows.reshape(-1, q).sum(1) + 31) // 32).sum().item())
+    def tiles(c, q, gr):  # fp32 kernel: q consecutive queries per wave, rows packed at gr-row granularity (csrc/sa_mlp.hip: GR)
+        rows = (c.clamp(1, 128) + gr - 1) // gr * gr
+        return int(((rows.reshape(-1, q).sum(1) + 31) // 32).sum().item())
 
-        # queries per unit as the launchers choose them (csrc/sa_mlp.hip: launch_sa / mpx_sa_mlp_factored)
-        q1 = 32 if cnt1.numel() >= 1024 * 32 else 4
-        q2 = 8 if cnt2.numel() >= 1024 * 8 else (2 if cnt2.numel() >= 1024 else 1)
-        t1, t2 = tiles(cnt1, q1, 2), tiles(cnt2, q2, 4)
-        sa1_exec, sa2_exec = t1 * 32 * 8448 * 2, t2 * 32 * SA2_ROW_MACS * 2
-        achieved = sa2_exec / (sa2_ms * 1e-3) / 1e12
-        total_envsteps = B * n_gpus * args.steps
-        # HBM traffic of the dominant kernel comes from committed PMC passes (it cannot be read live).  The record
-        # carries the SHA-256 of the kernel source it was measured on: a changed kernel file -> traffic null
-        traffic, traffic_note = None, None
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_RECORD)))
-            if tj["envs_per_gpu"] == B and tj["kernel_source_sha256"] == kernel_source_hash():
-                traffic, traffic_note = tj["hbm_bytes_per_launch"], tj["source"] + "; " + tj["correction"]
-            else:
-                traffic_note = f"profiles/{TRAFFIC_RECORD} is stale (kernel source or batch size changed since the PMC passes)"
-        except Exception as e:
-            traffic_note = f"no PMC record: {e}"
-        out = {
-            "metric": "env-steps/sec (FK+SDF+PointNet++)",
-            "value": total_envsteps / elapsed,
-            "unit": "env-steps/s",
-            "n_gpus": n_gpus,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
-            "config": {
-                "workload": f"BASELINE configs[4] per-GPU share: closed-loop step over {B} mixed tabletop / cubby / "
-                            "dresser envs per GPU: scene cloud re-render (4096 pts from the primitives) + PointNet++ "
-                            "forward (2048 robot + 4096 scene + 128 target pts) + joint update + FK robot-cloud "
-                            "refresh + 56-sphere SDF collision check vs 40 cuboids + 16 cylinders (zero-padded)",
-                "envs_per_gpu": B, "global_envs": B * n_gpus, "points_per_env": int(prob["xyz"].size(1)),
-                "parallelism": f"env-sharded x{n_gpus}, no collective on the step",
-                "weights": "random-init (seed 0)",
-                "scene_pool": f"{min(args.scene_pool, B * n_gpus)} distinct host-generated primitive sets tiled over the "
-                              f"{B * n_gpus} global environments (env g uses set g mod pool); every environment draws its "
-                              "own scene cloud on the device, keyed by its global id",
-                "env_ids": [envs.start, envs.stop] if n_gpus == 1 else f"rank r owns [r*{B}, (r+1)*{B})",
-                **({"devices_shared": True, "physical_gpus": ndev,
-                    "note": "DEVELOPMENT RUN: the ranks share GPUs (MPX_SHARE_GPU=1, gloo) -- not a scaling number"}
-                   if shared_devices else {}),
-            },
-            "roofline": {
-                "kernel": "sa_mlp_packed_kernel<64,128,128,256,8,true> (SA2 fused group + MLP layers 2-3 + maxpool; layer 1 factored out)",
-                "bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_note,
-                "ms_per_launch": sa2_ms, "flops_per_launch": sa2_exec,
-                "note": "achieved = FLOPs of the 32-row MFMA tiles actually issued / time; ball-query padding "
-                        "(repeats of the first neighbour) is not re-evaluated (bit-identical result)",
-                "tiles_walked": t2, "tiles_nominal": B * 128 * 4, "nominal_flops_per_launch": SA2_FLOPS * B,
-                "nominal_equivalent_tflops": SA2_FLOPS * B / (sa2_ms * 1e-3) / 1e12,
-            },
-            "kernels_ms": {
-                "sa2_mlp": sa2_ms, "sa1_mlp": sa1_ms,
-                "sa1_tflops_executed": sa1_exec / (sa1_ms * 1e-3) / 1e12, "sa1_tiles_walked": t1,
-                "sa1_tiles_nominal": B * 512 * 4,
-                "fps": float(np.sum(prof["mpx_fps"])) / args.steps,
-                "ball_query": float(np.sum(prof["mpx_ball_query"])) / args.steps,
-                "linear_all": float(np.sum(prof["mpx_linear"]) + np.sum(prof["mpx_linear_ws"]) + np.sum(prof["mpx_linear_rowmax"])) / args.steps,
-                "sa3_chain": float(np.sum(prof["mpx_sa3_chain"])) / args.steps,
-            },
-            # per-stage achieved / peak with the ALGORITHMIC work of SURVEY.md section 8(d) (per env-step, x B envs)
-            "stages": stage_table(prof, args.steps, B, sa1_ms, sa1_exec, sa2_ms, sa2_exec,
-                                  collision_flops(prob, slice(None), 1)),
-            "result_check": {"gathered_q": list(q_all.shape), "collision_rate": float((f_all != 0).float().mean())},
-            # N-rank self-check: the communicator the barrier / MAX / gather ran on ("nccl" = RCCL; null = a plain single
-            # process, no group), the number of ranks on it, and every rank's device + own ms_per_step (`ms_per_step`
-            # above is their maximum)
-            "dist_backend": dist_backend, "rccl_ranks": n_gpus if dist_backend == "nccl" else 0,
-            "ranks": rank_records,
+    # queries per unit as the launchers choose them (csrc/sa_mlp.hip: launch_sa / mpx_sa_mlp_factored)
+    q1 = 32 if cnt1.numel() >= 1024 * 32 else 4
+    q2 = 8 if cnt2.numel() >= 1024 * 8 else (2 if cnt2.numel() >= 1024 else 1)
+    t1, t2 = tiles(cnt1, q1, 2), tiles(cnt2, q2, 4)
+    sa1_exec, sa2_exec = t1 * 32 * 8448 * 2, t2 * 32 * SA2_ROW_MACS * 2
+    achieved = sa2_exec / (sa2_ms * 1e-3) / 1e12
+    total_envsteps = global_envs * args.steps
+    # HBM traffic of the dominant kernel comes from committed PMC passes (it cannot be read live).  The record
+    # carries the SHA-256 of the kernel source it was measured on: a changed kernel file -> traffic null
+    traffic, traffic_note = None, None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_RECORD)))
+        if tj["envs_per_gpu"] == B and tj["kernel_source_sha256"] == kernel_source_hash():
+            traffic, traffic_note = tj["hbm_bytes_per_launch"], tj["source"] + "; " + tj["correction"]
+        else:
+            traffic_note = f"profiles/{TRAFFIC_RECORD} is stale (kernel source or batch size changed since the PMC passes)"
+    except Exception as e:
+        traffic_note = f"no PMC record: {e}"
+    out = {
+        "metric": "env-steps/sec (FK+SDF+PointNet++)",
+        "value": total_envsteps / elapsed,
+        "unit": "env-steps/s",
+        "n_gpus": n_gpus,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": args.scaling,
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": (f"BASELINE configs[4] per-GPU share: closed-loop step over {B} mixed tabletop / cubby / dresser envs per GPU"
+                         if not strong else
+                         f"BASELINE configs[4] step, STRONG scaling: one batch of {global_envs} mixed tabletop / cubby / dresser "
+                         f"envs split evenly over {n_gpus} GPU(s)") +
+                        ": scene cloud re-render (4096 pts from the primitives) + PointNet++ "
+                        "forward (2048 robot + 4096 scene + 128 target pts) + joint update + FK robot-cloud refresh with the "
+                        "column subset redrawn every step (the reference's loop, model.py:170-181) + 56-sphere SDF collision "
+                        "check vs 40 cuboids + 16 cylinders (zero-padded)",
+            "envs_per_gpu": B, "global_envs": global_envs, "points_per_env": int(prob["xyz"].size(1)),
+            "parallelism": f"env-sharded x{n_gpus}, no collective on the step",
+            "weights": "random-init (seed 0)",
+            "scene_pool": f"{min(args.scene_pool, global_envs)} distinct host-generated primitive sets tiled over the "
+                          f"{global_envs} global environments (env g uses set g mod pool); every environment draws its "
+                          "own scene cloud on the device, keyed by its global id",
+            "env_ids": [envs.start, envs.stop] if n_gpus == 1 else [r["env_ids"] for r in rank_records],
+            **({"devices_shared": True, "physical_gpus": ndev,
+                "note": "DEVELOPMENT RUN: the ranks share GPUs (MPX_SHARE_GPU=1, gloo) -- not a scaling number"}
+               if shared_devices else {}),
+        },
+        "roofline": {
+            "kernel": "sa_mlp_packed_kernel<64,128,128,256,8,true> (SA2 fused group + MLP layers 2-3 + maxpool; layer 1 factored out)",
+            "bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
+            # the same launch priced with SURVEY.md 8(d)'s NOMINAL work (all 128 slots of every neighbourhood, layer 1
+            # per (query, neighbour) row: 1.892 GFLOP per env): above 1 means the kernel does not do the nominal work --
+            # it skips ball-query padding and evaluates layer 1 per point.  Scene-density dependent; `frac` is the
+            # executed-work fraction, `all_slots` the density-independent floor of the whole step.
+            "frac_nominal": SA2_FLOPS * B / (sa2_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+            "traffic": traffic, "traffic_source": traffic_note,
+            "ms_per_launch": sa2_ms, "flops_per_launch": sa2_exec,
+            "note": "achieved = FLOPs of the 32-row MFMA tiles actually issued / time; ball-query padding "
+                    "(repeats of the first neighbour) is not re-evaluated (bit-identical result)",
+            "tiles_walked": t2, "tiles_nominal": B * 128 * 4, "nominal_flops_per_launch": SA2_FLOPS * B,
+            "nominal_equivalent_tflops": SA2_FLOPS * B / (sa2_ms * 1e-3) / 1e12,
+        },
+        "kernels_ms": {
+            "sa2_mlp": sa2_ms, "sa1_mlp": sa1_ms,
+            "sa1_tflops_executed": sa1_exec / (sa1_ms * 1e-3) / 1e12, "sa1_tiles_walked": t1,
+            "sa1_tiles_nominal": B * 512 * 4,
+            "fps": float(np.sum(prof["mpx_fps"])) / args.steps,
+            "ball_query": float(np.sum(prof["mpx_ball_query"])) / args.steps,
+            "linear_all": float(np.sum(prof["mpx_linear"]) + np.sum(prof["mpx_linear_ws"]) + np.sum(prof["mpx_linear_rowmax"])) / args.steps,
+            "sa3_chain": float(np.sum(prof["mpx_sa3_chain"])) / args.steps,
+        },
+        # per-stage achieved / peak with the ALGORITHMIC work of SURVEY.md section 8(d) (per env-step, x B envs)
+        "stages": stage_table(prof, args.steps, B, sa1_ms, sa1_exec, sa2_ms, sa2_exec,
+                              collision_flops(prob, slice(None), 1)),
+        "result_check": {"gathered_q": list(q_all.shape), "collision_rate": float((f_all != 0).float().mean())},
+        # N-rank self-check: the communicator the barrier / MAX / gather ran on ("nccl" = RCCL; null = a plain single
+        # process, no group), the number of ranks on it, and every rank's device + own ms_per_step (`ms_per_step`
+        # above is their maximum)
+        "dist_backend": dist_backend, "rccl_ranks": n_gpus if dist_backend == "nccl" else 0,
+        "ranks": rank_records,
+    }
+    if extra:
+        out["extra_configs"] = extra
+    if pipelined is not None:
+        out["pipelined_two_streams"] = pipelined
+    if all_slots is not None:
+        out["all_slots"] = all_slots
+    if whole is not None:
+        out["whole_config4_one_gpu"] = whole
+    if fast is not None:
+        fel, f1_ms, f2_ms, fdense_ms = fast
+        out["fast_mode"] = {
+            "what": "same step with the grouped MLPs and the large dense layers on the bf16 matrix cores, each fp32 product "
+                    "evaluated as hi*hi + hi*lo + lo*hi (split-bf16, fp32 accumulate); opt-in via "
+                    "model.set_precision('bf16x3'); policy deltas stay within 1e-5 of the fp32 oracle "
+                    "(tests/test_gpu_policy.py: 2.6e-7 measured)",
+            "dtype": "bf16x3", "value": global_envs * args.fast_steps / fel, "unit": "env-steps/s",
+            "steps": args.fast_steps, "ms_per_step": fel / args.fast_steps * 1e3,
+            "sa1_ms": f1_ms, "sa2_ms": f2_ms, "dense_ms": fdense_ms,
+            # the persistent bf16x3 kernel packs the rows of 8 consecutive queries per unit, like the fp32 kernel:
+            # the same tile count; three bf16 MFMAs per fp32 product
+            "sa2_executed_tflops": t2 * 32 * SA2_ROW_MACS * 2 / (f2_ms * 1e-3) / 1e12,
+            "sa2_bf16_mfma_tflops": 3 * t2 * 32 * SA2_ROW_MACS * 2 / (f2_ms * 1e-3) / 1e12,
+            "sa2_frac_of_bf16_peak_2500": 3 * t2 * 32 * SA2_ROW_MACS * 2 / (f2_ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS,
+            "roofline": fast_roofline(B, f2_ms, 3 * t2 * 32 * SA2_ROW_MACS * 2),
         }
-        if extra is not None:
-            out["extra_configs"] = extra
-        if pipelined is not None:
-            out["pipelined_two_streams"] = pipelined
-        if all_slots is not None:
-            out["all_slots"] = all_slots
-        if whole is not None:
-            out["whole_config4_one_gpu"] = whole
-        if fast is not None:
-            fel, f1_ms, f2_ms, fdense_ms = fast
-            out["fast_mode"] = {
-                "what": "same step with the grouped MLPs and the large dense layers on the bf16 matrix cores, each fp32 product "
-                        "evaluated as hi*hi + hi*lo + lo*hi (split-bf16, fp32 accumulate); opt-in via "
-                        "model.set_precision('bf16x3'); policy deltas stay within 1e-5 of the fp32 oracle "
-                        "(tests/test_gpu_policy.py: 2.6e-7 measured)",
-                "dtype": "bf16x3", "value": B * n_gpus * args.fast_steps / fel, "unit": "env-steps/s",
-                "steps": args.fast_steps, "ms_per_step": fel / args.fast_steps * 1e3,
-                "sa1_ms": f1_ms, "sa2_ms": f2_ms, "dense_ms": fdense_ms,
-                # the persistent bf16x3 kernel packs the rows of 8 consecutive queries per unit, like the fp32 kernel:
-                # the same tile count; three bf16 MFMAs per fp32 product
-                "sa2_executed_tflops": t2 * 32 * SA2_ROW_MACS * 2 / (f2_ms * 1e-3) / 1e12,
-                "sa2_bf16_mfma_tflops": 3 * t2 * 32 * SA2_ROW_MACS * 2 / (f2_ms * 1e-3) / 1e12,
-                "sa2_frac_of_bf16_peak_2500": 3 * t2 * 32 * SA2_ROW_MACS * 2 / (f2_ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS,
-                "roofline": fast_roofline(B, f2_ms, 3 * t2 * 32 * SA2_ROW_MACS * 2),
-            }
-        if args.cpu_envs > 0:  # rank 0's host cores, for every N (the other ranks wait at the final barrier)
-            out["cpu_baseline"] = cpu_baseline(prob, model, args.cpu_envs)
-        print(json.dumps(out))
-    shard.barrier()
-    if torch.distributed.is_initialized():
-        torch.distributed.destroy_process_group()
+    if args.cpu_envs > 0:  # rank 0's host cores, for every N (the other ranks were released above)
+        out["cpu_baseline"] = cpu_baseline(prob, model, args.cpu_envs)
+    print(json.dumps(out))
 
 
 if __name__ == "__main__":

@@ -29,7 +29,10 @@ typedef void *mpx_stream_t;
 
 #define MPX_NUM_FRAMES 15 /* link0..8, hand, leftfinger, rightfinger, l/r fingertip, right_gripper */
 
-int mpx_version(void); /* 300: mpx_set_variant / mpx_get_variant, mpx_sa_mlp_bf16x3_wants_order takes nsample */
+int mpx_version(void); /* 310: struct mpx_policy_weights ends with sa3_pack (NULL = layer-by-layer group-all module at every
+                          batch size; a caller built against the 200 header must be rebuilt), MPX_VARIANT_UNIT_QUEUE,
+                          mpx_ball_query_hits rejects nsample > 256;
+                          300: mpx_set_variant / mpx_get_variant, mpx_sa_mlp_bf16x3_wants_order takes nsample */
 const char *mpx_last_error(void);
 /* host-side query of the device the library will launch on (name buffer may be NULL) */
 int mpx_device_info(char *name, int name_len, int *cu_count, int *lds_bytes);
@@ -285,7 +288,11 @@ int mpx_fps(const float *xyz, int B, int N, int stride, int npoint, int32_t *idx
  * both on the same clouds in one process (tests/test_gpu_soak.py).  Returns non-zero on a bad selector / value.      */
 #define MPX_VARIANT_FPS 0
 #define MPX_VARIANT_BALL_QUERY 1
-#define MPX_VARIANT_COUNT_ 2
+/* 1 (default): a stream's persistent grouped-MLP launches take a private set of unit-queue counters (256 distinct
+ * (device, stream) handles per process).  0: handles not seen before get none, as if all 256 were taken -- the fp32
+ * launchers then run one unit per wave without a queue (same results), mpx_sa_mlp_bf16x3_factored fails with a message. */
+#define MPX_VARIANT_UNIT_QUEUE 2
+#define MPX_VARIANT_COUNT_ 3
 int mpx_set_variant(int what, int value);
 int mpx_get_variant(int what); /* -1: unknown selector */
 
@@ -298,7 +305,8 @@ int mpx_ball_query(const float *new_xyz, int new_stride, const float *xyz, int s
 
 /* The same search, writing the HIT slots only: idx[b, j, 0 .. max(cnt, 1)) (an empty row still gets its slot 0 = 0); the
  * padding slots are left untouched.  For consumers that take `cnt` and never look past it (mpx_sa_mlp / _factored /
- * _bf16x3 with counts): most of a row is padding, so most of the index writes go away.  cnt is required.             */
+ *  _bf16x3 with counts): most of a row is padding, so most of the index writes go away.  cnt is required; nsample <= 256
+ * (the most slots per neighbourhood for which the grouped-MLP kernels honour the counts).                            */
 int mpx_ball_query_hits(const float *new_xyz, int new_stride, const float *xyz, int stride, int B,
                         int N, int npoint, float radius, int nsample, int32_t *idx, int32_t *cnt,
                         mpx_stream_t stream);
@@ -462,7 +470,8 @@ int mpx_append_columns(const float *src, int src_stride, int ncols, int nzero, i
  *   sa2_nb1 [128]        minus its bias
  *   sa3_w[0] [512,272]   group-all first layer, K padded 259 -> 272 with zero columns; sa3_w[1] [512,512];
  *                        sa3_w[2] [1024,512]; sa3_b[i] the biases (the layer-by-layer form: B < 256 problems)
- *   sa3_pack             the same three layers packed by mpx_sa3_pack_weights (the fused form: B >= 256)
+ *   sa3_pack             the same three layers packed by mpx_sa3_pack_weights (the fused form: B >= 256); NULL: the
+ *                        layer-by-layer form at every batch size (same results within rounding)
  *   fc_w / fc_b          1024 -> 4096 -> 2048 -> 2048; gn_g / gn_b: the two GroupNorm(16) affine vectors
  *   qe_w[0] [32,8]       joint encoder, first layer K padded 7 -> 8; then 32 -> 64 -> 128 -> 128 -> 64
  *   de_w / de_b          decoder 2112 -> 512 -> 256 -> 128 -> 7                                                  */
@@ -472,7 +481,7 @@ typedef struct mpx_policy_weights {
   const float *fc_w[3], *fc_b[3], *gn_g[2], *gn_b[2];
   const float *qe_w[5], *qe_b[5];
   const float *de_w[4], *de_b[4];
-  const float *sa3_pack; /* mpx_sa3_pack_weights of the group-all module (K1 = 272): the fused chain of B >= 256 problems */
+  const float *sa3_pack; /* mpx_sa3_pack_weights of the group-all module (K1 = 272): the fused chain of B >= 256 problems, or NULL */
 } mpx_policy_weights;
 
 /* bytes of 256-byte aligned device workspace a batch of B problems with N-point slabs needs */

@@ -640,11 +640,13 @@ static int opt_n_threads_log2(int n) {
 // query), variant 0 = the plain kernels they are proven against (fps_kernel, ball_query_kernel).  Both produce the same
 // indices bit for bit; the switch exists so that a test can run BOTH in one process on the same clouds
 // (tests/test_gpu_soak.py).  Process-wide, read at every launch.
-static std::atomic<int> g_variant[MPX_VARIANT_COUNT_] = {{1}, {1}};
+static std::atomic<int> g_variant[MPX_VARIANT_COUNT_] = {{1}, {1}, {1}};
 MPX_EXPORT int mpx_set_variant(int what, int value) {
   MPX_REQUIRE(what >= 0 && what < MPX_VARIANT_COUNT_, "mpx_set_variant: unknown selector %d", what);
   MPX_REQUIRE(value == 0 || value == 1, "mpx_set_variant: value must be 0 (plain kernels) or 1 (default)");
   g_variant[what].store(value, std::memory_order_relaxed);
+  // MPX_VARIANT_UNIT_QUEUE 0: streams not seen before get no unit-queue slot (as if all 256 were taken)
+  if (what == MPX_VARIANT_UNIT_QUEUE) mpx_unit_queue_set_slots(value ? 256 : 0);
   return 0;
 }
 MPX_EXPORT int mpx_get_variant(int what) {
@@ -1249,6 +1251,9 @@ MPX_EXPORT int mpx_ball_query_hits(const float *new_xyz, int new_stride, const f
                                    int npoint, float radius, int nsample, int32_t *idx, int32_t *cnt,
                                    mpx_stream_t stream) {
   MPX_REQUIRE(cnt != nullptr, "mpx_ball_query_hits: the hit counts are required (they say which slots were written)");
+  // (the grouped-MLP kernels honour `cnt` up to 256 slots per neighbourhood; above that mpx_sa_mlp walks every slot, and
+  // would read the slots this entry point leaves unwritten)
+  MPX_REQUIRE(nsample <= 256, "mpx_ball_query_hits: nsample = %d > 256 (use mpx_ball_query: full rows)", nsample);
   return ball_query_impl(new_xyz, new_stride, xyz, stride, B, N, npoint, radius, nsample, idx, cnt, 0, stream);
 }
 

@@ -249,8 +249,7 @@ MPX_EXPORT int mpx_policy_forward(const mpx_policy_weights *w, const float *xyz,
                               bu.sa3_in + 3, K3, stream));
   // ---- group-all module: B >= SA3_CHAIN_MIN_BATCH problems -> the fused chain (nothing between the rows and the pooled
   // row touches HBM); fewer: three dense layers over the B*128 rows, max over each environment's rows -------------------
-  if (B >= SA3_CHAIN_MIN_BATCH) {
-    MPX_REQUIRE(w->sa3_pack, "mpx_policy_forward: sa3_pack missing (mpx_sa3_pack_weights)");
+  if (B >= SA3_CHAIN_MIN_BATCH && w->sa3_pack) {  // (no pack: the layer-by-layer form below)
     MPX_TRY(mpx_sa3_chain(bu.sa3_in, K3, B, NP2, w->sa3_pack, K3, H3, H3, C3, bu.pooled, C3, stream));
   } else {
   MPX_TRY(lin(bu.sa3_in, K3, w->sa3_w[0], w->sa3_b[0], B * NP2, H3, K3, MPX_ACT_RELU, bu.h_a, H3));

@@ -518,8 +518,8 @@ class MotionPolicyNetwork(nn.Module):
                   "sa2_wpoint": wp, "sa2_wcentre": wc, "sa2_nb1": nb1,
                   "sa3_pack": enc._sa3_pack((3 + c2[-1].out_channels + 15) // 16 * 16)}
         w = self._NativeWeights()
-        for k, t in single.items():
-            setattr(w, k, t.data_ptr())
+        for k, t in single.items():  # (sa3_pack is None for widths the fused chain does not cover: NULL = layer by layer)
+            setattr(w, k, t.data_ptr() if t is not None else None)
         for k, ts in groups.items():
             setattr(w, k, (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts]))
         return w, (single, groups)
@@ -557,7 +557,12 @@ class MotionPolicyNetwork(nn.Module):
         self.point_cloud_encoder(xyz, out=cat[:, :2048], aux=aux, side_work=lambda: self.encode_configuration(q, out=cat[:, 2048:]))
         if aux is not None:
             aux["encoding"] = cat[:, :2048]
-        return self.decode(cat)
+        dq = self.decode(cat)
+        # every derived weight buffer this configuration needs now exists (built by launches on the current stream):
+        # rollout.PipelinedRollout compares this with cache_signature() to know whether its streams must be ordered
+        # around a rebuild
+        self._warm_signature = self.cache_signature()
+        return dq
 
     def encode_configuration(self, q: torch.Tensor, out: Optional[torch.Tensor] = None):
         """``feature_encoder`` (model.py:45-55): q [B,7] -> [B,64], written to ``out`` when given.  Returns the output

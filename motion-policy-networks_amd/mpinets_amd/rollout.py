@@ -280,13 +280,16 @@ class PipelinedRollout:
         # The shares use ONE model, whose derived weight buffers (MFMA-stream packs, factored SA2 weights, bf16 pairs,
         # padded first layers) are built lazily by kernels on the stream that first misses them -- share 0's.  The other
         # shares then hit the host-side cache and would read those buffers on their own streams with nothing ordering
-        # them after the build.  So whenever the model's cache signature is not the one this object last ran with (first
-        # use, optimizer step, set_precision, invalidate_caches ...), every other stream waits for share 0's first whole
-        # step of this call (the stagger is subsumed: a cold start is serialised for one step).
-        cold = model.cache_signature() != getattr(self, "_warm_signature", None)
+        # them after the build.  Warmth is tracked ON THE MODEL (``_warm_signature``: set by every inference forward,
+        # whose launches the streams above are ordered after): when the cache signature differs (first use, optimizer
+        # step, set_precision, invalidate_caches ...) every other stream waits for share 0's first whole step of this
+        # call.  The stagger -- share i+1 starts once share i has issued its sampling -- applies to the first step
+        # that is not serialised that way: step 0 on a warm model, step 1 after a cold start.
+        cold = model.cache_signature() != getattr(model, "_warm_signature", None)
+        stagger_at = (1 if cold else 0) if (self.stagger and self.steps_done == 0) else -1
         for t in range(steps):
             for i, (e, s) in enumerate(zip(self.engines, self.streams)):
-                first = self.stagger and not cold and t == 0 and self.steps_done == 0 and i + 1 < self.ways
+                first = t == stagger_at and i + 1 < self.ways
                 if first:  # share i+1 starts when share i has issued its sampling and entered its matrix kernels
                     ev = torch.cuda.Event()
                     enc.after_sampling = lambda ev=ev: ev.record()
@@ -300,7 +303,6 @@ class PipelinedRollout:
                     built.record(s)
                     for other in self.streams[1:]:
                         other.wait_event(built)
-        self._warm_signature = model.cache_signature()
         self.steps_done += steps
         for s in self.streams:
             cur.wait_stream(s)
@@ -349,8 +351,21 @@ def rollout_until_success(mdl: MotionPolicyNetwork, q0, target, point_cloud: tor
             "cuboid_quats": torch.tensor([[[1.0, 0, 0, 0]]], device=dev), "cylinder_centers": zeros(1, 1, 3),
             "cylinder_radii": zeros(1, 1, 1), "cylinder_heights": zeros(1, 1, 1),
             "cylinder_quats": torch.tensor([[[1.0, 0, 0, 0]]], device=dev)}
-    eng = RolloutEngine(mdl, prob, robot_subset=fk_sampler.draw_subset(2048))
+    eng = RolloutEngine(mdl, prob, robot_subset=torch.zeros(2048, dtype=torch.int32, device=dev))
     eng.sampler = fk_sampler
     eng.track_success(tm)
-    traj, lengths = eng.rollout_until_success(max_rollout_length, check_every=1)
-    return traj[0, : int(lengths[0])].cpu().numpy()
+    # The reference's loop (run_inference.py:171-189): forward, clamp, unnormalise, append, success test (one host
+    # synchronisation per step, like its .cpu() there), and only when the test fails a fresh robot cloud -- whose column
+    # subset robofin draws from np.random at every call.  The engine's step does the same work in one pass, so the
+    # subset of step i is drawn in front of it and the draw is undone when the step turns out to be the last one: the
+    # host RNG is left exactly where the reference leaves it.
+    traj = [eng.q_norm.new_tensor(np.asarray(q0, dtype=np.float32)).reshape(1, 7)]
+    for _ in range(max_rollout_length):
+        state, rows = np.random.get_state(), point_cloud[:, :2048, :3].clone()
+        eng.subset = fk_sampler.draw_subset(2048)
+        traj.append(eng.step().clone())
+        if bool(eng.done[0] != 0):  # (the reference breaks BEFORE it resamples: undo the draw and the cloud refresh)
+            np.random.set_state(state)
+            point_cloud[:, :2048, :3] = rows
+            break
+    return torch.cat(traj, dim=0).cpu().numpy()

@@ -50,7 +50,18 @@ def init(backend: Optional[str] = None, device: Optional[torch.device] = None) -
     force = os.environ.get("MPX_DIST_FORCE") == "1"
     if (ws > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
+        if "MASTER_PORT" not in os.environ:
+            # torchrun (and bench.py's own launcher) always export the port.  Without one, a single forced rank takes a
+            # free port of its own (two such processes on one box never collide on a fixed default); several ranks
+            # cannot each pick one, so that is an error rather than a guess.
+            if ws > 1:
+                raise RuntimeError("shard.init: WORLD_SIZE > 1 but MASTER_PORT is not set -- launch the ranks with "
+                                   "torch.distributed.run (or `python bench.py --gpus N`), which agree on a port")
+            import socket
+
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         kwargs = {}
         if backend == "nccl":
             kwargs["device_id"] = device
@@ -109,14 +120,20 @@ def max_over_ranks(value: float, device=None) -> float:
 
 
 def gather_to_rank0(t: torch.Tensor) -> Optional[torch.Tensor]:
-    """Final host gather: equal-shaped per-rank results -> concatenated on rank 0 (None elsewhere)."""
+    """Final host gather: per-rank results -> concatenated along dim 0 on rank 0 (None elsewhere).  The ranks' leading
+    dimensions may differ (``split_even`` shares of a strong-scaling run): shorter shares are padded for the collective
+    and trimmed afterwards."""
     if not dist.is_initialized():
         return t
     rank, ws = dist.get_rank(), dist.get_world_size()
     t = t.contiguous().to(_comm_device(t.device))
+    sizes = gather_objects(int(t.size(0)))
+    top = max(sizes)
+    if t.size(0) < top:
+        t = torch.cat((t, t.new_zeros((top - t.size(0),) + tuple(t.shape[1:]))), dim=0)
     bufs = [torch.empty_like(t) for _ in range(ws)] if rank == 0 else None
     dist.gather(t, bufs, dst=0)
-    return torch.cat(bufs, dim=0) if rank == 0 else None
+    return torch.cat([b[:n] for b, n in zip(bufs, sizes)], dim=0) if rank == 0 else None
 
 
 # ---- training only (row N1): the one collective of the code base ----------------------------------------

@@ -1,7 +1,9 @@
 /*
  * oracle/mpn_oracle.c -- TEST INFRASTRUCTURE ONLY.
  *
- * CPU restatement (plain C, scalar, single thread) of the hot path of
+ * CPU restatement (plain C, scalar arithmetic; the loops over independent environments are
+ * OpenMP-parallel so that bench.py's cpu_baseline can use every host core -- orc_set_threads;
+ * one thread gives the same bits) of the hot path of
  * NVlabs/motion-policy-networks.  Only tests/, __graft_entry__.smoke() and bench.py's
  * cpu_baseline leg may load this library, and only as the checker.  The product
  * (motion-policy-networks_amd/) never links, imports or calls anything in oracle/.
@@ -30,6 +32,28 @@
 #include <string.h>
 
 #define ORC_API __attribute__((visibility("default")))
+
+/* Environments never interact, so the loops over them (and over their points / queries) run in parallel; every output
+ * element is computed by exactly one iteration with the same scalar arithmetic: the results do not depend on the
+ * thread count.  Built without -fopenmp the pragmas vanish. */
+#ifdef _OPENMP
+#include <omp.h>
+#define ORC_PRAGMA(x) _Pragma(#x)
+#define ORC_PARALLEL_FOR ORC_PRAGMA(omp parallel for schedule(static))
+#define ORC_PARALLEL_FOR2 ORC_PRAGMA(omp parallel for collapse(2) schedule(static))
+#define ORC_PARALLEL ORC_PRAGMA(omp parallel)
+#define ORC_FOR ORC_PRAGMA(omp for schedule(dynamic, 1))
+ORC_API int orc_set_threads(int n) {
+  if (n > 0) omp_set_num_threads(n);
+  return omp_get_max_threads();
+}
+#else
+#define ORC_PARALLEL_FOR
+#define ORC_PARALLEL_FOR2
+#define ORC_PARALLEL
+#define ORC_FOR
+ORC_API int orc_set_threads(int n) { (void)n; return 1; }
+#endif
 
 /* ------------------------------------------------------------------------------------------
  * Primitive inverse frames.  Reference: mpinets/geometry.py:151 (quaternion normalisation),
@@ -108,6 +132,7 @@ ORC_API void orc_cuboid_sdf(int B, int M, int P, const float *centers, const flo
                             const float *quats, const float *points, float *out) {
   float *frames = (float *)malloc(sizeof(float) * 12 * (size_t)(B * M > 0 ? B * M : 1));
   orc_prim_frames(centers, quats, B * M, frames);
+  ORC_PARALLEL_FOR2
   for (int b = 0; b < B; ++b)
     for (int n = 0; n < P; ++n) {
       const float *p = points + ((size_t)b * P + n) * 3;
@@ -131,6 +156,7 @@ ORC_API void orc_cylinder_sdf(int B, int M, int P, const float *centers, const f
                               float *out) {
   float *frames = (float *)malloc(sizeof(float) * 12 * (size_t)(B * M > 0 ? B * M : 1));
   orc_prim_frames(centers, quats, B * M, frames);
+  ORC_PARALLEL_FOR2
   for (int b = 0; b < B; ++b)
     for (int n = 0; n < P; ++n) {
       const float *p = points + ((size_t)b * P + n) * 3;
@@ -151,6 +177,7 @@ ORC_API void orc_cylinder_sdf(int B, int M, int P, const float *centers, const f
 /* TorchSpheres.sdf / sdf_sequence (geometry.py:87-123). */
 ORC_API void orc_sphere_sdf(int B, int M, int P, const float *centers, const float *radii,
                             const float *points, float *out) {
+  ORC_PARALLEL_FOR2
   for (int b = 0; b < B; ++b)
     for (int n = 0; n < P; ++n) {
       const float *p = points + ((size_t)b * P + n) * 3;
@@ -252,6 +279,7 @@ ORC_API void orc_franka_fk(const float *q, int B, float finger, float *T) {
   static const float F_HAND[12] = {SQRT_HALF, SQRT_HALF, 0, -SQRT_HALF, SQRT_HALF, 0, 0, 0, 1, 0, 0, 0};
   static const float F_TIP[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0.0f, 0.0f, 0.045f};
   static const float F_GRIP[12] = {-SQRT_HALF, -SQRT_HALF, 0, SQRT_HALF, -SQRT_HALF, 0, 0, 0, 1, 0.0f, 0.0f, 0.1f};
+  ORC_PARALLEL_FOR
   for (int b = 0; b < B; ++b) {
     float *out = T + (size_t)b * 15 * 12;
     float cur[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0};
@@ -281,6 +309,7 @@ ORC_API void orc_franka_fk(const float *q, int B, float finger, float *T) {
 ORC_API void orc_transform_table(const float *T, int B, int n_frames, const float *pts,
                                  const int32_t *link, const int32_t *subset, int n_out,
                                  float *out) {
+  ORC_PARALLEL_FOR
   for (int b = 0; b < B; ++b)
     for (int j = 0; j < n_out; ++j) {
       int src = subset ? subset[j] : j;
@@ -308,6 +337,7 @@ ORC_API void orc_collision_flags(int B, int T, int S, const float *centres, cons
   float *c = (float *)malloc(sizeof(float) * (size_t)B * P);
   orc_cuboid_sdf(B, M1, P, cc, cd, cq, centres, a);
   orc_cylinder_sdf(B, M2, P, yc, yr, yh, yq, centres, c);
+  ORC_PARALLEL_FOR
   for (int b = 0; b < B; ++b) {
     uint8_t f = 0;
     for (int i = 0; i < P; ++i) {
@@ -358,9 +388,12 @@ static float sqdist(const float *a, const float *b) {
 ORC_API void orc_fps(const float *xyz, int B, int N, int stride, int npoint, int32_t *idx) {
   if (npoint <= 0) return;
   int bs = orc_opt_n_threads(N);
+  ORC_PARALLEL /* (environments are independent: one scratch set per thread) */
+  {
   float *temp = (float *)malloc(sizeof(float) * (size_t)N);
   float *tv = (float *)malloc(sizeof(float) * (size_t)bs);
   int *ti = (int *)malloc(sizeof(int) * (size_t)bs);
+  ORC_FOR
   for (int b = 0; b < B; ++b) {
     const float *pts = xyz + (size_t)b * N * stride;
     int32_t *out = idx + (size_t)b * npoint;
@@ -399,6 +432,7 @@ ORC_API void orc_fps(const float *xyz, int B, int N, int stride, int npoint, int
   free(temp);
   free(tv);
   free(ti);
+  }
 }
 
 /* gather_points_kernel, on [B,N,stride] rows: out[b,j,:3] = xyz[b,idx[b,j],:3] */
@@ -417,6 +451,7 @@ ORC_API void orc_ball_query(const float *new_xyz, const float *xyz, int B, int N
                             int npoint, float radius, int nsample, int32_t *idx, int32_t *cnt_out) {
   float r2 = radius * radius;
   memset(idx, 0, sizeof(int32_t) * (size_t)B * npoint * nsample);
+  ORC_PARALLEL_FOR2
   for (int b = 0; b < B; ++b)
     for (int j = 0; j < npoint; ++j) {
       const float *c = new_xyz + ((size_t)b * npoint + j) * 3;
@@ -444,6 +479,7 @@ ORC_API void orc_group_points(const float *xyz, int stride, const float *new_xyz
                               const float *feat, const int32_t *idx, int B, int N, int C,
                               int npoint, int nsample, float *out) {
   size_t plane = (size_t)npoint * nsample;
+  ORC_PARALLEL_FOR2
   for (int b = 0; b < B; ++b)
     for (int j = 0; j < npoint; ++j)
       for (int l = 0; l < nsample; ++l) {

@@ -45,6 +45,12 @@ def lib() -> ctypes.CDLL:
     return _lib
 
 
+def set_threads(n: int = 0) -> int:
+    """OpenMP threads of the C restatement's per-environment loops (0 = leave as is).  Returns the count in effect.
+    Results do not depend on it; bench.py's cpu_baseline sets it to the host's core count and reports it."""
+    return int(lib().orc_set_threads(int(n)))
+
+
 def _f(a) -> np.ndarray:
     return np.ascontiguousarray(a, dtype=np.float32)
 
@@ -505,10 +511,12 @@ def _group_norm(x, groups, w, b, eps=1e-5):
 
 def shared_mlp(x, layers: Sequence[Tuple[np.ndarray, np.ndarray]]) -> np.ndarray:
     """x [..., Cin] -> [..., Cout]; Conv2d 1x1 + ReLU per layer (bn=False)."""
+    lead = x.shape[:-1]
+    x = x.reshape(-1, x.shape[-1])  # one large product per layer (the BLAS pool sees the whole row count)
     for w, b in layers:
         w2 = w.reshape(w.shape[0], -1)
         x = np.maximum(_linear(x, w2, b), 0).astype(np.float32)
-    return x
+    return x.reshape(lead + (x.shape[-1],))
 
 
 def sa_module(xyz, feat, npoint, radius, nsample, layers):

@@ -130,3 +130,67 @@ def test_scene_cloud_odd_sizes(oracle):
     opts, oassign, olabels, onobs = oracle.scene_cloud(scn, 1001, 99)
     np.testing.assert_array_equal(assign.cpu().numpy().view(np.uint16), oassign)
     np.testing.assert_allclose(out.cpu().numpy(), opts, atol=1e-6)
+
+
+def test_stream_without_a_unit_queue_slot_never_shares_one():
+    """MPX_VARIANT_UNIT_QUEUE = 0 stands in for "256 distinct streams already seen": a NEW stream gets no counters.  The
+    fp32 grouped MLPs then run one unit per wave without a queue -- bit-identical output -- and the bf16x3 persistent
+    kernel, which cannot run without one, reports it instead of sharing another stream's counters (round-3 advisor)."""
+    from mpinets_amd import _lib
+    from mpinets_amd.model import MotionPolicyNetwork
+    from mpinets_amd.scenes import make_problem_batch
+
+    lib = _lib.load()
+    torch.manual_seed(3)
+    mdl = MotionPolicyNetwork().to(dev()).eval()
+    prob = make_problem_batch(640, seed=4, device=dev(), scene_pool=8)  # (>= 4 units per wave slot: the persistent launches)
+    with torch.no_grad():
+        ref = mdl(prob["xyz"], prob["q_norm"])
+        torch.cuda.synchronize()
+        assert lib.mpx_set_variant(2, 0) == 0 and lib.mpx_get_variant(2) == 0
+        try:
+            fresh = torch.cuda.Stream(device=dev())
+            with torch.cuda.stream(fresh):
+                got = mdl(prob["xyz"], prob["q_norm"])
+                mdl.set_precision("bf16x3")
+                with pytest.raises(_lib.MpxError, match="no unit-queue slot"):
+                    mdl(prob["xyz"], prob["q_norm"])
+            fresh.synchronize()
+        finally:
+            mdl.set_precision("fp32")
+            assert lib.mpx_set_variant(2, 1) == 0
+    assert torch.equal(got, ref)
+
+
+def test_ball_query_hits_rejects_rows_longer_than_the_counts_are_honoured():
+    from mpinets_amd import _lib
+
+    x = torch.zeros(1, 600, 3, device=dev())
+    idx = torch.empty((1, 4, 288), dtype=torch.int32, device=dev())
+    cnt = torch.empty((1, 4), dtype=torch.int32, device=dev())
+    with pytest.raises(_lib.MpxError, match="nsample = 288 > 256"):
+        _lib.call("mpx_ball_query_hits", _lib.ptr(x), 3, _lib.ptr(x), 3, 1, 600, 4, 0.1, 288, _lib.ptr(idx), _lib.ptr(cnt))
+
+
+def test_policy_forward_without_the_group_all_pack():
+    """struct mpx_policy_weights.sa3_pack = NULL: the layer-by-layer group-all module at every batch size."""
+    import ctypes
+
+    from mpinets_amd import _lib
+    from mpinets_amd.model import MotionPolicyNetwork
+    from mpinets_amd.scenes import make_problem_batch
+
+    torch.manual_seed(5)
+    mdl = MotionPolicyNetwork().to(dev()).eval()
+    prob = make_problem_batch(256, seed=6, device=dev(), scene_pool=4)
+    xyz, q = prob["xyz"], prob["q_norm"]
+    with torch.no_grad():
+        ref = mdl.forward_native(xyz, q)
+        w, keep = mdl.native_weights()
+        w.sa3_pack = None
+        need = _lib.load().mpx_policy_workspace(256, xyz.size(1))
+        ws = torch.empty(need, dtype=torch.uint8, device=dev())
+        dq = torch.empty((256, 7), dtype=torch.float32, device=dev())
+        _lib.call("mpx_policy_forward", ctypes.addressof(w), _lib.ptr(xyz), xyz.size(1), _lib.ptr(q), 256, _lib.ptr(dq),
+                  _lib.ptr(ws), need)
+    assert (dq - ref).abs().max().item() <= 1e-6

@@ -168,6 +168,56 @@ def test_bench_distributed_path_on_a_real_rccl_communicator():
     assert out["fast_mode"]["value"] > 0
 
 
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_two_ranks_report_sharded_extras_and_both_scalings(scaling):
+    """`python bench.py --gpus 2` starts its own two ranks (free port); on this one-GPU box they share the device over
+    gloo (MPX_SHARE_GPU=1, the JSON says so).  Checks the N-rank fields of the line: config 3's trajectories split over
+    the ranks with per-rank times, config 1 on every rank, the data-parallel training step, strong / weak accounting.
+    BASELINE configs[3] ("sharded"), model.py:293-314."""
+    import json
+
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, MPX_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("MPX_DIST_BACKEND", "MPX_DIST_FORCE", "WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--scaling", scaling, "--envs", "520", "--global-envs",
+           "1041", "--steps", "1", "--warmup", "1", "--fast-steps", "0", "--pipeline-steps", "0", "--static-steps", "0",
+           "--all-slots-steps", "0", "--train-steps", "1", "--cpu-envs", "0", "--scene-pool", "32"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["scaling"] == scaling and out["dist_backend"] == "gloo" and out["rccl_ranks"] == 0
+    assert out["config"]["devices_shared"] is True
+    ids = [rec["env_ids"] for rec in out["ranks"]]
+    if scaling == "weak":
+        assert ids == [[0, 520], [520, 1040]] and out["config"]["global_envs"] == 1040
+    else:  # 1041 environments over two ranks: 521 + 520
+        assert ids == [[0, 521], [521, 1041]] and out["config"]["global_envs"] == 1041
+    assert abs(out["value"] - out["config"]["global_envs"] * out["steps"] / (out["ms_per_step"] * out["steps"] * 1e-3)) < 1e-6 * out["value"]
+    assert out["result_check"]["gathered_q"] == [out["config"]["global_envs"], 7]
+    assert "frac_nominal" in out["roofline"] and out["roofline"]["frac_nominal"] > out["roofline"]["frac"] > 0
+    c4 = out["extra_configs"]["c4_collision_validation"]
+    assert len(c4["ms_per_rank"]) == 2 and c4["envs"] == sum(c4["envs_per_rank"]) and min(c4["envs_per_rank"]) >= 520
+    assert c4["ms"] == max(c4["ms_per_rank"]) and abs(c4["env_waypoints_per_s"] - c4["envs"] * 50 / c4["ms"] * 1e3) < 1e-6 * c4["env_waypoints_per_s"]
+    assert 0.0 <= c4["collision_rate"] <= 1.0
+    c2 = out["extra_configs"]["c2_fk_sdf_1024"]
+    assert len(c2["ms_per_rank"]) == 2 and c2["envs"] == sum(c2["envs_per_rank"])
+    tr = out["extra_configs"]["n1_training_step"]
+    assert tr["allreduce_ranks"] == 2 and tr["batch_10"]["samples_per_gpu"] == 10 and tr["batch_10"]["samples_per_s"] > 0
+    assert np.isfinite(tr["batch_256"]["loss"])
+    assert out["extra_configs"]["c1_single_problem"]["ms_per_step"] > 0  # (rank 0 alone, after the others were released)
+
+
+def test_shard_init_takes_a_free_port_for_a_forced_single_rank(monkeypatch):
+    from mpinets_amd import shard
+
+    monkeypatch.delenv("MASTER_PORT", raising=False)
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.setenv("RANK", "0")
+    with pytest.raises(RuntimeError, match="MASTER_PORT is not set"):
+        shard.init(backend="gloo")
+
+
 def test_shard_init_device_defaults(monkeypatch):
     """shard.init(): a gloo rank whose LOCAL_RANK exceeds the device count shares a GPU (device = LOCAL_RANK mod count);
     an RCCL rank in the same position fails with a clear message instead of 'invalid device ordinal'."""

@@ -16,14 +16,15 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, envs_per_rank, out_dir):
+def _worker(rank, world, port, envs_per_rank, out_dir, strong_total=0):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
     from mpinets_amd import shard
 
     r, w, _ = shard.init(backend="gloo")
     assert (r, w) == (rank, world)
-    ids = shard.env_range(r, w, envs_per_rank)
+    # weak scaling: equal shares; strong scaling: split_even shares of a fixed total, which may differ by one
+    ids = shard.split_even(strong_total, w)[r] if strong_total else shard.env_range(r, w, envs_per_rank)
     # stand-in for the per-rank rollout result: a deterministic function of the GLOBAL env id
     q = torch.tensor([[float(i) + 0.1 * j for j in range(7)] for i in ids])
     flags = torch.tensor([i % 3 == 0 for i in ids], dtype=torch.int32)
@@ -47,6 +48,17 @@ def test_two_rank_shard_equals_single_rank(tmp_path):
     q = np.load(tmp_path / "q.npy")
     f = np.load(tmp_path / "f.npy")
     ids = np.arange(world * per_rank)
+    np.testing.assert_allclose(q, ids[:, None] + 0.1 * np.arange(7)[None], rtol=1e-6)
+    np.testing.assert_array_equal(f, (ids % 3 == 0).astype(np.int32))
+
+
+def test_strong_scaling_shares_of_unequal_size_gather_in_order(tmp_path):
+    """bench.py --scaling strong: 11 environments over 2 ranks = 6 + 5; the final gather pads and trims."""
+    world, total = 2, 11
+    mp.spawn(_worker, args=(world, _free_port(), 0, str(tmp_path), total), nprocs=world, join=True)
+    q, f = np.load(tmp_path / "q.npy"), np.load(tmp_path / "f.npy")
+    ids = np.arange(total)
+    assert q.shape == (total, 7) and f.shape == (total,)
     np.testing.assert_allclose(q, ids[:, None] + 0.1 * np.arange(7)[None], rtol=1e-6)
     np.testing.assert_array_equal(f, (ids % 3 == 0).astype(np.int32))
 
