@@ -187,14 +187,28 @@ __global__ void __launch_bounds__(256)
 
 // Per-environment form (the default whenever M1, M2 <= 64): a workgroup owns ONE environment and a chunk of up to
 // COL_TC of its waypoints, so everything that depends on the environment alone is done once:
-//   * the zero-volume masks of its primitives become two 64-bit wave-uniform words (a ballot over lanes = primitives);
-//     the evaluation loops walk the SET bits only (s_ff1 / clear lowest bit), and an unmasked primitive's frame and
-//     sizes arrive through scalar loads as SGPR operands -- a masked row costs nothing, not even a compare;
+//   * the zero-volume masks of its primitives become two 64-bit wave-uniform words (a ballot over lanes = primitives)
+//     and the live primitives are compacted into LDS rows: the evaluation loops walk live rows only;
 //   * FK runs once per waypoint (lanes of the first wave), frames parked in LDS;
-//   * the (waypoint, sphere) pairs of the chunk are FLATTENED over the lanes: 50 x 56 pairs fill 43.75 waves instead
-//     of 50 waves that each idle 8 of 64 lanes.
-// Arithmetic per (sphere, primitive) and the order of the minima are those of franka_collision_kernel: bit-identical.
-template <int BLOCK, int COL_TC>
+//   * the (waypoint, sphere) pairs of the chunk are FLATTENED over the lanes (50 x 56 pairs fill 43.75 waves instead of
+//     50 waves that each idle 8 of 64 lanes) and a thread keeps ALL its pairs (<= PPT sphere centres) in registers: the
+//     loops run primitive-outer, pair-inner, so a primitive's frame and half sizes are fetched ONCE per wave (four
+//     broadcast LDS reads of its compacted row) and feed PPT independent chains;
+//   * no square root per (sphere, primitive): with d_i = |p_i| - h_i, a primitive's distance is
+//     sqrt(sum max(d_i, 0)^2) + min(max_i d_i, 0), where at most one term is non-zero.  The correctly rounded sqrt is
+//     monotone, so  min over primitives = sqrt(min of the sums) + min(min of the max_i d_i, 0)  EXACTLY (an inside
+//     primitive zeroes the first term and makes the second the answer; with none inside the second term is 0): the
+//     loop tracks two minima (2 v_min) and the sqrt runs once per sphere.  Same for cylinders (their inner rho sqrt
+//     stays).  Results are bit-identical to franka_collision_kernel / oracle orc_collision_flags.
+// VALU per (sphere, cuboid): projection 12 + 3 |p| - h + max3 + 3 max + 3 (sum of squares) + 2 min = 24 (was ~45 with the
+// sqrt expansion, the halvings and the compare-selects inside); 18 with two pairs per packed-fp32 instruction (below).
+#ifndef MPX_COL_PACK
+#define MPX_COL_PACK 0  // 1: two pairs per packed-fp32 instruction (v_pk_fma_f32 ...) -- measured: no faster (see below)
+#endif
+#ifndef MPX_COL_TC
+#define MPX_COL_TC 64  // waypoints per workgroup of the swept-sphere check (A/B: tools/ab_build.sh)
+#endif
+template <int BLOCK, int COL_TC, int PPT>
 __global__ void __launch_bounds__(BLOCK)
     franka_collision_env_kernel(const float *__restrict__ q, int T, int chunks, float finger, const float *__restrict__ sc,
                                 const float *__restrict__ sr, const int32_t *__restrict__ sl, int S,
@@ -202,7 +216,9 @@ __global__ void __launch_bounds__(BLOCK)
                                 const float *__restrict__ cyl_f, const float *__restrict__ cyl_r,
                                 const float *__restrict__ cyl_h, int M2, int32_t *__restrict__ flags,
                                 float *__restrict__ min_sdf) {
-  extern __shared__ float lds[];  // nt x FRAME_FLOATS
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // [128 primitive rows x 16 floats | nt x FRAME_FLOATS]
+  float4 *prim_rows = reinterpret_cast<float4 *>(lds);         // live cuboids from row 0, live cylinders from row 64
+  float *frames = lds + 128 * 16;
   const int b = blockIdx.x / chunks, t0 = (blockIdx.x - b * chunks) * COL_TC;  // (block-uniform)
   const int nt = min(COL_TC, T - t0);
   const int lane = threadIdx.x & 63;
@@ -210,47 +226,168 @@ __global__ void __launch_bounds__(BLOCK)
     float qq[7];
 #pragma unroll
     for (int j = 0; j < 7; ++j) qq[j] = q[((size_t)b * T + t0 + threadIdx.x) * 7 + j];
-    franka_fk_frames(qq, finger, lds + threadIdx.x * FRAME_FLOATS);
+    franka_fk_frames(qq, finger, frames + threadIdx.x * FRAME_FLOATS);
   }
+  // live primitives, COMPACTED into LDS rows [R (3 x 4 floats: rotation row | Rt) | half sizes]: lane m of the staging
+  // wave tests primitive m, a live one takes the slot = number of live ones before it.  The evaluation loops below read
+  // a row with four broadcast ds_read_b128 (every lane the same address) -- a masked primitive costs nothing at all.
+  // Staging runs on the LAST waves of the workgroup (the first one is busy with FK).
   const float *cf = cub_f + (size_t)b * M1 * 16;
   const float *cd = cub_d + (size_t)b * M1 * 3;
   const float *yf = cyl_f + (size_t)b * M2 * 16;
   const float *yr = cyl_r + (size_t)b * M2;
   const float *yh = cyl_h + (size_t)b * M2;
-  // live-primitive masks: lane m tests primitive m (every wave computes the same two words)
   bool clive = false, ylive = false;
-  if (lane < M1) clive = !(mpx_is_zero(cd[3 * lane + 0]) || mpx_is_zero(cd[3 * lane + 1]) || mpx_is_zero(cd[3 * lane + 2]));
-  if (lane < M2) ylive = !(mpx_is_zero(yr[lane]) || mpx_is_zero(yh[lane]));
+  float c0 = 0.0f, c1 = 0.0f, c2 = 0.0f, r0 = 0.0f, h0 = 0.0f;
+  if (lane < M1) {
+    c0 = cd[3 * lane + 0], c1 = cd[3 * lane + 1], c2 = cd[3 * lane + 2];
+    clive = !(mpx_is_zero(c0) || mpx_is_zero(c1) || mpx_is_zero(c2));
+  }
+  if (lane < M2) {
+    r0 = yr[lane], h0 = yh[lane];
+    ylive = !(mpx_is_zero(r0) || mpx_is_zero(h0));
+  }
   const unsigned long long cmask = __builtin_amdgcn_ballot_w64(clive), ymask = __builtin_amdgcn_ballot_w64(ylive);
+  const int n_cub = __builtin_popcountll(cmask), n_cyl = __builtin_popcountll(ymask);  // (every wave: the same counts)
+  const unsigned long long below = ((unsigned long long)1 << lane) - 1;
+  constexpr int CUB_WAVE = BLOCK / 64 - 1, CYL_WAVE = BLOCK >= 128 ? BLOCK / 64 - 2 : 0;
+  const int wave = (int)threadIdx.x >> 6;
+  if (wave == CUB_WAVE && clive) {
+    float4 *dst = prim_rows + 4 * __builtin_popcountll(cmask & below);
+    const float4 *src = reinterpret_cast<const float4 *>(cf + 16 * lane);
+    dst[0] = src[0], dst[1] = src[1], dst[2] = src[2];
+    dst[3] = make_float4(c0 / 2.0f, c1 / 2.0f, c2 / 2.0f, 0.0f);  // geometry.py:276
+  }
+  if (wave == CYL_WAVE && ylive) {
+    float4 *dst = prim_rows + 4 * (64 + __builtin_popcountll(ymask & below));
+    const float4 *src = reinterpret_cast<const float4 *>(yf + 16 * lane);
+    dst[0] = src[0], dst[1] = src[1], dst[2] = src[2];
+    dst[3] = make_float4(r0, h0 / 2.0f, 0.0f, 0.0f);  // geometry.py:489
+  }
   __syncthreads();
   const int npairs = nt * S;
-  const int dq = BLOCK / S, dr = BLOCK - dq * S;  // a step of BLOCK pairs = dq waypoints + dr spheres
-  int t = (int)threadIdx.x / S, s = (int)threadIdx.x - t * S;
+  // pairs of this thread: p = threadIdx.x + k * BLOCK, k < PPT (the launcher picks PPT = the chunk's pairs / BLOCK, rounded
+  // up to even: straight-line code, no per-pair branches; pairs past the end repeat pair 0 and are not stored)
+  // What bounds the kernel: a wave64 VALU instruction occupies its SIMD for 4 cycles, and SQ_ACTIVE_INST_VALU x 4 is
+  // 98 % of the kernel's cycles (profiles/r04_collision_pmc_pass1.csv) -- VALU ISSUE, so only fewer instructions help.
+  // The vector type below can hold TWO pairs per register pair (MPX_COL_PACK=1: the projection, the subtraction and the
+  // sum of squares become v_pk_mul / v_pk_fma / v_pk_add_f32, 18 instead of 24 instructions per (sphere, cuboid), same
+  // IEEE results per element): measured 0.322 vs 0.316 ms -- a packed fp32 instruction costs two issue slots' worth of
+  // time on this chip, so the default stays one pair per instruction (profiles/r04_other_measurements.md).
+  constexpr int W = (MPX_COL_PACK && PPT % 2 == 0) ? 2 : 1, NV = PPT / W;
+  typedef float vec __attribute__((ext_vector_type(W)));
+  vec x[NV], y[NV], z[NV], ssc[NV], dc[NV], ssy[NV], dy[NV];
+  {
+    const int dq = BLOCK / S, dr = BLOCK - dq * S;  // a step of BLOCK pairs = dq waypoints + dr spheres
+    int tt = (int)threadIdx.x / S, ss = (int)threadIdx.x - tt * S;
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+      ssc[k / W][k % W] = dc[k / W][k % W] = ssy[k / W][k % W] = dy[k / W][k % W] = __builtin_inff();
+      x[k / W][k % W] = y[k / W][k % W] = z[k / W][k % W] = 0.0f;
+      {
+        const bool on = (int)threadIdx.x + k * BLOCK < npairs;
+        const int t1 = on ? tt : 0, s1 = on ? ss : 0;
+        float ox, oy, oz;
+        rigid_apply(frames + t1 * FRAME_FLOATS + 12 * sl[s1], sc[3 * s1 + 0], sc[3 * s1 + 1], sc[3 * s1 + 2], ox, oy, oz);
+        x[k / W][k % W] = ox, y[k / W][k % W] = oy, z[k / W][k % W] = oz;
+      }
+      tt += dq, ss += dr;
+      if (ss >= S) ss -= S, ++tt;
+    }
+  }
+  auto vfma = [](vec a, vec b, vec c) __attribute__((always_inline)) { return __builtin_elementwise_fma(a, b, c); };
+  auto vabs = [](vec a) __attribute__((always_inline)) { return __builtin_elementwise_abs(a); };
+  auto vmax = [](vec a, vec b) __attribute__((always_inline)) { return __builtin_elementwise_max(a, b); };
+  auto vmin = [](vec a, vec b) __attribute__((always_inline)) { return __builtin_elementwise_min(a, b); };
+  // mpx_project (sdf_device.h), element-wise on the packed pairs: the same operations in the same order
+  struct Frame {
+    vec r[12];
+  };
+  auto splat = [](const float4 &f0, const float4 &f1, const float4 &f2) __attribute__((always_inline)) {
+    Frame f;
+    f.r[0] = (vec)f0.x, f.r[1] = (vec)f0.y, f.r[2] = (vec)f0.z, f.r[3] = (vec)f0.w;
+    f.r[4] = (vec)f1.x, f.r[5] = (vec)f1.y, f.r[6] = (vec)f1.z, f.r[7] = (vec)f1.w;
+    f.r[8] = (vec)f2.x, f.r[9] = (vec)f2.y, f.r[10] = (vec)f2.z, f.r[11] = (vec)f2.w;
+    return f;
+  };
+  auto project = [&](const Frame &f, vec vx, vec vy, vec vz, vec &px, vec &py, vec &pz) __attribute__((always_inline)) {
+    px = vfma(f.r[2], vz, vfma(f.r[1], vy, f.r[0] * vx)) + f.r[3];
+    py = vfma(f.r[6], vz, vfma(f.r[5], vy, f.r[4] * vx)) + f.r[7];
+    pz = vfma(f.r[10], vz, vfma(f.r[9], vy, f.r[8] * vx)) + f.r[11];
+  };
+  const vec zero = (vec)0.0f;
+  for (int i = 0; i < n_cub; ++i) {
+    const float4 hs = prim_rows[4 * i + 3];
+    const Frame f = splat(prim_rows[4 * i + 0], prim_rows[4 * i + 1], prim_rows[4 * i + 2]);
+    const vec hx = (vec)hs.x, hy = (vec)hs.y, hz = (vec)hs.z;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        vec px, py, pz;
+        project(f, x[v], y[v], z[v], px, py, pz);
+        const vec d0 = vabs(px) - hx, d1 = vabs(py) - hy, d2 = vabs(pz) - hz;
+        const vec m0 = vmax(d0, zero), m1 = vmax(d1, zero), m2 = vmax(d2, zero);
+        ssc[v] = vmin(ssc[v], vfma(m2, m2, vfma(m1, m1, m0 * m0)));
+        dc[v] = vmin(dc[v], vmax(d0, vmax(d1, d2)));
+      }
+  }
+  for (int i = 0; i < n_cyl; ++i) {
+    const float4 hs = prim_rows[4 * (64 + i) + 3];
+    const Frame f = splat(prim_rows[4 * (64 + i) + 0], prim_rows[4 * (64 + i) + 1], prim_rows[4 * (64 + i) + 2]);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        vec px, py, pz, rho;
+        project(f, x[v], y[v], z[v], px, py, pz);
+        const vec r2 = vfma(py, py, px * px);
+#pragma unroll
+        for (int e = 0; e < W; ++e) rho[e] = sqrtf(r2[e]);
+        const vec d0 = vabs(rho) - (vec)hs.x, d1 = vabs(pz) - (vec)hs.y;
+        const vec m0 = vmax(d0, zero), m1 = vmax(d1, zero);
+        ssy[v] = vmin(ssy[v], vfma(m1, m1, m0 * m0));
+        dy[v] = vmin(dy[v], vmax(d0, d1));
+      }
+  }
   bool any_hit = false;
-  for (int p0 = 0; p0 < npairs; p0 += BLOCK) {  // (block-uniform trip count)
-    const bool on = p0 + (int)threadIdx.x < npairs;
-    const int tt = on ? t : 0, ss = on ? s : 0;
-    float x, y, z;
-    rigid_apply(lds + tt * FRAME_FLOATS + 12 * sl[ss], sc[3 * ss + 0], sc[3 * ss + 1], sc[3 * ss + 2], x, y, z);
-    float best = __builtin_inff();
-    for (unsigned long long m = cmask; m; m &= m - 1) {
-      const int i = __builtin_ctzll(m);  // wave-uniform: the frame and the sizes are scalar loads
-      const float v = cuboid_sdf_live(cf + 16 * i, cd[3 * i + 0], cd[3 * i + 1], cd[3 * i + 2], x, y, z);
-      best = v < best ? v : best;
+  bool exact = min_sdf != nullptr;  // (block-uniform)
+  if (!exact) {
+    // Flags only (the validation sweep): `sqrt(ss) + min(d, 0) <= r` without the square root.  With d <= 0 the value IS
+    // d; otherwise it is sqrt(ss), and for r >= 0  ss < r^2 (1 - 2e-6) => sqrt(ss) < r,  ss > r^2 (1 + 2e-6) => sqrt(ss) > r
+    // (the margins are 16 x the rounding of the products and of a correctly rounded sqrt).  A lane whose ss falls
+    // BETWEEN the two bounds (or whose radius is negative) sends its wave through the exact branch below -- same flags
+    // either way, the bounds only decide which arithmetic produces them.
+    const int dq = BLOCK / S, dr = BLOCK - dq * S;
+    int tt = (int)threadIdx.x / S, ss = (int)threadIdx.x - tt * S;
+    bool unsure = false;
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+      if ((int)threadIdx.x + k * BLOCK < npairs) {
+        const float r = sr[ss], r2 = r * r, lo = r2 * 0.999998f, hi = r2 * 1.000002f;
+        const float sc_ = ssc[k / W][k % W], dc_ = dc[k / W][k % W], sy_ = ssy[k / W][k % W], dy_ = dy[k / W][k % W];
+        const bool cin = dc_ <= 0.0f, yin = dy_ <= 0.0f;
+        any_hit |= (cin ? dc_ <= r : sc_ < lo) | (yin ? dy_ <= r : sy_ < lo);
+        unsure |= (r < 0.0f) | (!cin & (sc_ >= lo) & (sc_ <= hi)) | (!yin & (sy_ >= lo) & (sy_ <= hi));
+      }
+      ss += dr, tt += dq;
+      if (ss >= S) ss -= S, ++tt;
     }
-    float besty = __builtin_inff();
-    for (unsigned long long m = ymask; m; m &= m - 1) {
-      const int i = __builtin_ctzll(m);
-      const float v = cylinder_sdf_live(yf + 16 * i, yr[i], yh[i], x, y, z);
-      besty = v < besty ? v : besty;
+    exact = __any(unsure);
+    if (exact) any_hit = false;
+  }
+  if (exact) {
+    const int dq = BLOCK / S, dr = BLOCK - dq * S;
+    int tt = (int)threadIdx.x / S, ss = (int)threadIdx.x - tt * S;
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+      if ((int)threadIdx.x + k * BLOCK < npairs) {
+        const float cub = sqrtf(ssc[k / W][k % W]) + fminf(dc[k / W][k % W], 0.0f);  // = min over the live cuboids (none: +inf)
+        // (no live cylinder in this environment -- block-uniform, two environments in three: +inf without the sqrt)
+        const float cyl = n_cyl ? sqrtf(ssy[k / W][k % W]) + fminf(dy[k / W][k % W], 0.0f) : __builtin_inff();
+        const float best = fminf(cub, cyl);  // torch.minimum(cuboids, cylinders), model.py:304-307
+        if (min_sdf) min_sdf[((size_t)b * T + t0 + tt) * S + ss] = best;
+        any_hit |= best <= sr[ss];  // model.py:309-311
+      }
+      tt += dq, ss += dr;
+      if (ss >= S) ss -= S, ++tt;
     }
-    best = fminf(best, besty);  // torch.minimum(cuboids, cylinders), model.py:304-307
-    if (on) {
-      if (min_sdf) min_sdf[((size_t)b * T + t0 + tt) * S + ss] = best;
-      any_hit |= best <= sr[ss];  // model.py:309-311
-    }
-    t += dq, s += dr;
-    if (s >= S) s -= S, ++t;
   }
   if (__any(any_hit) && lane == 0) atomicOr(flags + b, 1);
 }
@@ -265,19 +402,32 @@ MPX_EXPORT int mpx_franka_collision(const float *q, int B, int T, float finger, 
   MPX_REQUIRE((int64_t)B * T < (int64_t)1 << 31, "mpx_franka_collision: B*T overflows int32");
   if (B == 0 || T == 0 || S == 0) return 0;
   if (M1 <= 64 && M2 <= 64 && S <= 64) {  // per-environment form: masks in two scalar words, pairs flattened over the lanes
-#define COL_ENV(BLOCK, TC)                                                                                             \
+#define COL_ENV(BLOCK, TC, PPT)                                                                                        \
   do {                                                                                                                 \
     const int chunks = cdiv(T, TC);                                                                                    \
     MPX_REQUIRE((int64_t)B * chunks < (int64_t)1 << 31, "mpx_franka_collision: too many workgroups");                  \
-    hipLaunchKernelGGL((franka_collision_env_kernel<BLOCK, TC>), dim3((unsigned)(B * chunks)), dim3(BLOCK),            \
-                       (size_t)min(T, TC) * FRAME_FLOATS * sizeof(float), mpx_s(stream), q, T, chunks, finger,         \
+    hipLaunchKernelGGL((franka_collision_env_kernel<BLOCK, TC, PPT>),                                                  \
+                       dim3((unsigned)(B * chunks)), dim3(BLOCK),                                                      \
+                       (size_t)(128 * 16 + min(T, TC) * FRAME_FLOATS) * sizeof(float), mpx_s(stream), q, T, chunks, finger,         \
                        sph_centers, sph_radii, sph_link, S, cub_frames, cub_dims, M1, cyl_frames, cyl_radii,           \
                        cyl_heights, M2, flags, min_sdf);                                                               \
   } while (0)
     // (waypoints per workgroup, measured at 8192 x 50: 64 -> 0.486 ms, 32 -> 0.508, 16 -> 0.570; one- and two-wave
     // workgroups with 16 / 32 waypoints 0.735 / 0.673: FK runs once per chunk on as many lanes as the chunk has waypoints)
-    if (T * S <= 64) COL_ENV(64, 64);  // one waypoint (the rollout step): one wave per environment
-    else COL_ENV(256, 64);
+    // (round 4, pairs in registers: MPX_COL_TC waypoints x <= 64 spheres over 256 threads = MPX_COL_TC / 4 pairs per thread)
+    if (T * S <= 64) COL_ENV(64, 64, 1);  // one waypoint (the rollout step): one wave per environment, one pair per lane
+    else {
+      switch ((min(T, MPX_COL_TC) * S + 511) / 512) {  // packed pairs per thread of a full chunk
+        case 1: COL_ENV(256, MPX_COL_TC, 2); break;
+        case 2: COL_ENV(256, MPX_COL_TC, 4); break;
+        case 3: COL_ENV(256, MPX_COL_TC, 6); break;
+        case 4: COL_ENV(256, MPX_COL_TC, 8); break;
+        case 5: COL_ENV(256, MPX_COL_TC, 10); break;
+        case 6: COL_ENV(256, MPX_COL_TC, 12); break;
+        case 7: COL_ENV(256, MPX_COL_TC, 14); break;
+        default: COL_ENV(256, MPX_COL_TC, 16); break;
+      }
+    }
 #undef COL_ENV
     MPX_LAUNCH_CHECK("mpx_franka_collision");
   }

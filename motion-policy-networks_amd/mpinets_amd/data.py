@@ -107,10 +107,13 @@ class PointCloudBase:
 
     @torch.no_grad()
     def get_inputs_batch(self, trajectory_idx: torch.Tensor, timestep: Optional[torch.Tensor],
-                         with_supervision: bool, seed: Optional[int] = None, sample_offset: int = 0) -> Dict[str, torch.Tensor]:
+                         with_supervision: bool, seed: Optional[int] = None, sample_offset: int = 0,
+                         robot_subset: Optional[torch.Tensor] = None,
+                         target_subset: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
         """Batched ``get_inputs`` (+ the supervision row of ``PointCloudInstanceDataset.__getitem__``).  Every random
         draw of row b is keyed by (seed, ``sample_offset + b``): a rank holding rows [o, o+n) of a global batch passes
-        ``sample_offset=o`` and draws what a single process would."""
+        ``sample_offset=o`` and draws what a single process would.  ``robot_subset`` / ``target_subset``: point-table
+        rows to use for the robot / target clouds instead of the two host draws (tests replay the reference's)."""
         dev = self.device
         ti = torch.as_tensor(trajectory_idx, dtype=torch.int64, device=dev).contiguous()
         ts = None if timestep is None else torch.as_tensor(timestep, dtype=torch.int32, device=dev).contiguous()
@@ -137,9 +140,13 @@ class PointCloudBase:
         xyz[:, :nr, 3] = 0  # label column (data_loader.py:261-267)
         xyz[:, nr:nr + no, 3] = 1
         xyz[:, nr + no:, 3] = 2
-        self.fk_sampler.sample_into(q, xyz, self.fk_sampler.draw_subset(nr))
+        if robot_subset is None:
+            robot_subset = self.fk_sampler.draw_subset(nr)
+        robot_subset = robot_subset.to(device=dev, dtype=torch.int32).contiguous()
+        assert robot_subset.numel() == nr
+        self.fk_sampler.sample_into(q, xyz, robot_subset)
         sample_scene_clouds(item, no, seed ^ 0x5CE7E, out=xyz[:, nr:nr + no], env_offset=sample_offset)
-        tgt = self.fk_sampler.sample_end_effector(pose, num_points=nt)
+        tgt = self.fk_sampler.sample_end_effector(pose, num_points=nt, subset=target_subset)
         xyz[:, nr + no:, :3] = tgt
         item["xyz"] = xyz
         return item

@@ -182,8 +182,10 @@ class FrankaSampler:
         _lib.call("mpx_franka_cloud", _lib.ptr(qc), q.size(0), self.finger, _lib.ptr(self.table_pts),
                   _lib.ptr(self.table_link), _lib.ptr(subset), n_out, _lib.ptr(out), out.stride(0), out.stride(1))
 
-    def sample_end_effector(self, poses: torch.Tensor, num_points: int, frame: str = "right_gripper") -> torch.Tensor:
-        """poses [B,4,4] of ``frame`` -> gripper points [B,num_points,3] (run_inference.py:66-69)."""
+    def sample_end_effector(self, poses: torch.Tensor, num_points: int, frame: str = "right_gripper",
+                            subset: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """poses [B,4,4] of ``frame`` -> gripper points [B,num_points,3] (run_inference.py:66-69).  ``subset`` (optional,
+        int32 indices into the gripper table): use these rows instead of drawing ``num_points`` of them."""
         if poses.ndim == 2:
             poses = poses.unsqueeze(0)
         poses = poses.to(self.device, dtype=torch.float32)  # (no-op for the GPU handle)
@@ -191,7 +193,10 @@ class FrankaSampler:
         assert poses.shape[1:] == (4, 4)
         table = self.eef_table if frame == "right_gripper" else torch.as_tensor(
             ft.end_effector_point_table(frame=frame)).to(self.device)
-        subset = self._draw(num_points, total=int(table.size(0)))
+        if subset is None:
+            subset = self._draw(num_points, total=int(table.size(0)))
+        subset = subset.to(device=self.device, dtype=torch.int32).contiguous()
+        assert subset.numel() == num_points
         out = torch.empty((poses.size(0), num_points, 3), dtype=torch.float32, device=poses.device)
         pc = _lib.f32c(poses)
         _lib.call("mpx_pose_cloud", _lib.ptr(pc), poses.size(0), _lib.ptr(table), _lib.ptr(subset), num_points,

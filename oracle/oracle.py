@@ -663,6 +663,35 @@ def rollout(sd, xyz, q, steps: int, sampler, limits, unnormalize_out: bool = Fal
     return traj
 
 
+def rollout_until_success(sd, q0, target, point_cloud, sampler, limits, max_rollout_length: int = 150):
+    """run_inference.py:137-191 for one problem: normalise q0; per step ``q = clamp(q + f(cloud, q), -1, 1)``,
+    unnormalise, append, test the end effector against ``target`` [4,4] (closer than 1 cm and 15 degrees: stop, BEFORE
+    the cloud is touched), otherwise resample the robot rows of ``point_cloud`` [1,N,4] in place.
+    ``sampler(q_unnorm [1,7], step)`` -> [1,P,3].  Returns the trajectory [T,7] (joint angles, start included)."""
+    q = _f(q0).reshape(1, 7)
+    traj = [q]
+    qn = normalize(q, limits)
+    tgt = _f(target).reshape(1, 16)
+    for i in range(max_rollout_length):
+        dq, _ = policy_forward(sd, point_cloud, qn)
+        qn = np.clip(qn + dq, np.float32(-1), np.float32(1)).astype(np.float32)
+        qt = unnormalize(qn, limits)
+        traj.append(qt)
+        ok, _, _ = success(franka_fk(qt)[:, RIGHT_GRIPPER_FRAME], tgt)
+        if ok[0]:
+            break
+        samples = sampler(qt, i)
+        point_cloud[:, : samples.shape[1], :3] = samples
+    return np.concatenate(traj, axis=0)
+
+
+def repair_quaternions(quats) -> np.ndarray:
+    """data_loader.py:202,232: rows whose four components are all ``np.isclose`` to zero get w = 1."""
+    q = np.array(quats, copy=True)
+    q[np.all(np.isclose(q, 0), axis=-1), 0] = 1
+    return q
+
+
 def validation_reduce(traj, target_position, sphere_table, cub, cyl, finger: float = 0.025):
     """The tail of validation_step (model.py:274-318) for a given unnormalised rollout ``traj`` [B,T,7]: final
     end-effector position error per environment, has_collision [B] by the radius-group reduce (restated as one

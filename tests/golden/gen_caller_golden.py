@@ -1,0 +1,272 @@
+"""Generates tests/golden/caller_golden.npz by IMPORTING AND RUNNING the reference's callers either side of the path:
+mpinets/data_loader.py (``PointCloudBase.get_inputs`` through the two dataset classes, :141-280, :283-417) and
+mpinets/run_inference.py (``make_point_cloud_from_primitives`` :93-134, ``rollout_until_success`` :137-191).
+
+Runs only in the build container (needs /root/reference); only the .npz is committed.  On top of the stubs of
+gen_model_golden.py (pytorch_lightning, pointnet2_ops, robofin samplers backed by the oracle FK) these modules import
+more absent packages; each stub supplies only what the executed lines touch:
+
+* ``h5py.File``: a context manager over a dict of arrays (``f[key][i, ...]``, ``.shape``, ``f.keys()``);
+* ``geometrout.primitive``: this repo's ``mpinets_amd.primitives`` (``Cuboid(c, d, q)``, ``.is_zero_volume()``,
+  ``.surface_area``, ``.sample_surface(n)`` -- the draws inside come from np.random like geometrout's);
+* ``geometrout.transform.SE3`` / ``pyquaternion.Quaternion``: ``.matrix``, ``.xyz`` / ``._xyz``, ``.so3._quat`` with the three
+  quaternion operations of run_inference.py:183-186 (product, conjugate, ``.radians``);
+* ``robofin.robots.FrankaRobot.fk`` / ``FrankaRealRobot.fk``: the oracle FK of ``right_gripper`` as such an SE3;
+* ``torch.Tensor.cuda``: identity (there is no GPU in the build container; run_inference.py:160 calls it);
+* trimesh, meshcat, urchin, termcolor, robofin.bullet, robofin.collision: empty modules (imported, never touched here).
+
+What executes is the reference's own: zero-quaternion repair and the dummy cylinder of get_inputs, its normalisation and
+target pose, the zero-volume filter, ``construct_mixed_point_cloud``, the slab layout and label column, the supervision
+row; the inference driver's slab assembly and its loop (normalise, clamp, unnormalise, append, success test BEFORE the
+resample, trajectory as an array).
+
+    python tests/golden/gen_caller_golden.py
+"""
+import math
+import os
+import random
+import sys
+import tempfile
+import types
+from pathlib import Path
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import gen_model_golden as gm  # noqa: E402  (sets sys.path; common stubs)
+
+from mpinets_amd import franka_tables as ft  # noqa: E402
+from mpinets_amd import primitives, scenes  # noqa: E402
+from oracle import oracle  # noqa: E402
+import seeded_weights  # noqa: E402
+
+NR, NS, NT = 2048, 4096, 128
+EEF_SUBSETS = []
+
+
+class Quat:
+    def __init__(self, w, x, y, z):
+        self.q = np.array([w, x, y, z], dtype=np.float64)
+
+    def __mul__(self, o):
+        a, b = self.q, o.q
+        return Quat(a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3],
+                    a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2],
+                    a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1],
+                    a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0])
+
+    @property
+    def conjugate(self):
+        return Quat(self.q[0], -self.q[1], -self.q[2], -self.q[3])
+
+    @property
+    def radians(self):  # rotation angle in (-pi, pi]
+        q = self.q / np.linalg.norm(self.q)
+        a = 2.0 * math.atan2(np.linalg.norm(q[1:]), q[0])
+        return ((a + math.pi) % (2 * math.pi)) - math.pi if a > math.pi else a
+
+
+def quat_of(R):
+    t = np.trace(R)
+    if t > 0:
+        s = math.sqrt(t + 1.0) * 2
+        return Quat(0.25 * s, (R[2, 1] - R[1, 2]) / s, (R[0, 2] - R[2, 0]) / s, (R[1, 0] - R[0, 1]) / s)
+    i = int(np.argmax(np.diag(R)))
+    j, k = (i + 1) % 3, (i + 2) % 3
+    s = math.sqrt(1.0 + R[i, i] - R[j, j] - R[k, k]) * 2
+    v = [0.0, 0.0, 0.0]
+    v[i], v[j], v[k] = 0.25 * s, (R[j, i] + R[i, j]) / s, (R[k, i] + R[i, k]) / s
+    return Quat((R[k, j] - R[j, k]) / s, *v)
+
+
+class SE3:
+    def __init__(self, matrix):
+        self.matrix = np.asarray(matrix, dtype=np.float64)
+        self._xyz = self.xyz = self.matrix[:3, 3].copy()
+        self.so3 = types.SimpleNamespace(_quat=quat_of(self.matrix[:3, :3]))
+
+
+def fk_se3(q, eff_frame="right_gripper"):
+    T = oracle.franka_fk(np.asarray(q, dtype=np.float32).reshape(1, 7))
+    return SE3(oracle.frames_to_4x4(T[0, ft.LINK_ID[eff_frame]]))
+
+
+class Sampler(gm._FrankaSampler):
+    def sample_end_effector(self, poses, num_points, frame="right_gripper"):
+        sub = np.random.choice(len(self.eef), num_points, replace=False).astype(np.int32)
+        EEF_SUBSETS.append(sub)
+        p = poses.numpy().astype(np.float32).reshape(-1, 4, 4)
+        pts = np.einsum("bij,nj->bni", p[:, :3, :3], self.eef[sub]) + p[:, None, :3, 3]
+        return torch.as_tensor(pts.astype(np.float32))
+
+
+class H5File:
+    data = {}
+
+    def __init__(self, path, mode="r"):
+        pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+    def __getitem__(self, k):
+        return H5File.data[k]
+
+    def keys(self):
+        return H5File.data.keys()
+
+
+def install_stubs():
+    gm.install_stubs()
+
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+
+    class _Empty:
+        pass
+
+    class FrankaRealRobot:
+        JOINT_LIMITS, DOF, fk = ft.JOINT_LIMITS_REAL, 7, staticmethod(fk_se3)
+
+    class FrankaRobot:
+        JOINT_LIMITS, DOF, fk = ft.JOINT_LIMITS_PUBLISHED, 7, staticmethod(fk_se3)
+
+    mod("h5py", File=H5File)
+    mod("pyquaternion", Quaternion=Quat)
+    mod("geometrout.primitive", Cuboid=primitives.Cuboid, Cylinder=primitives.Cylinder, Sphere=primitives.Sphere)
+    mod("geometrout.transform", SE3=SE3, SO3=_Empty)
+    mod("robofin.robots", FrankaRealRobot=FrankaRealRobot, FrankaRobot=FrankaRobot, FrankaGripper=_Empty)
+    mod("robofin.bullet", Bullet=_Empty, BulletController=_Empty)
+    mod("robofin.collision", FrankaSelfCollisionChecker=_Empty)
+    mod("robofin.pointcloud.torch", FrankaSampler=Sampler, FrankaCollisionSampler=gm._FrankaCollisionSampler)
+    mod("termcolor", colored=lambda s, *a, **k: s)
+    for name in ("trimesh", "meshcat", "urchin"):
+        mod(name)
+    sys.modules["pytorch_lightning"].LightningDataModule = object
+    torch.Tensor.cuda = lambda self, *a, **k: self
+
+
+def rng_fingerprint():
+    """Where np.random's generator stands: the first key words and the position inside the 624-word block."""
+    st = np.random.get_state()
+    return np.concatenate((st[1][:8].astype(np.int64), [st[2]]))
+
+
+def dataset_arrays():
+    """Four problems in the HDF5 schema (gen_data.py:676-700): zero-padded primitive rows with ALL-ZERO quaternions."""
+    scn = scenes.make_scenes(4, 31, ("tabletop", "cubby"), 10, 6)
+    arr = {"cuboid_dims": scn["cuboid_dims"].copy(), "cuboid_centers": scn["cuboid_centers"].copy(),
+           "cuboid_quaternions": scn["cuboid_quats"].copy(), "cylinder_radii": scn["cylinder_radii"].copy(),
+           "cylinder_heights": scn["cylinder_heights"].copy(), "cylinder_centers": scn["cylinder_centers"].copy(),
+           "cylinder_quaternions": scn["cylinder_quats"].copy(),
+           "hybrid_solutions": scenes.linear_trajectories(4, 50, 32)}
+    arr["cuboid_quaternions"][(arr["cuboid_dims"] == 0).all(-1)] = 0
+    arr["cylinder_quaternions"][arr["cylinder_radii"][..., 0] == 0] = 0
+    return arr
+
+
+def main():
+    install_stubs()
+    import mpinets.data_loader as dl
+    import mpinets.model as ref_model
+    import mpinets.run_inference as ri
+
+    torch.set_grad_enabled(False)
+    out = {}
+    # ---------------------------------------------------------------- data_loader.get_inputs
+    arr = dataset_arrays()
+    H5File.data = arr
+    for k, v in arr.items():
+        out["d_" + k] = v
+    root = Path(tempfile.mkdtemp())
+    for sub in ("val", "train"):
+        (root / sub).mkdir()
+        (root / sub / f"{sub}.hdf5").touch()
+
+    def record(tag, item, n_draws):
+        for k, v in item.items():
+            out[f"{tag}_{k}"] = v.numpy()
+        out[f"{tag}_robot_subset"] = gm.SUBSETS[-1]
+        out[f"{tag}_target_subset"] = EEF_SUBSETS[-1]
+        assert len(gm.SUBSETS) == n_draws and len(EEF_SUBSETS) == n_draws
+
+    val = dl.PointCloudTrajectoryDataset(root, "hybrid_solutions", NR, NS, NT, dl.DatasetType.VAL)
+    assert len(val) == 4 and val.expert_length == 50
+    random.seed(41), np.random.seed(41)
+    record("dv", val[2], 1)
+    # a file without cylinders (the dummy-cylinder branch, data_loader.py:210-215) and with ONE cuboid per scene stored
+    # without the M axis (:189-201)
+    H5File.data = {"cuboid_dims": arr["cuboid_dims"][:, 0], "cuboid_centers": arr["cuboid_centers"][:, 0],
+                   "cuboid_quaternions": arr["cuboid_quaternions"][:, 0], "hybrid_solutions": arr["hybrid_solutions"]}
+    random.seed(42), np.random.seed(42)
+    record("d1", val[1], 2)
+    H5File.data = arr
+    train = dl.PointCloudInstanceDataset(root, "hybrid_solutions", NR, NS, NT, dl.DatasetType.TRAIN, random_scale=0.015)
+    assert len(train) == 200
+    random.seed(43), np.random.seed(43), torch.manual_seed(43)
+    record("dt", train[3 * 50 + 49], 3)  # the last waypoint: supervised by itself (data_loader.py:408-412)
+    noise = torch.manual_seed(43) and torch.randn(7)  # the draw get_inputs made (data_loader.py:170-172)
+    out["dt_noise"] = noise.numpy()
+
+    # ---------------------------------------------------------------- run_inference
+    mdl = ref_model.MotionPolicyNetwork()
+    shapes = {k: tuple(v.shape) for k, v in mdl.state_dict().items()}
+    sd = seeded_weights.seeded_state_dict(shapes, seed=0)
+    mdl.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()}, strict=True)
+    mdl.eval()
+    out["param_sha256"] = np.array(seeded_weights.digest(sd))
+    scn = scenes.make_scenes(1, 51, ("tabletop",), 10, 6)
+    obstacles = [primitives.Cuboid(c, d, q) for c, d, q in zip(scn["cuboid_centers"][0], scn["cuboid_dims"][0], scn["cuboid_quats"][0])
+                 if not np.isclose(d, 0).any()]
+    obstacles += [primitives.Cylinder(c, r[0], h[0], q) for c, r, h, q in
+                  zip(scn["cylinder_centers"][0], scn["cylinder_radii"][0], scn["cylinder_heights"][0], scn["cylinder_quats"][0])
+                  if r[0] > 0]
+    for k, v in scn.items():
+        out["i_" + k] = v[0]
+    q0 = scenes.random_configurations(1, 52)[0]
+    target0 = fk_se3(scenes.random_configurations(1, 53)[0])
+    sampler = Sampler("cpu", use_cache=True)
+    n_r, n_t = len(gm.SUBSETS), len(EEF_SUBSETS)
+    random.seed(61), np.random.seed(61)
+    pc = ri.make_point_cloud_from_primitives(torch.as_tensor(q0), target0, obstacles, sampler)
+    assert pc.shape == (NR + NS + NT, 4)
+    out.update(i_q0=q0, i_target0=target0.matrix.astype(np.float32), i_slab=pc.numpy().copy(),
+               i_slab_robot_subset=gm.SUBSETS[n_r], i_slab_target_subset=EEF_SUBSETS[n_t])
+
+    def run(target, max_len):
+        ri.MAX_ROLLOUT_LENGTH = max_len
+        slab = pc.clone().unsqueeze(0)
+        n0 = len(gm.SUBSETS)
+        np.random.seed(62)
+        traj = ri.rollout_until_success(mdl, q0, target, slab, sampler)
+        return traj, slab[0].numpy(), np.stack(gm.SUBSETS[n0:]) if len(gm.SUBSETS) > n0 else np.zeros((0, NR), np.int32), \
+            rng_fingerprint()
+
+    # (1) a target nobody reaches: the loop runs its full length (12 here; 150 in the reference -- same body)
+    traj_a, slab_a, subs_a, rng_a = run(target0, 12)
+    assert traj_a.shape == (13, 7) and len(subs_a) == 12
+    # (2) success target = the pose of waypoint 7 of that run, same cloud: the loop must stop there, BEFORE resampling
+    target1 = fk_se3(traj_a[7])
+    traj_b, slab_b, subs_b, rng_b = run(target1, 12)
+    assert traj_b.shape == (8, 7) and len(subs_b) == 6 and np.array_equal(traj_b, traj_a[:8])
+    out.update(i_traj_full=traj_a, i_subsets_full=subs_a, i_robot_full=slab_a[:NR, :3].copy(), i_rng_full=rng_a,
+               i_target1=target1.matrix.astype(np.float32), i_traj_stop=traj_b, i_subsets_stop=subs_b,
+               i_robot_stop=slab_b[:NR, :3].copy(), i_rng_stop=rng_b)
+    print("rollout_until_success: full", traj_a.shape, "early stop", traj_b.shape)
+
+    np.savez_compressed(os.path.join(HERE, "caller_golden.npz"), **out)
+    print("wrote caller_golden.npz:", os.path.getsize(os.path.join(HERE, "caller_golden.npz")) // 1024, "KB")
+    for k in sorted(out):
+        if k.startswith(("dv_", "dt_")):
+            print(" ", k, out[k].shape, out[k].dtype)
+
+
+if __name__ == "__main__":
+    main()

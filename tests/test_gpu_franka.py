@@ -130,6 +130,55 @@ def test_fused_collision_check_matches_oracle(oracle, B, Tn, M1, M2):
     assert not cs.check(T(traj), None, None).any()
 
 
+def test_flags_only_sweep_decides_like_the_distance_form_at_the_boundary():
+    """The flags-only form of the per-environment kernel skips the square root behind two conservative bounds and falls
+    back to the exact arithmetic in between: spheres whose radius IS their distance (and the floats just below / above
+    it, and radii 1e-6 off) must get the flag `min_sdf <= radius` gives -- bit for bit, never a bound's guess."""
+    from mpinets_amd import _lib
+    from mpinets_amd.geometry import TorchCuboids, TorchCylinders
+    from mpinets_amd.robot import FrankaCollisionSampler
+    from mpinets_amd.scenes import linear_trajectories, make_scenes
+
+    B, Tn = 24, 3
+    scn = make_scenes(B, 17, ("tabletop", "cubby", "dresser"), 40, 16)
+    traj = T(linear_trajectories(B, Tn, 4))
+    cs = FrankaCollisionSampler(dev())
+    cub = TorchCuboids(T(scn["cuboid_centers"]), T(scn["cuboid_dims"]), T(scn["cuboid_quats"]))
+    cyl = TorchCylinders(T(scn["cylinder_centers"]), T(scn["cylinder_radii"]), T(scn["cylinder_heights"]),
+                         T(scn["cylinder_quats"]))
+    _, msdf = cs.check(traj, cub, cyl, return_sdf=True)  # [B,T,56]
+    msdf = msdf.cpu().numpy()
+    yr, yh = cyl.radii.contiguous(), cyl.heights.contiguous()
+    cd = cub.dims.contiguous()
+
+    def flags_only(radii, b, t):  # one (environment, waypoint) with its own sphere radii
+        fl = torch.zeros(1, dtype=torch.int32, device=dev())
+        _lib.call("mpx_franka_collision", _lib.ptr(traj[b, t:t + 1].contiguous()), 1, 1, cs.finger, _lib.ptr(cs.centers),
+                  _lib.ptr(T(radii)), _lib.ptr(cs.links), 56, _lib.ptr(cub.inv_frames[b:b + 1].contiguous()),
+                  _lib.ptr(cd[b:b + 1].contiguous()), 40, _lib.ptr(cyl.inv_frames[b:b + 1].contiguous()),
+                  _lib.ptr(yr[b:b + 1].contiguous()), _lib.ptr(yh[b:b + 1].contiguous()), 16, _lib.ptr(fl), None)
+        return bool(fl.item())
+
+    checked = 0
+    for b in range(B):
+        for t in range(Tn):
+            d = msdf[b, t]
+            if not (d > 1e-3).all():
+                continue  # (a sphere inside an obstacle: every non-negative radius collides, nothing to decide)
+            s = int(np.argmin(d))
+            for radii, want in ((np.full(56, -1.0), False),):
+                assert flags_only(radii.astype(np.float32), b, t) is want
+            base = np.zeros(56, np.float32)  # every other sphere: radius 0 < its distance
+            for r, want in ((d[s], True), (np.nextafter(d[s], np.float32(0)), False), (np.nextafter(d[s], np.float32(9)), True),
+                            (d[s] * np.float32(1 - 1e-6), False), (d[s] * np.float32(1 + 1e-6), True),
+                            (d[s] * np.float32(0.99), False), (d[s] * np.float32(1.01), True)):
+                radii = base.copy()
+                radii[s] = r
+                assert flags_only(radii, b, t) is want, (b, t, s, float(d[s]), float(r))
+            checked += 1
+    assert checked >= 10
+
+
 def test_joint_step(oracle):
     from mpinets_amd import _lib
     from mpinets_amd import franka_tables as ft

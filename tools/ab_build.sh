@@ -6,7 +6,7 @@ NAME=$1; SRC=$2; FLAGS=$3
 ROOT=$(cd "$(dirname "$0")/.." && pwd); C=$ROOT/motion-policy-networks_amd/csrc; O=$ROOT/build_ab
 mkdir -p $O
 EXTRA=""
-case $SRC in sa_mlp.hip|sa_mlp_bf16.hip) EXTRA="-mno-amdgpu-ieee -fno-honor-nans";; esac
+case $SRC in sa_mlp.hip|sa_mlp_bf16.hip|franka.hip) EXTRA="-mno-amdgpu-ieee -fno-honor-nans";; esac
 make -s -C $C all
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fvisibility=hidden -fno-gpu-rdc -Wall -Wno-unused-function \
   -mllvm -pragma-unroll-threshold=1000000 $EXTRA $FLAGS -c $C/$SRC -o $O/${SRC%.hip}_$NAME.o
