@@ -934,7 +934,7 @@ __global__ void __launch_bounds__(64 * v2::WV) __attribute__((amdgpu_waves_per_e
   };
 
   // ---- the units of this wave: handed out by a device-side queue (one counter per XCD: an environment's units go to
-  // the waves of one XCD, in order); the next unit is requested when the current one starts.  Unit sizes differ 1 : 30:
+  // the waves of one XCD, in order); the next unit is requested when the current one's last tile starts.  Unit sizes differ 1 : 30:
   // with a static stride the waves were resident 87 % of the kernel. ---------------------------------------------
   const int64_t n_units = (n_query + Q - 1) / Q;
   const int upe = npoint / Q;  // units per environment (xcd_aware only)
@@ -959,7 +959,6 @@ __global__ void __launch_bounds__(64 * v2::WV) __attribute__((amdgpu_waves_per_e
       j = next_unit();
     }
     if (dry) break;
-    j_next = next_unit();
     const int64_t unit = xcd_aware ? ((j / upe) * 8 + ((xcd + steal) & 7)) * upe + j % upe : j;
     const int64_t q0 = unit * Q;
     const int nq = (int)min((int64_t)Q, n_query - q0);
@@ -1074,6 +1073,10 @@ __global__ void __launch_bounds__(64 * v2::WV) __attribute__((amdgpu_waves_per_e
     }
 
     for (int rt = 0; rt < n_rows; rt += 32) {
+      // the next unit is claimed when the LAST tile of this one starts (the counter's round trip hides behind the tile;
+      // claimed a whole unit ahead, the units in flight under one L2 span twice as many environments -- the fp32
+      // kernel's fetch halved with this line, sa_mlp.hip)
+      if (rt + 32 >= n_rows) j_next = next_unit();
       const int ql_tile = ql_cur;
       const int env_gather = env_next, k_gather = k_next;
       const float *cq_next = ctr_w + ql_next * C1 + 4 * half;  // LDS row of the next tile's query (this lane's row)
