@@ -1,16 +1,19 @@
 #!/bin/bash
-# Round-3 evidence run (one MI355X): GPU tests, bench line (+ whole configs[4] extra), kernel stats, PMC passes of the fp32
-# headline and of the bf16x3 mode, collision counters.  Everything lands in gpurun_out/r03ev/; tools/r03_collect.sh copies
-# the summaries into profiles/.
-mkdir -p gpurun_out/r03ev
+# Evidence run of a round (one MI355X): GPU tests, bench line (+ whole configs[4] extra), kernel stats, PMC passes of the
+# fp32 headline and of the bf16x3 mode, collision counters.  usage (on the box): bash tools/evidence.sh r04 [notests]
+# Everything lands in gpurun_out/<round>ev/; tools/collect.sh <round> copies the summaries into profiles/.
+R=${1:-r04}
+mkdir -p gpurun_out/${R}ev
 export PYTHONUNBUFFERED=1
-REPO=$(pwd); O=$REPO/gpurun_out/r03ev
+REPO=$(pwd); O=$REPO/gpurun_out/${R}ev
 ( rocm-smi --showproductname 2>/dev/null | grep -i "card\|gfx" | head -4; echo "host cores: $(nproc)" ) > $O/box.log 2>&1
+if [ "$2" != "notests" ]; then
 timeout 1800 python -m pytest tests -m gpu -q -rA --tb=short -p no:cacheprovider > $O/pytest_gpu.log 2>&1
 echo "pytest exit: $?" >> $O/pytest_gpu.log; tail -3 $O/pytest_gpu.log | cut -c1-200
+fi
 cp gpurun_out/soak_hashes.json gpurun_out/horizon_report.json $O/ 2>/dev/null
 timeout 1200 python bench.py --whole-batch-steps 1 > $O/bench.log 2> $O/bench.err; echo "bench exit: $?" >> $O/bench.err; tail -1 $O/bench.err; cut -c1-200 $O/bench.log
-HEAD_ARGS="--steps 3 --warmup 1 --cpu-envs 0 --extra 0 --fast-steps 0 --pipeline-steps 0 --all-slots-steps 0"
+HEAD_ARGS="--steps 3 --warmup 1 --cpu-envs 0 --extra 0 --fast-steps 0 --pipeline-steps 0 --all-slots-steps 0 --train-steps 0"
 pmc() {  # tag, counters, command...
   tag=$1; ctr=$2; shift 2
   ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/pmc_$tag && timeout 900 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/pmc_$tag -o run -- python $REPO/"$@" > $O/pmc_${tag}.log 2>&1
@@ -24,7 +27,7 @@ stats() {  # tag, command...
     find /tmp/st_$tag -name "*kernel_stats.csv" -exec cp {} $O/stats_${tag}_kernel_stats.csv \; )
 }
 stats head bench.py $HEAD_ARGS
-PARGS="--envs 8192 --steps 2 --warmup 1 --cpu-envs 0 --extra 0 --fast-steps 0 --pipeline-steps 0 --all-slots-steps 0"
+PARGS="--envs 8192 --steps 2 --warmup 1 --cpu-envs 0 --extra 0 --fast-steps 0 --pipeline-steps 0 --all-slots-steps 0 --train-steps 0"
 pmc head1 "FETCH_SIZE" bench.py $PARGS
 pmc head2 "WRITE_SIZE" bench.py $PARGS
 pmc head3 "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE" bench.py $PARGS
@@ -42,5 +45,6 @@ pmc col1 "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" tool
 pmc col2 "SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_TRANS_F32" tools/collision_timing.py 8192 50 3
 pmc col3 "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_SALU SQ_INSTS_SMEM" tools/collision_timing.py 8192 50 3
 stats col tools/collision_timing.py 8192 50 5
-python tools/probes/sa3_phase_probe.py > $O/sa3_phase_probe.log 2>&1
+stats train tools/train_timing.py 256 5
+python tools/train_timing.py 256 5 > $O/train_256.log 2>&1; python tools/train_timing.py 10 10 > $O/train_10.log 2>&1
 echo done

@@ -29,7 +29,7 @@ else:
         mdl.set_precision("bf16x3")
         got = mdl(prob["xyz"][:64], prob["q_norm"][:64]).clone()
     print(f"lib {os.path.basename(_lib.LIB_PATH)}: |dq(bf16x3) - dq(fp32)| max = {(got - ref).abs().max().item():.2e}")
-eng = RolloutEngine(mdl, prob, rerender_scene=True, scene_seed=17)
+eng = RolloutEngine(mdl, prob, rerender_scene=True, scene_seed=17, resample_subset=True, subset_seed=23)
 eng.step()
 torch.cuda.synchronize()
 names = ("mpx_sa_mlp_bf16x3", "mpx_sa_mlp_bf16x3_factored", "mpx_linear_bf16x3", "mpx_linear_bf16x3_to_pairs",

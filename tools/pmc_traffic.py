@@ -1,5 +1,5 @@
 """Derive profiles/rNN_traffic.json (HBM bytes + MFMA-busy of the dominant kernel) from the per-pass PMC
-summaries written by tools/gpu_session.sh pmc=...   usage: pmc_traffic.py <dir with pass{1,2,3}_summary.csv> <envs> <out.json>"""
+summaries written by tools/evidence.sh   usage: pmc_traffic.py <dir with pass{1,2,3}_summary.csv> <envs> <out.json>"""
 import csv
 import json
 import os
@@ -28,7 +28,7 @@ active = per_launch(f"{d}/pass3_summary.csv", "GRBM_GUI_ACTIVE")  # summed over 
 alg = envs * (512 * 128 * 4 + 128 * 128 * 4 + 128 * 256 * 4 + 128 * 128 * 4 // 3)
 json.dump({
     "kernel": "void " + KERNEL, "envs_per_gpu": envs,
-    "source": "profiles/r03_pmc_pass{1,2,3}_envs%d.csv (rocprofv3 --pmc, separate passes)" % envs,
+    "source": "profiles/%s_pmc_pass{1,2,3}_envs%d.csv (rocprofv3 --pmc, separate passes)" % (os.path.basename(out).split("_")[0], envs),
     "kernel_source_sha256": kernel_source_hash(),
     "fetch_size_kib_per_launch": fetch, "write_size_kib_per_launch": write,
     "correction": "gfx950: FETCH_SIZE counts half of wide (16 B/lane) coalesced reads (MI355X_MICROARCH.md, HBM): reads doubled",
