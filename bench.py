@@ -44,10 +44,19 @@ SA2_FLOPS = 16384 * 57728 * 2  # 128*128 rows x (67*128 + 128*128 + 128*256) MAC
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 
 
-def cpu_step(orc, ft, sd, xyz, qn, prim, tables):
-    """One pass of the hot path over a batch on the host, by the oracle (a port, not the product)."""
+def cpu_step(orc, ft, sd, xyz, qn, prim, tables, torch_threads=0):
+    """One pass of the hot path over a batch on the host, by the oracle (a port, not the product).  The policy forward
+    is the oracle's torch restatement in fp32 on `torch_threads` threads (the identical op sequence on
+    all host cores), or its float64-accumulate numpy form when `torch_threads` is 0."""
     (c, r, l), (tp, tl) = tables
-    dq, _ = orc.policy_forward(sd, xyz, qn)
+    if torch_threads:
+        torch.set_num_threads(torch_threads)
+        sdt = {k: torch.from_numpy(v) for k, v in sd.items()}
+        with torch.no_grad():  # (chunks of 32 environments: the grouped activations of one chunk are ~2 GB)
+            dq = np.concatenate([orc.policy_forward_torch(sdt, xyz[i:i + 32], torch.from_numpy(qn[i:i + 32])).numpy()
+                                 for i in range(0, xyz.shape[0], 32)])
+    else:
+        dq, _ = orc.policy_forward(sd, xyz, qn)
     q = np.clip(qn + dq, -1, 1).astype(np.float32)
     qu = orc.unnormalize(q, ft.JOINT_LIMITS_REAL)
     T = orc.franka_fk(qu)
@@ -88,16 +97,21 @@ def cpu_baseline(prob, model, n_env: int):
     cpu_step(orc, ft, sd, xyz, qn, prim, tables)
     dt1 = time.perf_counter() - t0
     omp = orc.set_threads(host)
+    prev_threads = torch.get_num_threads()
     xyz, qn, prim = sample(n_env)
+    cpu_step(orc, ft, sd, xyz[:2], qn[:2], prim and {k: v[:2] for k, v in prim.items()}, tables, torch_threads=host)  # (thread pools up)
     t0 = time.perf_counter()
-    cpu_step(orc, ft, sd, xyz, qn, prim, tables)
+    cpu_step(orc, ft, sd, xyz, qn, prim, tables, torch_threads=host)
     dt = time.perf_counter() - t0
+    torch.set_num_threads(prev_threads)
     return {"value": n_env / dt, "unit": "env-steps/s", "cores": int(min(omp, host)), "omp_threads": int(omp),
-            "blas_threads": int(blas), "host_cores": host, "kind": "port",
+            "torch_threads": host, "blas_threads": int(blas), "host_cores": host, "kind": "port",
             "scalar_1t": {"value": n1 / dt1, "unit": "env-steps/s", "cores": 1,
-                          "sample": f"{n1} env-steps, C parts on one thread, {dt1:.1f} s"},
-            "sample": f"{n_env} env-steps of the same step (oracle/: C FPS + ball query + grouping + FK + SDF OpenMP-parallel "
-                      f"over environments on {omp} threads, numpy float64 MLPs on {blas} BLAS threads), {dt:.1f} s"}
+                          "sample": f"{n1} env-steps, C parts on one thread, float64-accumulate numpy MLPs, {dt1:.1f} s "
+                                    "(the definition rounds 1-3 reported)"},
+            "sample": f"{n_env} env-steps of the same step (oracle/: C FPS + ball query + FK + SDF OpenMP-parallel over "
+                      f"environments on {omp} threads; grouping, MLPs and heads as the oracle's torch restatement in fp32 "
+                      f"on {host} torch threads), {dt:.1f} s"}
 
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E ~8 TB/s
@@ -248,7 +262,7 @@ def main():
     ap.add_argument("--all-slots-steps", type=int, default=2, help="steps of the worst-case extra: padding elision off, all 128 slots per neighbourhood (0 = skip)")
     ap.add_argument("--whole-batch-steps", type=int, default=0, help="opt-in extra: steps of the whole 65 536-environment configs[4] batch on this one GPU (0 = skip; needs ~90 GB)")
     ap.add_argument("--pipeline-steps", type=int, default=3, help="steps of the two-stream pipelined measurement of the headline workload (0 = skip)")
-    ap.add_argument("--cpu-envs", type=int, default=64, help="env-steps in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-envs", type=int, default=256, help="env-steps in the CPU baseline sample (0 = skip)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak (default): --envs environments per GPU; strong: --global-envs environments split evenly over the GPUs")
     ap.add_argument("--global-envs", type=int, default=8192, help="total environments of a --scaling strong run")
