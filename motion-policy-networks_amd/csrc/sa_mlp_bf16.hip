@@ -872,11 +872,21 @@ static std::atomic<int> unit_queue_slots{256};
 int mpx_unit_queue_slots() { return unit_queue_slots.load(); }
 void mpx_unit_queue_set_slots(int n) { unit_queue_slots.store(n < 0 ? 0 : n > 256 ? 256 : n); }
 
+template <bool PROBE = false>
 __global__ void __launch_bounds__(64 * v2::WV) __attribute__((amdgpu_waves_per_eu(1, 1)))
     sa2_bf16x3_persistent_kernel(const int32_t *__restrict__ idx, const int32_t *__restrict__ cnt, int64_t n_query, int N,
                                  int npoint, int nsample, const unsigned char *__restrict__ wpack, float *__restrict__ out,
                                  int out_stride, const float *__restrict__ pre_rows, const float *__restrict__ ctr,
-                                 int xcd_aware, unsigned int *__restrict__ queue) {
+                                 int xcd_aware, unsigned int *__restrict__ queue, long long *__restrict__ probe) {
+  // PROBE (measurement only, tools/probes/sa2_bf16_phase_probe.py): s_memtime stamps of workgroup 100, wave 0 at the
+  // start of a tile, after its layer 2 and after its layer 3, for the first 20 tiles it runs
+  int pi = 0;
+  auto stamp = [&]() __attribute__((always_inline)) {
+    if constexpr (PROBE) {
+      if (blockIdx.x == 100 && threadIdx.x == 0 && pi < 80) probe[pi] = (long long)__builtin_amdgcn_s_memtime();
+      ++pi;
+    }
+  };
   using namespace v2;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63;
@@ -893,6 +903,9 @@ __global__ void __launch_bounds__(64 * v2::WV) __attribute__((amdgpu_waves_per_e
   __syncthreads();  // the only barrier: from here on the waves are independent
   const float *bias2_s = reinterpret_cast<const float *>(smem + LDS_BIAS2);
   const float *bias3_s = reinterpret_cast<const float *>(smem + LDS_BIAS3);
+  float b3v[Cfg::OT3];  // this lane's channel of every layer-3 output tile
+#pragma unroll
+  for (int ot = 0; ot < Cfg::OT3; ++ot) b3v[ot] = bias3_s[ot * 32 + col];
   float *ctr_w = reinterpret_cast<float *>(smem + LDS_CTR) + wave * Q * C1;
   const unsigned char *w3_lane = smem + lane * 16;
 
@@ -921,6 +934,10 @@ __global__ void __launch_bounds__(64 * v2::WV) __attribute__((amdgpu_waves_per_e
 #pragma unroll
   for (int n = 0; n < RD; ++n) fetch2(n);
 
+  // (Round 4, s_memtime probe -- tools/probes/sa2_bf16_phase_probe.py: the compiler sinks most of the next tile's
+  // relu(pre - ctr) + split behind the tile's last MFMA, 1.7 k cycles between two tiles.  Pinning every quantum in its gap
+  // with an empty volatile asm on its operand registers moves those cycles INTO the layer loops and leaves the tile time
+  // where it was (14.9 k / 17.9 k cycles with / without a query boundary): the fillers are not what the tile waits for.)
   // relu + hi / lo split of elements (2e, 2e+1) of a 16-float accumulator tile into the packed bf16 operand pairs
   // (one "quantum": ~8 VALU) -- relu_split_tile, two elements at a time
   auto split_q = [&](const f32x16 &acc, bf16x8 (&hi)[2], bf16x8 (&lo)[2], int e) __attribute__((always_inline)) {
@@ -1029,12 +1046,15 @@ __global__ void __launch_bounds__(64 * v2::WV) __attribute__((amdgpu_waves_per_e
 #pragma unroll
     for (int ot = 0; ot < Cfg::OT3; ++ot) run[ot] = -__builtin_inff();
     int cur = 0;  // local query being merged (wave-uniform)
+    // (the lane's eight layer-3 biases sit in registers and the unit's output rows start at one 64-bit base: a flush in
+    // the middle of a tile -- a query boundary, every other tile -- used to wait for an LDS read and to rebuild a 64-bit
+    // row address with quarter-rate integer multiplies, 3.3 k of a 12.7 k-cycle layer 3; s_memtime probe, round 4)
+    float *const out_unit = out + q0 * out_stride + col;
     auto flush = [&](int ot, int qi) __attribute__((always_inline)) {
       float v = run[ot];
       v = mpx_max_across_halves(v);
-      const int ch = ot * 32 + col;
-      v = fmaxf(v + bias3_s[ch], 0.0f);
-      if (half == 0) out[(q0 + qi) * out_stride + ch] = v;
+      v = fmaxf(v + b3v[ot], 0.0f);
+      if (half == 0) out_unit[__builtin_amdgcn_readfirstlane(qi) * out_stride + ot * 32] = v;
       run[ot] = -__builtin_inff();
     };
 
@@ -1077,6 +1097,7 @@ __global__ void __launch_bounds__(64 * v2::WV) __attribute__((amdgpu_waves_per_e
       // claimed a whole unit ahead, the units in flight under one L2 span twice as many environments -- the fp32
       // kernel's fetch halved with this line, sa_mlp.hip)
       if (rt + 32 >= n_rows) j_next = next_unit();
+      stamp();
       const int ql_tile = ql_cur;
       const int env_gather = env_next, k_gather = k_next;
       const float *cq_next = ctr_w + ql_next * C1 + 4 * half;  // LDS row of the next tile's query (this lane's row)
@@ -1109,6 +1130,7 @@ __global__ void __launch_bounds__(64 * v2::WV) __attribute__((amdgpu_waves_per_e
         if (pair == 1 && mm % 3 == 2) split_q(a2[(mm / 3) >> 3], h2[(mm / 3) >> 3], l2[(mm / 3) >> 3], (mm / 3) & 7);
         V2_FENCE();
       }
+      stamp();
       // the next tile's rows are requested now: layer 3 reads LDS only, so these slower loads are not in front of
       // anything the matrix stream waits for; they are consumed from output pair 2 on (~3000 cycles from here)
       // (round 3: one gather load per MFMA gap behind the first 16 MFMAs of layer 3, not 16 back to back here)
@@ -1184,6 +1206,8 @@ __global__ void __launch_bounds__(64 * v2::WV) __attribute__((amdgpu_waves_per_e
       pool(3, 0);
       pool(3, 1);
       cur = gq[7];
+      stamp();
+      stamp();  // (back to back: the cost of a stamp itself)
       V2_FENCE();
     }
 #pragma unroll
@@ -1245,6 +1269,7 @@ static int launch_sa_bf16(const float *xyz, int stride, const float *new_xyz, in
 // (Kept in the ABI: callers written against version 200 ask before they sort.)
 MPX_EXPORT int mpx_sa_mlp_bf16x3_factored_wants_order(void) { return 0; }
 
+static long long *g_sa2_probe = nullptr;
 MPX_EXPORT int mpx_sa_mlp_bf16x3_factored(const float *pre, const float *ctr, const int32_t *idx, const int32_t *cnt,
                                           const int32_t *order, int B, int N, int npoint, int nsample, const void *wpack,
                                           int C, int c1, int c2, int c3, float *out, int out_stride, mpx_stream_t stream) {
@@ -1270,15 +1295,30 @@ MPX_EXPORT int mpx_sa_mlp_bf16x3_factored(const float *pre, const float *ctr, co
   }
   const int grid = cus[dev & 63];
   const int xcd_aware = (B % 8 == 0 && grid % 8 == 0 && npoint % v2::Q == 0) ? 1 : 0;
-  MPX_LDS_LIMIT_ONCE(sa2_bf16x3_persistent_kernel, v2::LDS_BYTES, "mpx_sa_mlp_bf16x3_factored");
+  MPX_LDS_LIMIT_ONCE(sa2_bf16x3_persistent_kernel<false>, v2::LDS_BYTES, "mpx_sa_mlp_bf16x3_factored");
   int exhausted = 0;
   unsigned int *queue = mpx_unit_queue_for(mpx_s(stream), &exhausted);
   MPX_REQUIRE(queue != nullptr, exhausted ? "mpx_sa_mlp_bf16x3_factored: no unit-queue slot left for this stream (256 "
                                             "distinct streams per process; reuse streams)"
                                           : "mpx_sa_mlp_bf16x3_factored: cannot reset the unit queue");
-  hipLaunchKernelGGL(sa2_bf16x3_persistent_kernel, dim3(grid), dim3(64 * v2::WV), v2::LDS_BYTES, mpx_s(stream), idx, cnt, nq, N,
-                     npoint, nsample, static_cast<const unsigned char *>(wpack), out, out_stride, pre, ctr, xcd_aware, queue);
+  if (g_sa2_probe) {  // (measurement only: mpx_sa2_bf16x3_set_probe, not in the header)
+    MPX_LDS_LIMIT_ONCE(sa2_bf16x3_persistent_kernel<true>, v2::LDS_BYTES, "mpx_sa_mlp_bf16x3_factored");
+    hipLaunchKernelGGL(sa2_bf16x3_persistent_kernel<true>, dim3(grid), dim3(64 * v2::WV), v2::LDS_BYTES, mpx_s(stream), idx, cnt,
+                       nq, N, npoint, nsample, static_cast<const unsigned char *>(wpack), out, out_stride, pre, ctr, xcd_aware,
+                       queue, g_sa2_probe);
+    MPX_LAUNCH_CHECK("mpx_sa_mlp_bf16x3_factored");
+  }
+  hipLaunchKernelGGL(sa2_bf16x3_persistent_kernel<false>, dim3(grid), dim3(64 * v2::WV), v2::LDS_BYTES, mpx_s(stream), idx, cnt,
+                     nq, N, npoint, nsample, static_cast<const unsigned char *>(wpack), out, out_stride, pre, ctr, xcd_aware,
+                     queue, (long long *)nullptr);
   MPX_LAUNCH_CHECK("mpx_sa_mlp_bf16x3_factored");
+}
+
+// measurement only (not in the header): route the next launches of the persistent kernel through its PROBE instantiation,
+// which writes s_memtime stamps of one wave into `probe` (>= 80 int64; nullptr = off)
+MPX_EXPORT int mpx_sa2_bf16x3_set_probe(long long *probe) {
+  g_sa2_probe = probe;
+  return 0;
 }
 
 MPX_EXPORT int mpx_sa_mlp_bf16x3(const float *xyz, int stride, const float *new_xyz, int new_stride,
