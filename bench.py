@@ -67,51 +67,71 @@ def cpu_step(orc, ft, sd, xyz, qn, prim, tables, torch_threads=0):
                          prim["cylinder_quats"]))
 
 
+def _cpu_worker(args):
+    """One worker process of the CPU baseline: `threads` threads, environments [i0, i1) of the sample file."""
+    path, i0, i1, threads, barrier = args
+    from mpinets_amd import franka_tables as ft
+    from oracle import oracle as orc
+
+    data = np.load(path)
+    sd = {k[3:]: data[k] for k in data.files if k.startswith("sd.")}
+    prim = {k[5:]: data[k][i0:i1] for k in data.files if k.startswith("prim.")}
+    xyz, qn = data["xyz"][i0:i1], data["qn"][i0:i1]
+    tables = (ft.collision_sphere_table(False)[:3], ft.link_point_table())
+    orc.set_threads(threads)
+    cpu_step(orc, ft, sd, xyz[:2], qn[:2], {k: v[:2] for k, v in prim.items()}, tables, torch_threads=threads)  # (pools up)
+    barrier.wait()
+    t0 = time.time()
+    cpu_step(orc, ft, sd, xyz, qn, prim, tables, torch_threads=threads)
+    return t0, time.time()
+
+
 def cpu_baseline(prob, model, n_env: int):
-    """Oracle (CPU port) timed on `n_env` env-steps of the same workload on ALL host cores: the C parts
-    (FPS, ball query, grouping, FK, SDF) are OpenMP-parallel over environments, the numpy float64 matrix products use
-    the BLAS pool; `cores` = the threads actually used by both.  `scalar_1t`: the same step on 8 environments with the C
-    parts on ONE thread (what rounds 1-3 reported)."""
+    """Oracle (CPU port) timed on `n_env` env-steps of the same workload on ALL host cores.  One process
+    does not use 256 cores on this op mix (measured on the box: the torch fp32 restatement peaks at 16-32 threads, 22
+    env-steps/s, and drops to 3 with 256), so the sample is cut over host_cores / 16 worker processes of 16 threads each
+    (C parts OpenMP-parallel over environments, grouping / MLPs / heads as the oracle's torch restatement in fp32);
+    `cores` = processes x threads.  The workers start together behind a barrier; the time is first start -> last end.
+    `scalar_1t`: the same step on 8 environments in this process with the C parts on ONE thread and the float64 numpy
+    MLPs (what rounds 1-3 reported)."""
+    import multiprocessing as mp
+    import tempfile
+
     from mpinets_amd import franka_tables as ft
     from oracle import oracle as orc
 
     orc.build()
     host = int(os.cpu_count() or 1)
-    try:
-        from threadpoolctl import threadpool_info
-
-        blas = max([p.get("num_threads", 1) for p in threadpool_info() if p.get("user_api") == "blas"] + [1])
-    except Exception:
-        blas = host
     sd = {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
     tables = (ft.collision_sphere_table(False)[:3], ft.link_point_table())
-
-    def sample(n):
-        return (prob["xyz"][:n].cpu().numpy(), prob["q_norm"][:n].cpu().numpy(),
-                {k: prob[k][:n].cpu().numpy() for k in prob if k.startswith(("cuboid_", "cylinder_"))})
-
+    prim_keys = [k for k in prob if k.startswith(("cuboid_", "cylinder_"))]
     n1 = min(8, n_env)
     orc.set_threads(1)
-    xyz, qn, prim = sample(n1)
     t0 = time.perf_counter()
-    cpu_step(orc, ft, sd, xyz, qn, prim, tables)
+    cpu_step(orc, ft, sd, prob["xyz"][:n1].cpu().numpy(), prob["q_norm"][:n1].cpu().numpy(),
+             {k: prob[k][:n1].cpu().numpy() for k in prim_keys}, tables)
     dt1 = time.perf_counter() - t0
-    omp = orc.set_threads(host)
-    prev_threads = torch.get_num_threads()
-    xyz, qn, prim = sample(n_env)
-    cpu_step(orc, ft, sd, xyz[:2], qn[:2], prim and {k: v[:2] for k, v in prim.items()}, tables, torch_threads=host)  # (thread pools up)
-    t0 = time.perf_counter()
-    cpu_step(orc, ft, sd, xyz, qn, prim, tables, torch_threads=host)
-    dt = time.perf_counter() - t0
-    torch.set_num_threads(prev_threads)
-    return {"value": n_env / dt, "unit": "env-steps/s", "cores": int(min(omp, host)), "omp_threads": int(omp),
-            "torch_threads": host, "blas_threads": int(blas), "host_cores": host, "kind": "port",
+    threads = min(16, host)
+    nw = max(1, min(host // threads, n_env // 8))
+    cuts = [n_env * i // nw for i in range(nw + 1)]
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "sample.npz")
+        np.savez(path, xyz=prob["xyz"][:n_env].cpu().numpy(), qn=prob["q_norm"][:n_env].cpu().numpy(),
+                 **{"sd." + k: v for k, v in sd.items()}, **{"prim." + k: prob[k][:n_env].cpu().numpy() for k in prim_keys})
+        ctx = mp.get_context("spawn")  # (fork is unsafe once the GPU runtime is up)
+        with ctx.Manager() as mgr:
+            barrier = mgr.Barrier(nw)
+            with ctx.Pool(nw) as pool:
+                spans = pool.map(_cpu_worker, [(path, cuts[i], cuts[i + 1], threads, barrier) for i in range(nw)])
+    dt = max(e for _, e in spans) - min(s for s, _ in spans)
+    return {"value": n_env / dt, "unit": "env-steps/s", "cores": nw * threads, "processes": nw, "threads_per_process": threads,
+            "host_cores": host, "kind": "port",
             "scalar_1t": {"value": n1 / dt1, "unit": "env-steps/s", "cores": 1,
                           "sample": f"{n1} env-steps, C parts on one thread, float64-accumulate numpy MLPs, {dt1:.1f} s "
                                     "(the definition rounds 1-3 reported)"},
-            "sample": f"{n_env} env-steps of the same step (oracle/: C FPS + ball query + FK + SDF OpenMP-parallel over "
-                      f"environments on {omp} threads; grouping, MLPs and heads as the oracle's torch restatement in fp32 "
-                      f"on {host} torch threads), {dt:.1f} s"}
+            "sample": f"{n_env} env-steps of the same step over {nw} processes x {threads} threads (oracle/: C FPS + ball query "
+                      f"+ FK + SDF OpenMP-parallel over environments; grouping, MLPs and heads as the oracle's torch restatement "
+                      f"in fp32), {dt:.1f} s from the first worker's start to the last one's end"}
 
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E ~8 TB/s
@@ -262,7 +282,7 @@ def main():
     ap.add_argument("--all-slots-steps", type=int, default=2, help="steps of the worst-case extra: padding elision off, all 128 slots per neighbourhood (0 = skip)")
     ap.add_argument("--whole-batch-steps", type=int, default=0, help="opt-in extra: steps of the whole 65 536-environment configs[4] batch on this one GPU (0 = skip; needs ~90 GB)")
     ap.add_argument("--pipeline-steps", type=int, default=3, help="steps of the two-stream pipelined measurement of the headline workload (0 = skip)")
-    ap.add_argument("--cpu-envs", type=int, default=256, help="env-steps in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-envs", type=int, default=512, help="env-steps in the CPU baseline sample (0 = skip)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak (default): --envs environments per GPU; strong: --global-envs environments split evenly over the GPUs")
     ap.add_argument("--global-envs", type=int, default=8192, help="total environments of a --scaling strong run")
