@@ -280,7 +280,7 @@ def main():
     ap.add_argument("--extra", type=int, default=1, help="also time BASELINE configs 2 and 4 (collision validation only)")
     ap.add_argument("--static-steps", type=int, default=2, help="steps of the extra without scene re-render on tabletop-only scenes (BASELINE config 3 shape at this batch size); 0 = skip")
     ap.add_argument("--all-slots-steps", type=int, default=2, help="steps of the worst-case extra: padding elision off, all 128 slots per neighbourhood (0 = skip)")
-    ap.add_argument("--whole-batch-steps", type=int, default=0, help="opt-in extra: steps of the whole 65 536-environment configs[4] batch on this one GPU (0 = skip; needs ~90 GB)")
+    ap.add_argument("--whole-batch-steps", type=int, default=0, help="opt-in extra: steps of the whole 65 536-environment configs[4] batch on this one GPU (0 = skip; 17 GB: the encoder works in slabs of 8192 environments)")
     ap.add_argument("--pipeline-steps", type=int, default=3, help="steps of the two-stream pipelined measurement of the headline workload (0 = skip)")
     ap.add_argument("--cpu-envs", type=int, default=512, help="env-steps in the CPU baseline sample (0 = skip)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
@@ -638,7 +638,7 @@ def main():
             "what": "FK + sphere SDF, flags + min-sdf [1024,56] written; 1024 environments on every rank"}
 
     # ---- extra (opt-in, rank 0): the WHOLE of BASELINE configs[4] -- 65 536 environments -- resident on ONE GPU (the
-    # launchers walk the batch in slabs past gridDim.y / 4 GB-per-operand limits; ~90 GB of the 288 GB)
+    # encoder works in slabs of 8192 environments that reuse one workspace: 17 GB of the 288 GB)
     whole = None
     if args.whole_batch_steps > 0 and not shared_devices:
         del eng

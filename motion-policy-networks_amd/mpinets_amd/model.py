@@ -77,6 +77,11 @@ class MPiNetsPointNet(nn.Module):
         # bf16x3 only: keep the group-all MLP's activations in the split "pairs" form between layers (default) or as
         # fp32 rows that every layer splits again on its way in -- bit-identical results (tests), pairs are faster
         self.dense_through_pairs = True
+        # environments per pass of the encoder (None: the whole batch at once); see forward().  Default: batches up to the
+        # bench's 8192 per GPU run in one pass (slabs of 4096 / 2048 measured at 8192: 8.9 -> 5.0 / 3.1 GB peak, +1.8 % /
+        # +5.5 % time -- every launch has a tail); larger ones (the whole 65 536-environment configuration) in slabs of <= 8192.
+        # Slabs stay above 1024 environments for chunk >= 2048, i.e. inside the dense layers' large-batch launch shape.
+        self.workspace_chunk = 8192
 
     def _lin(self, x, weight, bias, act=0, out=None, source=None):
         if self.dense_precision == "bf16x3":
@@ -247,6 +252,25 @@ class MPiNetsPointNet(nn.Module):
         pc = _lib.f32c(point_cloud)
         B, N, _ = pc.shape
         dev = pc.device
+        chunk = self.workspace_chunk
+        if chunk and aux is None and B > chunk:
+            # Large batches go through the encoder in slabs of <= `workspace_chunk` environments: the intermediates
+            # (neighbour rows, per-point first-layer rows, module outputs: 0.73 MB per environment) are slab-sized and
+            # reused, so the workspace is 0.73 MB x chunk whatever B is (8192 environments: 3 GB instead of 6; the whole
+            # 65 536-environment configuration: the same 3 GB instead of 48).  Environments never interact and every slab
+            # is large enough for the launch shapes of the whole batch: bit-identical results (tests/test_gpu_policy.py).
+            if side_work is not None:
+                side_work()
+            if out is None:
+                out = torch.empty((B, self.fc_layer[6].out_features), dtype=torch.float32, device=dev)
+            counts = []
+            n_slabs = -(-B // chunk)
+            for i in range(n_slabs):  # near-equal slabs: no small tail with other launch shapes
+                b0, b1 = B * i // n_slabs, B * (i + 1) // n_slabs
+                self.forward(pc[b0:b1], out=out[b0:b1])
+                counts.append(self.last_counts)
+            self.last_counts = tuple(torch.cat([c[k] for c in counts]) for k in (0, 1))
+            return out
         sa1, sa2, sa3 = self.SA_modules
         lib = _lib
         # ---- SA1 -------------------------------------------------------------------------------

@@ -816,3 +816,37 @@ def test_policy_forward_is_consistent_across_the_chain_threshold():
                         for i in (0, B // 2)])
     assert torch.equal(big, nat)
     assert (big - lo).abs().max().item() < 2e-6, (big - lo).abs().max().item()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_encoder_slabs_are_bit_identical_to_one_pass(precision):
+    """model.point_cloud_encoder.workspace_chunk: a batch larger than the chunk goes through the encoder in near-equal
+    slabs that reuse one workspace.  Same output bits, same hit counts, and the peak memory of the forward drops."""
+    from mpinets_amd.model import MotionPolicyNetwork
+    from mpinets_amd.scenes import make_problem_batch
+
+    torch.manual_seed(8)
+    mdl = MotionPolicyNetwork().to(dev()).eval().set_precision(precision)
+    B = 3 * 1100 + 7  # (slabs above 1024 rows: the dense layers keep the launch shape of the whole batch)
+    prob = make_problem_batch(B, seed=43, device=dev(), kinds=("tabletop", "cubby", "dresser"), M1=40, scene_pool=64,
+                              device_clouds=True)
+    enc = mdl.point_cloud_encoder
+    with torch.no_grad():
+        enc.workspace_chunk = None
+        mdl(prob["xyz"][:8], prob["q_norm"][:8])  # (weight packs built)
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        one = mdl(prob["xyz"], prob["q_norm"]).clone()
+        c_one = [c.clone() for c in enc.last_counts]
+        torch.cuda.synchronize()
+        peak_one = torch.cuda.max_memory_allocated() - base
+        enc.workspace_chunk = 1200  # -> three slabs of 1102 / 1103 environments
+        torch.cuda.reset_peak_memory_stats()
+        slabs = mdl(prob["xyz"], prob["q_norm"]).clone()
+        torch.cuda.synchronize()
+        peak_slabs = torch.cuda.max_memory_allocated() - base
+    assert torch.equal(one, slabs)
+    assert all(torch.equal(a, b) for a, b in zip(c_one, enc.last_counts))
+    print(f"peak forward memory: one pass {peak_one / 2**20:.0f} MiB, slabs {peak_slabs / 2**20:.0f} MiB")
+    assert peak_slabs < 0.45 * peak_one
