@@ -626,6 +626,9 @@ __global__ void __launch_bounds__(64 * FPSC_WAVES)
   }
 }
 
+#ifndef MPX_FPS4_MIN_B
+#define MPX_FPS4_MIN_B 768  // from this many environments on, the 4-wave culled FPS (A/B: tools/ab_build.sh)
+#endif
 constexpr int FPS_MAX_N = 8192;                         // 512 threads x 16 points (include/mpinets_hip.h says the same)
 constexpr int FPS_MAX_LDS = 256 + 3 * FPS_MAX_N * 4;    // the cloud copy of the largest supported launch
 
@@ -678,7 +681,7 @@ MPX_EXPORT int mpx_fps(const float *xyz, int B, int N, int stride, int npoint, i
     // workgroups per CU instead of two (6.45 -> 6.11 ms at 8192 environments; with the LDS copy, two per CU: 7.10 ms)
     // (a few hundred environments or fewer are latency-bound, not throughput-bound: they keep the 8-wave form, whose pick
     // chain is shorter -- one planning problem: 0.69 vs 0.80 ms per step.  Same indices either way.)
-    const int waves = (N > 16 * 256 && B >= 768) ? 4 : 8;
+    const int waves = (N > 16 * 256 && B >= MPX_FPS4_MIN_B) ? 4 : 8;
     const size_t lds_c = fpsc_lds_bytes(N, waves == 4);
     // (wave counts measured in round 3 at 8192 environments x 6272 points: 16 waves x 7 points per lane 8.31 ms, 8 x 13
     // 6.41 ms, 4 x 25 with the LDS cloud copy 7.10 ms, 4 x 25 without it 6.11 ms: the cross-wave reduction and the

@@ -1,6 +1,6 @@
 """FPS timing at the model's sizes, fast kernels (variant 1) and plain kernels (variant 0). usage: fps_timing.py [B] [npoint]"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "motion-policy-networks_amd")]
 import torch
 from mpinets_amd import _lib
