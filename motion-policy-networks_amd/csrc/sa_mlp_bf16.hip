@@ -825,6 +825,9 @@ static_assert(Cfg::ST2 == 32 && Cfg::ST3 == 64 && Cfg::KS1 == 8 && Cfg::KS2 == 8
 }  // namespace v2
 
 #define V2_FENCE() __builtin_amdgcn_sched_barrier(0)
+#ifndef MPX_V2_SMOOTH
+#define MPX_V2_SMOOTH 1  // fillers of the tile loop in half quanta, one piece per MFMA gap (0: round 3's placement)
+#endif
 
 // Unit queues of the persistent kernel: 8 counters (one per XCD) per launch, in device memory that belongs to the
 // library image (nothing is allocated).  ONE SLOT PER (device, stream): the launches of a stream are ordered (memset,
@@ -948,6 +951,27 @@ __global__ void __launch_bounds__(64 * v2::WV) __attribute__((amdgpu_waves_per_e
     hi[u][k + 1] = h1;
     lo[u][k] = (__bf16)(v0 - (float)h0);
     lo[u][k + 1] = (__bf16)(v1 - (float)h1);
+  };
+
+  // Half quanta (round 4): a gap between two MFMAs of a lone in-order wave hides about three plain VALU; a fourth costs
+  // ~2 cycles, a burst of 9-13 (a whole quantum) stalls the next MFMA for the burst's own issue time (micro-benchmark:
+  // tools/probes/mfma_bf16_stream.hip).  So a quantum is cut in two -- relu + hi, then lo -- and the halves go into
+  // consecutive gaps; the empty volatile asm pins each half where it is written (the compiler otherwise sinks most of
+  // them behind the tile's last MFMA).
+  (void)split_q;  // (round 3's whole-quantum form: MPX_V2_SMOOTH=0)
+  float tv0 = 0.0f, tv1 = 0.0f;  // relu'd pair between the two halves of a split
+  auto split_h = [&](const f32x16 &acc, bf16x8 (&hi)[2], bf16x8 (&lo)[2], int e, int part) __attribute__((always_inline)) {
+    const int u = e >> 2, k = 2 * (e & 3);
+    if (part == 0) {
+      tv0 = fmaxf(acc[8 * u + k], 0.0f), tv1 = fmaxf(acc[8 * u + k + 1], 0.0f);
+      hi[u][k] = (__bf16)tv0;
+      hi[u][k + 1] = (__bf16)tv1;
+      asm volatile("" : "+v"(hi[u]), "+v"(tv0), "+v"(tv1));
+    } else {
+      lo[u][k] = (__bf16)(tv0 - (float)hi[u][k]);
+      lo[u][k + 1] = (__bf16)(tv1 - (float)hi[u][k + 1]);
+      asm volatile("" : "+v"(lo[u]));
+    }
   };
 
   // ---- the units of this wave: handed out by a device-side queue (one counter per XCD: an environment's units go to
@@ -1077,6 +1101,27 @@ __global__ void __launch_bounds__(64 * v2::WV) __attribute__((amdgpu_waves_per_e
       l1[ot][u][k + 1] = (__bf16)(v1 - (float)hh1);
     };
 
+    float fv0 = 0.0f, fv1 = 0.0f;
+    auto load_cq = [&](const float *cqp, int i) __attribute__((always_inline)) {  // the four ctr values of channel group i
+      cq[i & 3] = *reinterpret_cast<const float4 *>(cqp + 8 * i);
+    };
+    auto form_h = [&](const float *cqp, int g, int part) __attribute__((always_inline)) {
+      const int i = g >> 1, ot = i >> 2, gg = i & 3, pr2 = g & 1;
+      const int r = 4 * gg + 2 * pr2, u = r >> 3, k = r & 7;
+      if (part == 0) {
+        const float c0 = pr2 ? cq[gg].z : cq[gg].x, c1 = pr2 ? cq[gg].w : cq[gg].y;
+        fv0 = fmaxf(raw_pre[4 * i + 2 * pr2] - c0, 0.0f), fv1 = fmaxf(raw_pre[4 * i + 2 * pr2 + 1] - c1, 0.0f);
+        h1[ot][u][k] = (__bf16)fv0;
+        h1[ot][u][k + 1] = (__bf16)fv1;
+        asm volatile("" : "+v"(h1[ot][u]), "+v"(fv0), "+v"(fv1));
+      } else {
+        if (pr2 == 1 && i + 1 < C1 / 8) load_cq(cqp, i + 1);  // the next group's ctr values: read a gap ahead of their use
+        l1[ot][u][k] = (__bf16)(fv0 - (float)h1[ot][u][k]);
+        l1[ot][u][k + 1] = (__bf16)(fv1 - (float)h1[ot][u][k + 1]);
+        asm volatile("" : "+v"(l1[ot][u]));
+      }
+    };
+
     // row pipeline: the neighbour index of a tile's row is loaded a tile before its first-layer row is gathered (at the
     // end of layer 2 of the tile before), which is formed during layer 3 of that tile
     int ql_cur, ql_next = 0, env_next = 0, k_next = 0;
@@ -1126,8 +1171,19 @@ __global__ void __launch_bounds__(64 * v2::WV) __attribute__((amdgpu_waves_per_e
         if (mm % 6 < 4 && n + RD < 16) fetch2_part(n + RD, mm % 6);  // (the ring never holds more than RS = RD + 1 steps)
         a2[2 * pair + o] = mfma_bf16(as_bf(ring[n % RS][2 * o + (pass == 1 ? 1 : 0)]),
                                      pass == 2 ? l1[s >> 1][s & 1] : h1[s >> 1][s & 1], a2[2 * pair + o]);
+#if MPX_V2_SMOOTH
+        // pair A's accumulators are final after MFMA 47: their relu + split rides behind pair B's MFMAs, one HALF quantum
+        // per gap in two gaps of three; the third kind of gap (no weight fetch: mm % 6 >= 4) carries one load of the
+        // next tile's rows, consumed from output pair 1 of layer 3 on
+        if (pair == 1 && mm % 3 != 0) {
+          const int hh = (mm / 3) * 2 + (mm % 3 - 1), q = hh >> 1;
+          split_h(a2[q >> 3], h2[q >> 3], l2[q >> 3], q & 7, hh & 1);
+        }
+        if (pair == 1 && mm % 6 >= 4) gather_part(env_gather, k_gather, (mm / 6) * 2 + (mm % 6 - 4));
+#else
         // pair A's accumulators are final after MFMA 47: their relu + split rides behind pair B's MFMAs (16 quanta)
         if (pair == 1 && mm % 3 == 2) split_q(a2[(mm / 3) >> 3], h2[(mm / 3) >> 3], l2[(mm / 3) >> 3], (mm / 3) & 7);
+#endif
         V2_FENCE();
       }
       stamp();
@@ -1175,18 +1231,68 @@ __global__ void __launch_bounds__(64 * v2::WV) __attribute__((amdgpu_waves_per_e
           }
         }
       };
+      float gmb[2][4];  // group maxima of the output pair being pooled (pool_gm / pool_fin: pool() in five pieces)
+      auto pool_gm = [&](int pr, int part, int jj) __attribute__((always_inline)) {
+        const f32x16 &a = a3[pr & 1][part];
+        gmb[part][jj] = fmaxf(fmaxf(a[4 * jj], a[4 * jj + 1]), fmaxf(a[4 * jj + 2], a[4 * jj + 3]));
+        asm volatile("" : "+v"(gmb[part][jj]));
+      };
+      auto pool_fin = [&](int pr, int part) __attribute__((always_inline)) {
+        const int ot = 2 * pr + part;
+        const float *gm = gmb[part];
+        if (gq[7] == cur) {  // the whole tile belongs to the query being merged (the common case)
+          run[ot] = fmaxf(run[ot], fmaxf(fmaxf(gm[0], gm[1]), fmaxf(gm[2], gm[3])));
+        } else {
+          int c = cur;
+#pragma unroll
+          for (int g = 0; g < 8; ++g) {
+            if (gq[g] != c) {
+              flush(ot, c);
+              c = gq[g];
+            }
+            run[ot] = fmaxf(run[ot], ((g & 1) == half) ? gm[g >> 1] : -__builtin_inff());
+          }
+        }
+      };
       V2_FENCE();
 #pragma unroll
       for (int m = 0; m < 192; ++m) {
         const int pr = m / 48, mm = m % 48, s = mm / 6, pass = (mm % 6) / 2, o = mm % 2, n3 = pr * 8 + s;
         if (mm % 6 < 4 && n3 + 2 < 32) load3_part(n3 + 2, mm % 6);
+#if !MPX_V2_SMOOTH
         if (m >= 4 && m < 4 + 2 * (C1 / 8) && (m & 1) == 0) gather_part(env_gather, k_gather, (m - 4) >> 1);  // the next tile's rows
+#endif
         {
           const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
           const bf16x8 x = pass == 2 ? l2[s >> 1][s & 1] : h2[s >> 1][s & 1];
           const bf16x8 w = w3r[n3 % 3][2 * o + (pass == 1 ? 1 : 0)];
           a3[pr & 1][o] = mfma_bf16(x, w, (s == 0 && pass == 0) ? zero : a3[pr & 1][o]);
         }
+#if MPX_V2_SMOOTH
+        // fillers, one small piece per gap:
+        if (pr == 0) {  // pair B's split in half quanta: tile 2 in gaps 0..15 (needed from s = 4), tile 3 in gaps 16..31
+          if (mm < 32) split_h(a2[2 + mm / 16], h2[2 + mm / 16], l2[2 + mm / 16], (mm % 16) >> 1, mm & 1);
+          if (mm == 40) load_cq(cq_next, 0);
+        } else {
+          // pooling of the pair before, in the gaps with mm % 3 == 0: the four group maxima of a tile one per gap, then
+          // the merge into the running maximum (or the flushes of a tile with a query boundary)
+          if (mm % 3 == 0 && mm < 30) {
+            const int step = mm / 3, part = step / 5, piece = step % 5;
+            if (piece < 4) pool_gm(pr - 1, part, piece);
+            else pool_fin(pr - 1, part);
+          }
+          // the NEXT tile's layer-2 operands in half quanta: 32 halves in output pair 1 (two gaps of three), 16 each in
+          // pairs 2 and 3 (one gap of three)
+          if (pr == 1 && mm % 3 != 0) {
+            const int hh = (mm / 3) * 2 + (mm % 3 - 1);
+            form_h(cq_next, hh >> 1, hh & 1);
+          }
+          if (pr >= 2 && mm % 3 == 1) {
+            const int hh = 32 + (pr - 2) * 16 + mm / 3;
+            form_h(cq_next, hh >> 1, hh & 1);
+          }
+        }
+#else
         // fillers, by position in the tile:
         if (pr == 0) {  // pair B's split: tile 2 behind the first 12 MFMAs (needed from s = 4), tile 3 behind the next 12
           if (mm < 24 && mm % 3 == 0) split_q(a2[2 + mm / 12], h2[2 + mm / 12], l2[2 + mm / 12], (mm % 12) / 3 * 2);
@@ -1199,12 +1305,23 @@ __global__ void __launch_bounds__(64 * v2::WV) __attribute__((amdgpu_waves_per_e
           // layer 2)
           if (pr >= 2 && mm % 3 == 1) form_q(cq_next, (pr - 2) * 16 + mm / 3);
         }
+#endif
         // the first layer-2 stages of the NEXT tile (the weights never change): one block per gap over the last MFMAs
         if (m >= 192 - 4 * RD) fetch2_part((m - (192 - 4 * RD)) >> 2, (m - (192 - 4 * RD)) & 3);
         V2_FENCE();
       }
+#if MPX_V2_SMOOTH
+#pragma unroll
+      for (int part = 0; part < 2; ++part) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) pool_gm(3, part, jj);
+        pool_fin(3, part);
+      }
+      (void)pool;
+#else
       pool(3, 0);
       pool(3, 1);
+#endif
       cur = gq[7];
       stamp();
       stamp();  // (back to back: the cost of a stamp itself)
