@@ -137,6 +137,10 @@ def cpu_baseline(prob, model, n_env: int):
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector peak (64 FLOP / clk / SIMD)
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak at 2.4 GHz
+# what the chip SUSTAINS on a bare v_mfma_f32_32x32x16_bf16 stream (256 CUs x 4 waves, nothing in the gaps): the stream
+# issues at its 32-cycle floor while the clock falls to 1.48 GHz -- measured on the bench box, tools/probes/
+# mfma_bf16_stream.hip, profiles/r04_other_measurements.md (the fp32 pipe holds 155 of its 157.3 TF: mfma_f32_peak.hip)
+BF16_MFMA_SUSTAINED_TFLOPS = 1550.0
 TRAFFIC_RECORD = "r04_traffic.json"  # written by tools/pmc_traffic.py from the PMC passes of this round
 FAST_RECORD = "r04_fast_traffic.json"  # the same for the bf16x3 kernels (tools/pmc_fast.py)
 
@@ -219,6 +223,8 @@ def fast_roofline(B, live_ms, live_flops):
     out = {"kernel": "sa2_bf16x3_persistent_kernel", "bound": "mfma", "achieved": live_flops / (live_ms * 1e-3) / 1e12,
            "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": live_flops / (live_ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS,
            "ms_per_launch": live_ms, "flops_per_launch": live_flops, "clock_ghz": None, "mfma_busy_frac": None,
+           "sustained_stream_tflops": BF16_MFMA_SUSTAINED_TFLOPS,
+           "frac_of_sustained_stream": live_flops / (live_ms * 1e-3) / 1e12 / BF16_MFMA_SUSTAINED_TFLOPS,
            "frac_of_clock_adjusted_peak": None, "traffic": None}
     try:
         rec = json.load(open(os.path.join(ROOT, "profiles", FAST_RECORD)))
