@@ -46,6 +46,13 @@ def caller_golden():
 
 
 @pytest.fixture(scope="session")
+def metrics_golden():
+    """Vectors made by running the PyBullet-free methods of the reference's Evaluator (tests/golden/gen_metrics_golden.py)."""
+    path = os.path.join(ROOT, "tests", "golden", "metrics_golden.npz")
+    return dict(np.load(path, allow_pickle=False))
+
+
+@pytest.fixture(scope="session")
 def oracle():
     from oracle import oracle as orc
 

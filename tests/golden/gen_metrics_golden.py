@@ -1,0 +1,86 @@
+"""Generates tests/golden/metrics_golden.npz by IMPORTING AND RUNNING the PyBullet-free methods of the reference's
+``Evaluator`` (mpinets/metrics.py): ``violates_joint_limits`` (:311-322), ``check_final_position`` (:338-347),
+``check_final_orientation`` (:349-361), ``check_final_region`` (:363-384), ``calculate_smoothness`` (:387-409) and
+``calculate_eff_path_lengths`` (:410-434).
+
+Runs only in the build container (needs /root/reference); only the .npz is committed.  Stubs: those of
+gen_caller_golden.py (robofin's ``FrankaRobot.fk`` = the oracle FK as an SE3 with the three pyquaternion operations the
+methods use, ``within_limits`` on this repo's published-limit table, geometrout primitives = mpinets_amd.primitives; Bullet /
+termcolor / the collision checker: empty).  What executes is the reference's own: units (centimetres, degrees), the order of
+the quaternion products, the path-length sums, the speed profiles and sampling rate handed to its own sparc(), the
+target / negative volume logic.
+
+    python tests/golden/gen_metrics_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import gen_caller_golden as gc  # noqa: E402  (stubs + sys.path)
+
+from mpinets_amd import franka_tables as ft  # noqa: E402
+from mpinets_amd import primitives, scenes  # noqa: E402
+
+
+def main():
+    gc.install_stubs()
+    rr = sys.modules["robofin.robots"]
+    lim = ft.JOINT_LIMITS_PUBLISHED
+    rr.FrankaRobot.within_limits = staticmethod(lambda q: bool(np.all(np.asarray(q) >= lim[:, 0]) and np.all(np.asarray(q) <= lim[:, 1])))
+    import mpinets.metrics as ref
+
+    Ev = ref.Evaluator
+    B, T, dt = 10, 40, 0.12  # (run_inference.py evaluates at dt = 0.12 s)
+    traj = scenes.linear_trajectories(B, T, 71).astype(np.float64)
+    rng = np.random.default_rng(72)
+    traj += 0.02 * rng.standard_normal(traj.shape)  # not a straight line: the smoothness has something to measure
+    traj[1, 7, 2] = 3.4  # outside the limits
+    traj[4, :, :] = traj[4, :1, :]  # a trajectory that does not move (sparc's all-zero branch)
+    lengths = np.array([T, T, 5, 2, T, 17, T, 31, 9, T], np.int32)
+    goals = scenes.random_configurations(B, 73).astype(np.float64)
+    goals[6] = traj[6, lengths[6] - 1]  # ends exactly on its target
+    out = {"traj": traj.astype(np.float32), "lengths": lengths, "goals": goals.astype(np.float32), "dt": np.float64(dt)}
+    # target / negative volumes around some final positions
+    tv_c, tv_d, nv_c, nv_d = [], [], [], []
+    res = {k: [] for k in ("position_error", "orientation_error", "joint_limit_violation", "eff_position_path_length",
+                           "eff_orientation_path_length", "config_smoothness", "eff_smoothness", "correct_final_region")}
+    for b in range(B):
+        tr = [traj[b, t].astype(np.float32) for t in range(lengths[b])]  # (float32 like the engine's input)
+        final, target = gc.fk_se3(tr[-1]), gc.fk_se3(goals[b].astype(np.float32))
+        res["position_error"].append(Ev.check_final_position(final, target))
+        res["orientation_error"].append(Ev.check_final_orientation(final.so3, target.so3))
+        res["joint_limit_violation"].append(Ev.violates_joint_limits(tr))
+        pp, po = Ev.calculate_eff_path_lengths(None, tr)
+        res["eff_position_path_length"].append(pp)
+        res["eff_orientation_path_length"].append(po)
+        if len(tr) >= 2:
+            cs, es = Ev.calculate_smoothness(tr, dt)
+        else:
+            cs = es = 0.0
+        res["config_smoothness"].append(cs)
+        res["eff_smoothness"].append(es)
+        # region: a target box around the final position for even b (hit), around the target for odd b (usually missed);
+        # one negative box far away and, for b % 3 == 0, one around the final position (violated)
+        c_t = final._xyz if b % 2 == 0 else target._xyz
+        tv_c.append(c_t), tv_d.append([0.1, 0.12, 0.08])
+        neg = [primitives.Cuboid(final._xyz + 1.0, [0.1, 0.1, 0.1]),
+               primitives.Cuboid(final._xyz if b % 3 == 0 else final._xyz - 1.0, [0.05, 0.05, 0.05])]
+        nv_c.append([n.center for n in neg]), nv_d.append([n.dims for n in neg])
+        res["correct_final_region"].append(bool(Ev.check_final_region(final, primitives.Cuboid(c_t, [0.1, 0.12, 0.08]), neg)))
+    for k, v in res.items():
+        out["m_" + k] = np.asarray(v)
+    out.update(tv_centers=np.asarray(tv_c, np.float32), tv_dims=np.asarray(tv_d, np.float32),
+               nv_centers=np.asarray(nv_c, np.float32), nv_dims=np.asarray(nv_d, np.float32))
+    assert out["m_joint_limit_violation"][1] and not out["m_joint_limit_violation"].all()
+    assert out["m_position_error"][6] < 1e-3 and 0 < out["m_correct_final_region"].sum() < B
+    np.savez_compressed(os.path.join(HERE, "metrics_golden.npz"), **out)
+    for k in sorted(out):
+        if k.startswith("m_"):
+            print(k, np.round(out[k].astype(np.float64), 3))
+
+
+if __name__ == "__main__":
+    main()

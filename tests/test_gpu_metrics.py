@@ -138,3 +138,38 @@ def test_smoothness_on_the_device_matches_the_oracle(oracle):
     assert 0.0 <= m["is smooth"] <= 100.0 and m["total"] == B and "average eff sparc" in m
     # without dt the result carries no smoothness (and the summary no smoothness lines)
     assert "is smooth" not in BatchedEvaluator.metrics(ev.evaluate_trajectories(tt, targets, ln))
+
+
+def test_batched_evaluator_matches_the_reference_evaluator(metrics_golden):
+    """BatchedEvaluator.evaluate_trajectories vs vectors produced by RUNNING the reference's Evaluator methods
+    (tests/golden/gen_metrics_golden.py): errors, path lengths, joint-limit flag, target / negative volume logic, SPARC."""
+    from mpinets_amd import franka_tables as ft
+    from mpinets_amd.geometry import TorchCuboids
+    from mpinets_amd.metrics import BatchedEvaluator
+    from mpinets_amd.robot import franka_fk, frames_to_matrix
+
+    g = metrics_golden
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev())
+    B = g["traj"].shape[0]
+    targets = frames_to_matrix(franka_fk(T(g["goals"]))[:, ft.LINK_ID["right_gripper"]]).contiguous()
+    unit = lambda n: T(np.tile(np.float32([1, 0, 0, 0]), (B, n, 1)))
+    tv = TorchCuboids(T(g["tv_centers"][:, None]), T(g["tv_dims"][:, None]), unit(1))
+    nv = TorchCuboids(T(g["nv_centers"]), T(g["nv_dims"]), unit(2))
+    ev = BatchedEvaluator(dev())
+    got = ev.evaluate_trajectories(T(g["traj"]), targets, T(g["lengths"]), target_volume=tv, negative_volumes=nv,
+                                   dt=float(g["dt"]))
+    c = lambda k: got[k].cpu().numpy()
+    np.testing.assert_allclose(c("position_error"), g["m_position_error"], rtol=0, atol=2e-3)
+    np.testing.assert_allclose(c("orientation_error"), g["m_orientation_error"], rtol=0, atol=6e-2)
+    np.testing.assert_allclose(c("eff_position_path_length"), g["m_eff_position_path_length"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(c("eff_orientation_path_length"), g["m_eff_orientation_path_length"], rtol=1e-4, atol=5e-2)
+    np.testing.assert_array_equal(c("joint_limit_violation"), g["m_joint_limit_violation"].astype(bool))
+    # the negative volume around the final position of environments 0, 3, 6, 9 contains the TARGET only for 6 (which ends
+    # on its target): the reference's evaluate_trajectory drops such volumes first (metrics.py:507-512); check_final_region
+    # itself -- what the golden ran -- does not, so environment 6 is compared after the same correction
+    ref_region = g["m_correct_final_region"].astype(bool).copy()
+    ref_region[6] = True
+    np.testing.assert_array_equal(c("correct_final_region"), ref_region)
+    ok = g["lengths"] >= 2
+    np.testing.assert_allclose(c("config_smoothness")[ok], g["m_config_smoothness"][ok], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(c("eff_smoothness")[ok], g["m_eff_smoothness"][ok], rtol=0, atol=2e-3)
