@@ -39,6 +39,7 @@ import seeded_weights  # noqa: E402
 
 NR, NS, NT = 2048, 4096, 128
 SUBSETS = []  # every column subset the stub sampler drew, in call order
+FIXED_SUBSETS = []  # ... and the fixed subsets of samplers built with num_fixed_points
 
 
 # ------------------------------------------------------------------------------------------------ stubs
@@ -92,8 +93,14 @@ class _FrankaSampler:
     def __init__(self, device, num_fixed_points=None, use_cache=False, with_base_link=True):
         self.pts, self.link = ft.link_point_table(4096, with_base_link)
         self.eef = ft.end_effector_point_table()
+        self.fixed = None
+        if num_fixed_points is not None:  # (loss.py:142-147: one subset for the sampler's lifetime)
+            self.fixed = np.random.choice(len(self.pts), num_fixed_points, replace=False).astype(np.int32)
+            FIXED_SUBSETS.append(self.fixed)
 
     def sample(self, q, num_points=None):
+        if self.fixed is not None:  # differentiable: the losses back-propagate through the robot cloud
+            return oracle.robot_cloud_torch(q, self.pts, self.link, self.fixed)
         sub = np.random.choice(len(self.pts), num_points, replace=False).astype(np.int32)
         SUBSETS.append(sub)
         T = oracle.franka_fk(q.detach().numpy())
@@ -318,6 +325,28 @@ def main():
     for k in SCENE_KEYS:
         out["c_" + k] = scn2[k]
     print("validation (reduce only): flags", out["c_flags"].astype(int), "rate", out["c_rate"])
+
+    # E) training_step (model.py:185-240) + backward: the loss the reference returns (its own losses, weights 1 : 5 like
+    #    jobconfig.yaml) and the gradients autograd gives for a few parameters of every part of the network
+    tm = ref_model.TrainingMotionPolicyNetwork(NR, 1.0, 5.0)
+    tm.load_state_dict({k: torch.as_tensor(v) for k, v in sd.items()}, strict=True)
+    tm.train()
+    sup = np.clip(qn[:2] + np.float32(0.05) * rng.standard_normal((2, 7)).astype(np.float32), -1, 1).astype(np.float32)
+    tb = {k: torch.as_tensor(scn[k][:2]) for k in SCENE_KEYS}
+    tb.update(xyz=torch.as_tensor(xyz[:2].copy()), configuration=torch.as_tensor(qn[:2].copy()), supervision=torch.as_tensor(sup))
+    np.random.seed(9)
+    with torch.enable_grad():
+        loss = tm.training_step(tb, 0)
+        loss.backward()
+    grads = dict(tm.named_parameters())
+    out.update(t_supervision=sup, t_loss=loss.detach().numpy(), t_fixed_subset=FIXED_SUBSETS[-1])
+    for name in ("decoder.6.weight", "decoder.0.bias", "feature_encoder.0.weight", "point_cloud_encoder.fc_layer.1.weight",
+                 "point_cloud_encoder.fc_layer.6.bias", "point_cloud_encoder.SA_modules.0.mlps.0.0.weight",
+                 "point_cloud_encoder.SA_modules.1.mlps.0.2.bias", "point_cloud_encoder.SA_modules.2.mlps.0.4.bias"):
+        gr = grads[name].grad.numpy()
+        assert np.isfinite(gr).all() and np.abs(gr).max() > 0, name
+        out["t_grad." + name] = gr
+    print("training_step: loss", float(out["t_loss"]), {k[7:]: float(np.abs(v).max()) for k, v in out.items() if k.startswith("t_grad.")})
 
     np.savez_compressed(os.path.join(HERE, "model_golden.npz"), **out)
     print("wrote model_golden.npz:", os.path.getsize(os.path.join(HERE, "model_golden.npz")) // 1024, "KB;",

@@ -259,3 +259,31 @@ def test_validation_closed_loop_steps_teacher_forced(model_golden, mdl):
     print("teacher-forced validation steps vs reference-run golden: %.2e" % worst)
     assert worst <= TOL
     assert ft.JOINT_LIMITS_REAL.shape == (7, 2)
+
+
+def test_training_step_loss_and_gradients(model_golden):
+    """model.py:185-240 + backward on the device vs the reference's own training_step + autograd (weights 1 : 5):
+    np.random.seed(9) makes the loss container draw the fixed 1024-point subset the reference run drew (asserted)."""
+    from mpinets_amd.model import TrainingMotionPolicyNetwork
+
+    g = model_golden
+    tm = TrainingMotionPolicyNetwork(NR, 1.0, 5.0)
+    tm.load_state_dict({k: torch.from_numpy(v) for k, v in golden_state_dict(g).items()}, strict=True)
+    tm = tm.to(dev()).train()
+    batch = {k: T(g["v_" + k][:2]) for k in SCENE_KEYS}
+    batch.update(xyz=T(g["f_xyz"][:2].copy()), configuration=T(g["f_q"][:2].copy()), supervision=T(g["t_supervision"]))
+    np.random.seed(9)
+    loss = tm.training_step(batch, 0)
+    np.testing.assert_array_equal(tm.loss_fun.fk_sampler._fixed.cpu().numpy(), g["t_fixed_subset"])
+    loss.backward()
+    print("training_step loss: HIP %.8f, reference %.8f" % (loss.item(), float(g["t_loss"])))
+    assert abs(loss.item() - float(g["t_loss"])) < 1e-5
+    grads = dict(tm.named_parameters())
+    worst = 0.0
+    for k in g:
+        if k.startswith("t_grad."):
+            ref, mine = g[k], grads[k[7:]].grad.cpu().numpy()
+            err, scale = np.abs(mine - ref).max(), np.abs(ref).max()
+            worst = max(worst, err / scale)
+            assert err <= 2e-4 * scale + 1e-9, (k, err, scale)
+    print("worst relative gradient error vs the reference's autograd: %.2e" % worst)

@@ -145,3 +145,32 @@ def test_validation_closed_loop_steps_teacher_forced(oracle, model_golden, sd):
         dq, _ = oracle.policy_forward(sd, slab, qn)
         nxt = oracle.unnormalize(np.clip(qn + dq, -1, 1).astype(np.float32), lim)
         np.testing.assert_allclose(nxt, traj[:, i + 1], rtol=0, atol=5 * TOL)
+
+
+def test_training_step_loss_and_gradients(oracle, model_golden, sd):
+    """model.py:185-240 + backward, run by the reference (losses 1 : 5 like jobconfig.yaml): the oracle's float64 autograd
+    restatement gives the same loss and the same gradients for parameters of every part of the network."""
+    import torch
+
+    from mpinets_amd import franka_tables as ft
+
+    g = model_golden
+    leaf = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in sd.items()}
+    q = torch.tensor(g["f_q"][:2], dtype=torch.float64)
+    y = torch.clamp(q + oracle.policy_forward_torch(leaf, g["f_xyz"][:2], q), -1, 1)
+    lim = torch.tensor(ft.JOINT_LIMITS_REAL, dtype=torch.float64)
+    unnorm = lambda x: (x + 1) * (lim[:, 1] - lim[:, 0]) / 2 + lim[:, 0]
+    pts, link = ft.link_point_table(4096, with_base_link=False)
+    cloud = oracle.robot_cloud_torch(unnorm(y), pts, link, g["t_fixed_subset"])
+    target = oracle.robot_cloud_torch(unnorm(torch.tensor(g["t_supervision"], dtype=torch.float64)), pts, link, g["t_fixed_subset"])
+    t64 = lambda k: torch.tensor(g["v_" + k][:2], dtype=torch.float64)
+    cf = torch.tensor(oracle.inv_frames_4x4(g["v_cuboid_centers"][:2], g["v_cuboid_quats"][:2]), dtype=torch.float64)
+    yf = torch.tensor(oracle.inv_frames_4x4(g["v_cylinder_centers"][:2], g["v_cylinder_quats"][:2]), dtype=torch.float64)
+    coll = oracle.collision_loss_torch(cloud, cf, t64("cuboid_dims"), yf, t64("cylinder_radii")[..., 0], t64("cylinder_heights")[..., 0])
+    loss = oracle.point_match_loss_torch(cloud, target) + 5.0 * coll
+    loss.backward()
+    assert abs(loss.item() - float(g["t_loss"])) < 2e-6
+    for k in g:
+        if k.startswith("t_grad."):
+            ref, mine = g[k], leaf[k[7:]].grad.numpy()
+            assert np.abs(mine - ref).max() <= 2e-4 * np.abs(ref).max() + 1e-9, (k, np.abs(mine - ref).max(), np.abs(ref).max())
