@@ -30,6 +30,8 @@ import tempfile
 import types
 from pathlib import Path
 
+sys.dont_write_bytecode = True  # importing the reference must not leave __pycache__ in /root/reference
+
 import numpy as np
 import torch
 

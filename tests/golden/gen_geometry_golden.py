@@ -15,6 +15,8 @@ import random
 import sys
 import types
 
+sys.dont_write_bytecode = True  # importing the reference must not leave __pycache__ in /root/reference
+
 import numpy as np
 import torch
 

@@ -15,6 +15,8 @@ target / negative volume logic.
 import os
 import sys
 
+sys.dont_write_bytecode = True  # importing the reference must not leave __pycache__ in /root/reference
+
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))

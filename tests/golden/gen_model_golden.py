@@ -24,6 +24,8 @@ import os
 import sys
 import types
 
+sys.dont_write_bytecode = True  # importing the reference must not leave __pycache__ in /root/reference
+
 import numpy as np
 import torch
 from torch import nn

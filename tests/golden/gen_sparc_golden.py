@@ -9,8 +9,11 @@ import contextlib
 import importlib.util
 import io
 import os
+import sys
 
 import numpy as np
+
+sys.dont_write_bytecode = True  # importing the reference must not leave __pycache__ in /root/reference
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 spec = importlib.util.spec_from_file_location("ref_sparc", "/root/reference/mpinets/third_party/sparc.py")
