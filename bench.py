@@ -287,7 +287,6 @@ def main():
     ap.add_argument("--static-steps", type=int, default=2, help="steps of the extra without scene re-render on tabletop-only scenes (BASELINE config 3 shape at this batch size); 0 = skip")
     ap.add_argument("--all-slots-steps", type=int, default=2, help="steps of the worst-case extra: padding elision off, all 128 slots per neighbourhood (0 = skip)")
     ap.add_argument("--whole-batch-steps", type=int, default=0, help="opt-in extra: steps of the whole 65 536-environment configs[4] batch on this one GPU (0 = skip; 17 GB: the encoder works in slabs of 8192 environments)")
-    ap.add_argument("--pipeline-steps", type=int, default=3, help="steps of the two-stream pipelined measurement of the headline workload (0 = skip)")
     ap.add_argument("--cpu-envs", type=int, default=512, help="env-steps in the CPU baseline sample (0 = skip)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak (default): --envs environments per GPU; strong: --global-envs environments split evenly over the GPUs")
@@ -426,32 +425,6 @@ def main():
                                          "c2_envs": n2, "c2_ms": c2_ms, "c2_gflop": collision_flops(prob, slice(0, n2), 1) / 1e9})
         collision = {"records": col_recs, "c4_rate": None if flags4 is None else float((flags4 != 0).float().mean())}
         del traj, q1k, cub4, cyl4, cub2, cyl2
-
-    # ---- extra: the SAME headline workload with the batch cut into two shares on two HIP streams, one a stage behind
-    # the other (PipelinedRollout): share B's sampling kernels run while share A is in its matrix kernels.  All ranks.
-    pipelined = None
-    if args.pipeline_steps > 0:
-        from mpinets_amd.rollout import PipelinedRollout
-
-        prob_p = make_problem_batch(B, seed=1000, device=dev, kinds=("tabletop", "cubby", "dresser"), M1=40, M2=16,
-                                    scene_pool=args.scene_pool, device_clouds=True, env_offset=envs.start,
-                                    total_envs=global_envs)
-        pr = PipelinedRollout(model, prob_p, ways=2, rerender_scene=True, scene_seed=17, resample_subset=True, subset_seed=23)
-        pr.run(args.warmup + 1)
-        torch.cuda.synchronize()
-        shard.barrier()
-        tp0 = time.perf_counter()
-        pr.run(args.pipeline_steps)
-        torch.cuda.synchronize()
-        shard.barrier()
-        el_p = shard.max_over_ranks(time.perf_counter() - tp0, dev)
-        pipelined = {"ways": 2, "steps": args.pipeline_steps, "ms_per_step": el_p / args.pipeline_steps * 1e3,
-                     "env_steps_per_s": global_envs * args.pipeline_steps / el_p, "dtype": "f32",
-                     "what": "the headline workload with the batch in two shares on two HIP streams, one a stage behind "
-                             "the other (mpinets_amd.rollout.PipelinedRollout); state bit-identical to the single-stream "
-                             "run (tools/pipeline_timing.py).  The matrix kernels leave only 32 VGPRs per SIMD free, so a "
-                             "sampling workgroup cannot share a CU with them: the two streams mostly time-slice"}
-        del pr, prob_p
 
     # ---- extra: the same closed-loop step WITHOUT the scene re-render, on tabletop-only scenes (16 cuboids + 16
     # cylinders): the reference's rollout re-samples only the robot points (model.py:180-181); all ranks, weak scaling
@@ -769,8 +742,6 @@ def main():
     }
     if extra:
         out["extra_configs"] = extra
-    if pipelined is not None:
-        out["pipelined_two_streams"] = pipelined
     if all_slots is not None:
         out["all_slots"] = all_slots
     if whole is not None:

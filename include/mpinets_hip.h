@@ -87,7 +87,9 @@ int mpx_franka_spheres(const float *q, int B, float finger, const float *sph_cen
 /* Fused swept-sphere collision check, model.py:293-314, for q [B,T,7]:
  *   flags[b] |= any_{t,s} min(cuboid_sdf, cylinder_sdf)(centre[b,t,s]) <= sph_radii[s]
  * flags int32 [B] is OR-ed into (caller zeroes it); min_sdf [B,T,S] optional (may be NULL).
- * Either primitive set may be empty (M = 0).                                                */
+ * Either primitive set may be empty (M = 0).  The frame arrays are read fastest when they are
+ * 16-byte aligned (the classes' inv_frames always are); unaligned pointers are accepted and
+ * take a slower kernel with the same results.                                                */
 int mpx_franka_collision(const float *q, int B, int T, float finger, const float *sph_centers,
                          const float *sph_radii, const int32_t *sph_link, int S,
                          const float *cub_frames, const float *cub_dims, int M1,

@@ -401,7 +401,12 @@ MPX_EXPORT int mpx_franka_collision(const float *q, int B, int T, float finger, 
   MPX_REQUIRE(B >= 0 && T >= 0 && S >= 0 && M1 >= 0 && M2 >= 0, "mpx_franka_collision: negative size");
   MPX_REQUIRE((int64_t)B * T < (int64_t)1 << 31, "mpx_franka_collision: B*T overflows int32");
   if (B == 0 || T == 0 || S == 0) return 0;
-  if (M1 <= 64 && M2 <= 64 && S <= 64) {  // per-environment form: masks in two scalar words, pairs flattened over the lanes
+  // (the per-environment kernel stages the 4x4 frames as float4 rows: a frame pointer that is not 16-byte aligned -- a
+  // tensor view with an odd storage offset -- takes the general kernel below, which reads them with scalar loads)
+  const bool frames_aligned = (((uintptr_t)cub_frames | (uintptr_t)cyl_frames) & 15) == 0;
+  static_assert(MPX_COL_TC >= 1 && MPX_COL_TC <= 64 && MPX_COL_TC * 64 <= 16 * 256,
+                "MPX_COL_TC: FK runs on one thread per waypoint of a chunk and a thread holds at most 16 (waypoint, sphere) pairs");
+  if (M1 <= 64 && M2 <= 64 && S <= 64 && frames_aligned) {  // per-environment form: masks in two scalar words, pairs flattened over the lanes
 #define COL_ENV(BLOCK, TC, PPT)                                                                                        \
   do {                                                                                                                 \
     const int chunks = cdiv(T, TC);                                                                                    \

@@ -832,7 +832,7 @@ static_assert(Cfg::ST2 == 32 && Cfg::ST3 == 64 && Cfg::KS1 == 8 && Cfg::KS2 == 8
 // Unit queues of the persistent kernel: 8 counters (one per XCD) per launch, in device memory that belongs to the
 // library image (nothing is allocated).  ONE SLOT PER (device, stream): the launches of a stream are ordered (memset,
 // kernel, memset, kernel, ...), so they can share a slot, and launches on different streams never alias -- two engines
-// that share a model on two streams (rollout.PipelinedRollout) each get their own counters.  The slot is zeroed on the
+// that share a model on two streams each get their own counters.  The slot is zeroed on the
 // launch stream in front of the kernel (stream-ordered, hipGraph-capturable).  Limits, stated in include/mpinets_hip.h:
 // 256 distinct (device, stream) handles per process get a slot; a later handle gets NONE (`*exhausted` = 1, nullptr):
 // slots are never shared between streams -- two persistent kernels on one set of counters would each skip the units

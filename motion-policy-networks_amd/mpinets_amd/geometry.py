@@ -63,6 +63,17 @@ class TorchSpheres(_FramedPrimitives):
         # kept verbatim in meaning: the reference uses r**3 here (geometry.py:66)
         return 4 * np.pi * torch.pow(self.radii, 3)
 
+    def sample_surface(self, num_points: int) -> torch.Tensor:
+        """Samples points from all spheres, including ones with zero volume (geometry.py:69-85): [B, M, num_points, 3].
+
+        Same draw as the reference under the same ``torch.manual_seed``: it calls ``torch.rand`` without a device, i.e.
+        on the global CPU generator, normalises the [0,1)^3 samples (the positive octant only -- kept) and scales them.
+        Off the hot path (no caller in model / loss / loaders): plain torch on the spheres' device."""
+        B, M, _ = self.centers.shape
+        unnormalized = torch.rand((B, M, num_points, 3)).to(self.centers.device)
+        normalized = unnormalized / torch.linalg.norm(unnormalized, dim=-1)[:, :, :, None]
+        return normalized * self.radii[:, :, None, :] + self.centers[:, :, None, :]
+
     def _sdf(self, points: torch.Tensor) -> torch.Tensor:
         p, oshape, P = self._flatten(points)
         B, M, _ = self.radii.shape

@@ -69,7 +69,6 @@ class MPiNetsPointNet(nn.Module):
             nn.LeakyReLU(inplace=True),
             nn.Linear(2048, 2048),
         )
-        self.after_sampling = None  # optional callable, invoked once SA1's sampling + neighbour search are enqueued
         self._sa3_w0 = None  # first group-all layer with K padded 259 -> 272 (whole 16-float slabs: direct-to-LDS GEMM)
         self._sa3_pk = None  # (key, mpx_sa3_pack_weights of the group-all module)
         self.dense_precision = "fp32"  # "bf16x3": the large dense layers on the bf16 matrix cores (set_precision)
@@ -312,8 +311,6 @@ class MPiNetsPointNet(nn.Module):
         def module_sa1():
             lib.call(bq1, lib.ptr(xyz1), 3, lib.ptr(pc), 4, B, N, sa1.npoint, float(sa1.radius),
                      sa1.nsample, lib.ptr(nbr1), lib.ptr(cnt1))
-            if self.after_sampling is not None:  # (PipelinedRollout: the next share may start its own sampling now)
-                self.after_sampling()
             # (SA1 also completes its rows to [f1 | xyz1 | 0] when SA2's first layer is evaluated per point)
             state["centre_done"] = launch_sa(sa1.precision, lib.ptr(pc), 4, lib.ptr(xyz1), 3, lib.ptr(pc) + 12, 4, 1, nbr1,
                                              cnt1 if sa1.elide_padding else None, B, N, sa1.npoint, sa1.nsample, w1,
@@ -464,17 +461,6 @@ class MotionPolicyNetwork(nn.Module):
         self._q_w0 = None
         return self
 
-    def cache_signature(self) -> tuple:
-        """What the derived weight buffers depend on: the parameters' storage and versions and the arithmetic switches.
-        The buffers are (re)built lazily by kernels on whichever stream first misses them; a caller that runs ONE model
-        on several streams (rollout.PipelinedRollout) compares signatures to know when a rebuild is about to happen and
-        orders the streams around it."""
-        enc = self.point_cloud_encoder
-        return (tuple((p.data_ptr(), p._version) for p in self.parameters()),
-                tuple((sa.precision, getattr(sa, "factored", None)) for sa in enc.SA_modules), enc.dense_precision,
-                tuple(len(sa._packed.packs) for sa in enc.SA_modules), enc._sa3_w0 is None, enc._sa3_pk is None,
-                self._q_w0 is None)
-
     def configure_optimizers(self):
         return torch.optim.Adam(self.parameters(), lr=1e-4)
 
@@ -582,10 +568,6 @@ class MotionPolicyNetwork(nn.Module):
         if aux is not None:
             aux["encoding"] = cat[:, :2048]
         dq = self.decode(cat)
-        # every derived weight buffer this configuration needs now exists (built by launches on the current stream):
-        # rollout.PipelinedRollout compares this with cache_signature() to know whether its streams must be ordered
-        # around a rebuild
-        self._warm_signature = self.cache_signature()
         return dq
 
     def encode_configuration(self, q: torch.Tensor, out: Optional[torch.Tensor] = None):

@@ -233,105 +233,6 @@ class RolloutEngine:
         return torch.stack(traj, dim=1), self.steps + 1
 
 
-class PipelinedRollout:
-    """The same closed-loop steps with the batch cut into ``ways`` contiguous shares, each advanced by its own
-    ``RolloutEngine`` on its own HIP stream, one share running a stage behind the next.
-
-    Why: the sampling kernels at the head of every step (farthest-point sampling: 511 dependent picks per
-    environment; the bucketed ball query) are latency / LDS bound and keep the matrix cores idle for ~13 % of a
-    single-stream step, while the grouped MLPs and dense layers that follow are matrix-bound.  Environments are
-    independent, so share B's sampling can run while share A is in its matrix kernels -- also ACROSS steps (share A
-    starts step t+1 while share B finishes step t): nothing joins the streams until ``run`` returns.
-    Results are bit-identical to one engine over the whole batch whenever the shares' launch shapes equal the whole
-    batch's (every share >= 1025 environments, see tests/test_gpu_shard.py): same kernels, same per-environment
-    arithmetic, draws keyed by global environment ids.
-    """
-
-    def __init__(self, model: MotionPolicyNetwork, problem: Dict[str, torch.Tensor], ways: int = 2, stagger: bool = True,
-                 **engine_args):
-        B = problem["xyz"].size(0)
-        assert 1 <= ways <= B
-        self.B, self.ways, self.stagger = B, ways, bool(stagger)
-        base = int(engine_args.pop("env_offset", None) or problem.get("env_offset", 0))
-        cuts = [B * i // ways for i in range(ways + 1)]
-        self.ranges = list(zip(cuts[:-1], cuts[1:]))
-        subset = engine_args.pop("robot_subset", None)
-        if subset is None:
-            subset = problem.get("robot_subset")
-        self.engines = []
-        for a, b in self.ranges:  # leading-dimension slices: views of the caller's tensors (the slab is updated in place)
-            share = {k: (v[a:b] if torch.is_tensor(v) and v.ndim >= 1 and v.size(0) == B and k != "robot_subset" else v)
-                     for k, v in problem.items()}
-            self.engines.append(RolloutEngine(model, share, robot_subset=subset, env_offset=base + a, **engine_args))
-            subset = self.engines[0].subset  # one robot column subset for the whole batch
-        dev = problem["xyz"].device
-        self.streams = [torch.cuda.Stream(device=dev) for _ in range(ways)]
-        self.device = dev
-        self.steps_done = 0
-
-    @torch.no_grad()
-    def run(self, steps: int) -> None:
-        """Enqueue ``steps`` closed-loop steps of every share; the caller's stream continues after all of them."""
-        cur = torch.cuda.current_stream(self.device)
-        for s in self.streams:
-            s.wait_stream(cur)
-        model = self.engines[0].model
-        enc = model.point_cloud_encoder
-        # The shares use ONE model, whose derived weight buffers (MFMA-stream packs, factored SA2 weights, bf16 pairs,
-        # padded first layers) are built lazily by kernels on the stream that first misses them -- share 0's.  The other
-        # shares then hit the host-side cache and would read those buffers on their own streams with nothing ordering
-        # them after the build.  Warmth is tracked ON THE MODEL (``_warm_signature``: set by every inference forward,
-        # whose launches the streams above are ordered after): when the cache signature differs (first use, optimizer
-        # step, set_precision, invalidate_caches ...) every other stream waits for share 0's first whole step of this
-        # call.  The stagger -- share i+1 starts once share i has issued its sampling -- applies to the first step
-        # that is not serialised that way: step 0 on a warm model, step 1 after a cold start.
-        cold = model.cache_signature() != getattr(model, "_warm_signature", None)
-        stagger_at = (1 if cold else 0) if (self.stagger and self.steps_done == 0) else -1
-        for t in range(steps):
-            for i, (e, s) in enumerate(zip(self.engines, self.streams)):
-                first = t == stagger_at and i + 1 < self.ways
-                if first:  # share i+1 starts when share i has issued its sampling and entered its matrix kernels
-                    ev = torch.cuda.Event()
-                    enc.after_sampling = lambda ev=ev: ev.record()
-                with torch.cuda.stream(s):
-                    e.step()
-                if first:
-                    enc.after_sampling = None
-                    self.streams[i + 1].wait_event(ev)
-                if cold and t == 0 and i == 0:
-                    built = torch.cuda.Event()
-                    built.record(s)
-                    for other in self.streams[1:]:
-                        other.wait_event(built)
-        self.steps_done += steps
-        for s in self.streams:
-            cur.wait_stream(s)
-
-    def step(self) -> torch.Tensor:
-        self.run(1)
-        return self.q
-
-    @staticmethod
-    def _cat(parts):
-        return torch.cat(parts, dim=0)
-
-    @property
-    def q(self) -> torch.Tensor:
-        return self._cat([e.q for e in self.engines])
-
-    @property
-    def q_norm(self) -> torch.Tensor:
-        return self._cat([e.q_norm for e in self.engines])
-
-    @property
-    def flags(self) -> torch.Tensor:
-        return self._cat([e.flags for e in self.engines])
-
-    @property
-    def has_collision(self) -> torch.Tensor:
-        return self.flags != 0
-
-
 def rollout_until_success(mdl: MotionPolicyNetwork, q0, target, point_cloud: torch.Tensor, fk_sampler: FrankaSampler,
                           max_rollout_length: int = 150) -> np.ndarray:
     """Reference signature (run_inference.py:137-191) for one problem.

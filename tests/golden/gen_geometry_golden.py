@@ -186,6 +186,14 @@ def main():
     data["mixed/shape"] = np.array(pc.shape)
     data["mixed/empty_shape"] = np.array(geometry.construct_mixed_point_cloud([], 4096).shape)
 
+    # TorchSpheres.sample_surface / surface_area, geometry.py:60-85 (torch's global CPU generator: same seed, same draw;
+    # appended after every `rng` draw above, so the older arrays keep their bytes)
+    for name in ("tabletop_yaw", "cubby_yaw_padded"):
+        sph = geometry.TorchSpheres(torch.from_numpy(data[f"{name}/sph_centers"]), torch.from_numpy(data[f"{name}/sph_radii"]))
+        torch.manual_seed(11)
+        data[f"{name}/out/sph_surface_points_seed11_n7"] = sph.sample_surface(7).numpy()
+        data[f"{name}/out/sph_surface_area"] = sph.surface_area().numpy()
+
     out = os.path.join(HERE, "geometry_golden.npz")
     np.savez_compressed(out, **data)
     print("wrote", out, os.path.getsize(out), "bytes,", len(data), "arrays")

@@ -4,6 +4,7 @@ import ctypes
 import os
 import random
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -251,3 +252,54 @@ def test_oracle_fps_and_ball_query_properties(oracle):
     y[0, 600] = [5, 0, 0]
     y[0, 90] = [5, 0, 0]  # 600 mod 512 = 88 < 90
     assert oracle.fps(y, 2)[0, 1] == 600
+
+
+def test_dataset_loader_reads_hdf5_through_h5py_when_it_is_installed(tmp_path, monkeypatch):
+    """Row N2's file seam (data_loader.py:103-122,154): `.hdf5` databases are opened with h5py when the package is
+    there and refused with a clear message when it is not (this image).  h5py itself is absent here, so the reader's
+    calls (`h5py.File(path, "r")` as a context manager, `f.keys()`, `f[key][...]`) run against a stand-in module that
+    serves the arrays of an .npz -- the reference's directory layout `<dir>/val/**/*.hdf5` included."""
+    import types
+
+    from mpinets_amd import _lib
+    from mpinets_amd.data import DatasetType, _load_arrays
+
+    rng = np.random.default_rng(0)
+    arrays = {"cuboid_dims": rng.random((4, 3, 3)).astype(np.float32), "hybrid_solutions": rng.random((4, 50, 7)).astype(np.float32)}
+    (tmp_path / "val" / "sub").mkdir(parents=True)
+    db = tmp_path / "val" / "sub" / "val.hdf5"
+    np.savez(str(db) + ".npz", **arrays)
+    os.rename(str(db) + ".npz", db)
+    monkeypatch.setitem(sys.modules, "h5py", None)  # not importable
+    with pytest.raises(_lib.MpxError, match="needs h5py"):
+        _load_arrays(db, DatasetType.VAL)
+
+    class _Dataset:
+        def __init__(self, a):
+            self.a = a
+
+        def __getitem__(self, key):
+            assert key is Ellipsis
+            return self.a
+
+    class _File:
+        def __init__(self, path, mode):
+            assert mode == "r"
+            self.z = np.load(path)
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *exc):
+            self.z.close()
+
+        def keys(self):
+            return self.z.files
+
+        def __getitem__(self, k):
+            return _Dataset(self.z[k])
+
+    monkeypatch.setitem(sys.modules, "h5py", types.SimpleNamespace(File=_File))
+    for src in (db, tmp_path):  # the file itself, and the reference's directory layout
+        got = _load_arrays(src, DatasetType.VAL)
+        assert set(got) == set(arrays) and all(np.array_equal(got[k], arrays[k]) for k in arrays)

@@ -130,6 +130,31 @@ def test_fused_collision_check_matches_oracle(oracle, B, Tn, M1, M2):
     assert not cs.check(T(traj), None, None).any()
 
 
+def test_collision_check_accepts_unaligned_frame_pointers():
+    """the per-environment kernel stages the frames as float4 rows; a caller whose inv_frames view starts at
+    an odd storage offset (raw C callers, torch slices) must get the same flags and distances, not a misaligned-access
+    fault: such pointers take the general kernel (include/mpinets_hip.h, mpx_franka_collision)."""
+    from mpinets_amd.geometry import TorchCuboids, TorchCylinders
+    from mpinets_amd.robot import FrankaCollisionSampler
+    from mpinets_amd.scenes import linear_trajectories, make_scenes
+
+    B, Tn = 6, 9
+    scn = make_scenes(B, 5, ("tabletop", "cubby"), 16, 16)
+    traj = T(linear_trajectories(B, Tn, 2))
+    cs = FrankaCollisionSampler(dev())
+    cub = TorchCuboids(T(scn["cuboid_centers"]), T(scn["cuboid_dims"]), T(scn["cuboid_quats"]))
+    cyl = TorchCylinders(T(scn["cylinder_centers"]), T(scn["cylinder_radii"]), T(scn["cylinder_heights"]), T(scn["cylinder_quats"]))
+    flags, msdf = cs.check(traj, cub, cyl, return_sdf=True)
+    for prim in (cub, cyl):  # the same frames, one float further into a larger buffer
+        buf = torch.empty(prim.inv_frames.numel() + 1, dtype=torch.float32, device=dev())
+        shifted = buf[1:].view_as(prim.inv_frames)
+        shifted.copy_(prim.inv_frames)
+        assert shifted.data_ptr() % 16 == 4
+        prim.inv_frames = shifted
+    flags2, msdf2 = cs.check(traj, cub, cyl, return_sdf=True)
+    assert torch.equal(flags, flags2) and torch.equal(msdf, msdf2)
+
+
 def test_flags_only_sweep_decides_like_the_distance_form_at_the_boundary():
     """The flags-only form of the per-environment kernel skips the square root behind two conservative bounds and falls
     back to the exact arithmetic in between: spheres whose radius IS their distance (and the floats just below / above

@@ -123,6 +123,44 @@ def test_collision_sweep_fused_equals_unfused_at_config4_size(problem):
     assert torch.equal(fused, hit) and 0.02 < fused.float().mean().item() < 0.98
 
 
+def test_config1_fk_sdf_1024_envs_against_the_oracle(problem, oracle):
+    """BASELINE configs[1] as SURVEY 8(d) C2 states it: 1024 environments, one configuration each drawn uniformly inside
+    the joint limits, FK + swept-sphere SDF only, outputs has_collision [1024] and min-sdf [1024, 56].  A sample of 32
+    environments spread over the batch is compared with the oracle (distances <= 1e-5, flags exact away from the
+    radius); the whole batch through size-independent properties: T = 1 equals the [B, 7] form, the flag is
+    `any(min_sdf <= radius)`, and rows do not depend on their neighbours in the batch."""
+    from mpinets_amd.geometry import TorchCuboids, TorchCylinders
+    from mpinets_amd.robot import FrankaCollisionSampler
+    from mpinets_amd.scenes import random_configurations
+
+    n = 1024
+    q = torch.from_numpy(random_configurations(n, 6)).to(dev())
+    prim = lambda sl: (TorchCuboids(problem["cuboid_centers"][sl], problem["cuboid_dims"][sl], problem["cuboid_quats"][sl]),
+                       TorchCylinders(problem["cylinder_centers"][sl], problem["cylinder_radii"][sl],
+                                      problem["cylinder_heights"][sl], problem["cylinder_quats"][sl]))
+    cs = FrankaCollisionSampler(dev(), with_base_link=False)
+    cub, cyl = prim(slice(0, n))
+    flags, msdf = cs.check(q, cub, cyl, return_sdf=True)
+    assert flags.shape == (n,) and msdf.shape == (n, 1, 56) and flags.dtype == torch.bool
+    f3, m3 = cs.check(q[:, None, :], cub, cyl, return_sdf=True)
+    assert torch.equal(flags, f3) and torch.equal(msdf, m3)
+    assert torch.equal(flags, (msdf[:, 0] <= cs.radii[None]).any(dim=1)) and 0.02 < flags.float().mean().item() < 0.98
+    sel = np.linspace(0, n - 1, 32).astype(np.int64)
+    sel_t = torch.from_numpy(sel).to(dev())
+    cub_s, cyl_s = prim(sel_t)
+    f_s, m_s = cs.check(q[sel_t], cub_s, cyl_s, return_sdf=True)
+    assert torch.equal(f_s, flags[sel_t]) and torch.equal(m_s, msdf[sel_t])  # independent of the batch around a row
+    qh = q[sel_t].cpu().numpy()
+    centres = oracle.transform_table(oracle.franka_fk(qh), cs.centers.cpu().numpy(), cs.links.cpu().numpy()).reshape(32, 1, 56, 3)
+    h = lambda k: problem[k][sel_t].cpu().numpy()
+    oflags, omsdf = oracle.collision_flags(
+        centres, cs.radii.cpu().numpy(), (h("cuboid_centers"), h("cuboid_dims"), h("cuboid_quats")),
+        (h("cylinder_centers"), h("cylinder_radii"), h("cylinder_heights"), h("cylinder_quats")))
+    np.testing.assert_allclose(m_s.cpu().numpy(), omsdf, rtol=0, atol=1e-5)
+    border = np.abs(omsdf - cs.radii.cpu().numpy()[None, None]).min(axis=(1, 2)) < 1e-5
+    np.testing.assert_array_equal(f_s.cpu().numpy()[~border], oflags[~border])
+
+
 def test_rollout_step_keeps_the_slab_consistent(problem):
     from mpinets_amd.model import MotionPolicyNetwork
     from mpinets_amd.rollout import RolloutEngine

@@ -34,6 +34,26 @@ def test_golden_vectors(golden, suite):
         np.testing.assert_allclose(obj.sdf_sequence(T(g("seq"))).cpu().numpy(), g(f"out/{tag}_sdf_seq"), rtol=0, atol=TOL)
 
 
+@pytest.mark.parametrize("suite", ["tabletop_yaw", "cubby_yaw_padded"])
+def test_sphere_sample_surface_and_area_golden(golden, suite):
+    """TorchSpheres.sample_surface / surface_area (geometry.py:60-85) vs vectors made by running the reference under
+    torch.manual_seed(11): the same draw from torch's global CPU generator, the same normalise-and-scale arithmetic
+    (zero-radius spheres included: their samples collapse onto the centre)."""
+    from mpinets_amd.geometry import TorchSpheres
+
+    g = lambda k: golden[f"{suite}/{k}"]
+    sph = TorchSpheres(T(g("sph_centers")), T(g("sph_radii")))
+    torch.manual_seed(11)
+    pts = sph.sample_surface(7)
+    want = g("out/sph_surface_points_seed11_n7")
+    assert tuple(pts.shape) == want.shape and pts.device.type == "cuda"
+    np.testing.assert_allclose(pts.cpu().numpy(), want, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(sph.surface_area().cpu().numpy(), g("out/sph_surface_area"), rtol=1e-6, atol=0)
+    # every sample lies on its sphere: |sdf of the sphere alone| ~ 0
+    d = torch.linalg.norm(pts - sph.centers[:, :, None, :], dim=-1) - sph.radii
+    assert float(d.abs().max()) < 1e-6
+
+
 def test_matches_oracle_bitwise_on_random_scenes(oracle):
     """Same fp32 operation order as the oracle -> expect (and report) ulp-level agreement."""
     from mpinets_amd.geometry import TorchCuboids, TorchCylinders

@@ -81,66 +81,6 @@ def test_problem_batch_rows_do_not_depend_on_the_shard():
                     assert torch.equal(part[k], v[o:o + n]), (k, pool, clouds, o)
 
 
-def test_pipelined_rollout_equals_single_engine():
-    """rollout.PipelinedRollout (the batch in shares on their own HIP streams, a stage apart) leaves exactly the state one
-    engine over the whole batch leaves -- shares of >= 1025 environments keep the whole batch's launch shapes."""
-    from mpinets_amd.model import MotionPolicyNetwork
-    from mpinets_amd.rollout import PipelinedRollout, RolloutEngine
-    from mpinets_amd.scenes import make_problem_batch
-
-    dev = torch.device("cuda:0")
-    torch.manual_seed(0)
-    mdl = MotionPolicyNetwork().to(dev).eval()
-    B, steps = 2080, 3
-    mk = lambda: make_problem_batch(B, seed=12, device=dev, kinds=("tabletop", "cubby", "dresser"), M1=40, M2=16, scene_pool=64,
-                                    device_clouds=True, env_offset=7, total_envs=B + 7)
-    one = RolloutEngine(mdl, mk(), rerender_scene=True, scene_seed=3)
-    for _ in range(steps):
-        one.step()
-    prob = mk()
-    pr = PipelinedRollout(mdl, prob, ways=2, rerender_scene=True, scene_seed=3)
-    assert [e.env_offset for e in pr.engines] == [7, 7 + B // 2]
-    pr.run(2)
-    pr.run(steps - 2)  # (continues: the stagger is applied once, the step counters carry over)
-    torch.cuda.synchronize()
-    assert torch.equal(pr.q, one.q) and torch.equal(pr.q_norm, one.q_norm) and torch.equal(pr.flags, one.flags)
-    assert torch.equal(prob["xyz"], one.xyz)  # the shares are views of the caller's slab: updated in place
-
-
-def test_pipelined_rollout_on_a_cold_model():
-    """the shares of a PipelinedRollout use ONE model whose derived weight buffers are built by kernels on
-    share 0's stream.  With a model nobody has run yet (and again after set_precision / an in-place weight update) the
-    other shares must not read those buffers before they are built: first use == a single engine on a twin model."""
-    from mpinets_amd.model import MotionPolicyNetwork
-    from mpinets_amd.rollout import PipelinedRollout, RolloutEngine
-    from mpinets_amd.scenes import make_problem_batch
-
-    dev = torch.device("cuda:0")
-    B = 2080
-    mk = lambda: make_problem_batch(B, seed=13, device=dev, kinds=("tabletop", "cubby", "dresser"), M1=40, M2=16, scene_pool=64,
-                                    device_clouds=True)
-    torch.manual_seed(3)
-    cold = MotionPolicyNetwork().to(dev).eval()  # never run: every pack / pad is missing
-    torch.manual_seed(3)
-    twin = MotionPolicyNetwork().to(dev).eval()
-    pr = PipelinedRollout(cold, mk(), ways=2, rerender_scene=True, scene_seed=4)
-    pr.run(2)
-    one = RolloutEngine(twin, mk(), rerender_scene=True, scene_seed=4)
-    one.step(), one.step()
-    torch.cuda.synchronize()
-    assert torch.equal(pr.q, one.q) and torch.equal(pr.flags, one.flags)
-    # caches go cold again: precision switch, then an optimizer-like in-place update
-    for mdl in (cold, twin):
-        mdl.set_precision("bf16x3")
-    pr.run(1), one.step()
-    with torch.no_grad():
-        for mdl in (cold, twin):
-            mdl.point_cloud_encoder.SA_modules[1].convs()[1].weight.mul_(1.25)
-    pr.run(1), one.step()
-    torch.cuda.synchronize()
-    assert torch.equal(pr.q, one.q) and torch.equal(pr.flags, one.flags)
-
-
 def test_bench_distributed_path_on_a_real_rccl_communicator():
     """`bench.py`'s N > 1 code path -- shard.init -> init_process_group("nccl", device_id=...), barrier, MAX all-reduce,
     gather_to_rank0, all_gather_object -- executed on a REAL RCCL communicator: one rank under torch.distributed.run with
@@ -154,7 +94,7 @@ def test_bench_distributed_path_on_a_real_rccl_communicator():
     env.pop("MPX_DIST_BACKEND", None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "1", "--envs", "1040", "--steps", "2",
-           "--warmup", "1", "--extra", "0", "--fast-steps", "1", "--pipeline-steps", "0", "--cpu-envs", "0", "--scene-pool", "64"]
+           "--warmup", "1", "--extra", "0", "--fast-steps", "1", "--cpu-envs", "0", "--scene-pool", "64"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
@@ -181,7 +121,7 @@ def test_bench_two_ranks_report_sharded_extras_and_both_scalings(scaling):
     for k in ("MPX_DIST_BACKEND", "MPX_DIST_FORCE", "WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--scaling", scaling, "--envs", "520", "--global-envs",
-           "1041", "--steps", "1", "--warmup", "1", "--fast-steps", "0", "--pipeline-steps", "0", "--static-steps", "0",
+           "1041", "--steps", "1", "--warmup", "1", "--fast-steps", "0", "--static-steps", "0",
            "--all-slots-steps", "0", "--train-steps", "1", "--cpu-envs", "0", "--scene-pool", "32"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
@@ -206,6 +146,63 @@ def test_bench_two_ranks_report_sharded_extras_and_both_scalings(scaling):
     assert tr["allreduce_ranks"] == 2 and tr["batch_10"]["samples_per_gpu"] == 10 and tr["batch_10"]["samples_per_s"] > 0
     assert np.isfinite(tr["batch_256"]["loss"])
     assert out["extra_configs"]["c1_single_problem"]["ms_per_step"] > 0  # (rank 0 alone, after the others were released)
+
+
+@pytest.mark.parametrize("launcher,scaling", [("driver", "weak"), ("self", "strong")])
+def test_bench_eight_ranks_dress_rehearsal(launcher, scaling):
+    """The 1 -> 8 GPU curve is taken by the driver in ONE run on a node no round has touched, so the 8-rank command is
+    rehearsed here in full: eight processes (sharing this box's GPU over gloo: MPX_SHARE_GPU / MPX_SHARED_DEVICES, flagged
+    in the JSON), every default-on extra, small shares.  `driver` is the driver's own command line
+    (`python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P bench.py --gpus 8
+    --steps K --warmup W`), `self` lets bench.py start its ranks.  Checks: 8 rank records with contiguous environment
+    ranges, the gathered result's shape, config 3 split 8 ways, the data-parallel training step over 8 ranks, rank 0's
+    single-GPU extras after the others were released, and a wall-time bound.  north_star: "no RCCL collectives on the
+    step, only a final host gather"; reference launcher: mpinets/run_training.py:71-77."""
+    import json
+    import time
+
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("MPX_DIST_BACKEND", "MPX_DIST_FORCE", "WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MPX_SHARED_DEVICES"):
+        env.pop(k, None)
+    world, per = 8, 64
+    total = 515 if scaling == "strong" else world * per  # strong: 3 shares of 65 + 5 of 64 (padded gather)
+    small = ["--envs", str(per), "--global-envs", str(total), "--scaling", scaling, "--steps", "2", "--warmup", "1",
+             "--fast-steps", "1", "--static-steps", "1", "--all-slots-steps", "1", "--train-steps", "1",
+             "--cpu-envs", "0", "--scene-pool", "16"]
+    if launcher == "driver":
+        env.update(MPX_SHARED_DEVICES="1", MPX_DIST_BACKEND="gloo")  # (what bench.py sets for its own ranks under MPX_SHARE_GPU=1)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
+               "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", str(world)] + small
+    else:
+        env["MPX_SHARE_GPU"] = "1"
+        cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world)] + small
+    t0 = time.time()
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
+    wall = time.time() - t0
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly ONE JSON line (rank 0)"
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == world and out["scaling"] == scaling and out["dist_backend"] == "gloo" and out["rccl_ranks"] == 0
+    assert out["config"]["devices_shared"] is True and out["config"]["global_envs"] == total
+    recs = sorted(out["ranks"], key=lambda x: x["rank"])
+    assert [x["rank"] for x in recs] == list(range(world)) and [x["local_rank"] for x in recs] == list(range(world))
+    ids = [x["env_ids"] for x in recs]
+    assert ids[0][0] == 0 and ids[-1][1] == total and all(a[1] == b[0] for a, b in zip(ids, ids[1:]))
+    sizes = [b - a for a, b in ids]
+    assert sizes == ([65] * 3 + [64] * 5 if scaling == "strong" else [per] * world)
+    assert out["result_check"]["gathered_q"] == [total, 7]
+    assert out["ms_per_step"] >= max(x["ms_per_step"] for x in recs) * 0.999  # MAX over ranks
+    assert abs(out["value"] - total / (out["ms_per_step"] * 1e-3)) < 1e-6 * out["value"]
+    c4 = out["extra_configs"]["c4_collision_validation"]
+    assert len(c4["ms_per_rank"]) == world and len(c4["envs_per_rank"]) == world and c4["ms"] == max(c4["ms_per_rank"])
+    assert len(out["extra_configs"]["c2_fk_sdf_1024"]["ms_per_rank"]) == world
+    tr = out["extra_configs"]["n1_training_step"]
+    assert tr["allreduce_ranks"] == world and np.isfinite(tr["batch_10"]["loss"]) and np.isfinite(tr["batch_256"]["loss"])
+    assert out["fast_mode"]["value"] > 0
+    assert out["extra_configs"]["c1_single_problem"]["ms_per_step"] > 0  # rank 0 alone, after the release
+    assert wall < 900, f"8-rank rehearsal took {wall:.0f} s"
 
 
 def test_shard_init_takes_a_free_port_for_a_forced_single_rank(monkeypatch):

@@ -1,4 +1,5 @@
-"""N > 1 path on CPU: env sharding + barrier + max-over-ranks + final gather with gloo, world_size 2."""
+"""N > 1 path on CPU: env sharding + barrier + max-over-ranks + final gather with gloo, world_size 2 and 8 (the
+driver's scaling run uses 8 ranks: the same collectives, uneven shares and padded gathers at that width)."""
 import os
 import socket
 
@@ -85,6 +86,20 @@ def _scene_worker(rank, world, port, per_rank, out_dir):
     torch.distributed.destroy_process_group()
 
 
+@pytest.mark.parametrize("total", [8 * 5, 67, 8])
+def test_eight_ranks_gather_in_order(tmp_path, total):
+    """The driver's 8-rank run: weak shares (8 x 5), an uneven strong split (67 = 3 x 9 + 5 x 8: the final gather pads to
+    9 rows and trims) and one environment per rank.  north_star: "no RCCL collectives on the step, only a final host
+    gather"; run_training.py:71-77 is the reference's one-process-per-GPU launcher."""
+    world = 8
+    mp.spawn(_worker, args=(world, _free_port(), 5, str(tmp_path), 0 if total == 40 else total), nprocs=world, join=True)
+    q, f = np.load(tmp_path / "q.npy"), np.load(tmp_path / "f.npy")
+    ids = np.arange(total)
+    assert q.shape == (total, 7) and f.shape == (total,)
+    np.testing.assert_allclose(q, ids[:, None] + 0.1 * np.arange(7)[None], rtol=1e-6)
+    np.testing.assert_array_equal(f, (ids % 3 == 0).astype(np.int32))
+
+
 def test_sharded_scene_draw_equals_unsharded(tmp_path, oracle):
     """The per-environment random draws of the step are keyed by the global environment id (env_offset of
     mpx_scene_cloud, restated by the oracle): two ranks' gathered draws == one process's draw, bit for bit.
@@ -131,9 +146,9 @@ def _grad_worker(rank, world, port, out_dir):
     torch.distributed.destroy_process_group()
 
 
-def test_gradient_allreduce_averages_over_ranks(tmp_path):
-    """Row N1: bucketed gradient all-reduce == the gradient of the mean loss over both ranks' batches."""
-    world = 2
+@pytest.mark.parametrize("world", [2, 8])
+def test_gradient_allreduce_averages_over_ranks(tmp_path, world):
+    """Row N1: bucketed gradient all-reduce == the gradient of the mean loss over all ranks' batches."""
     mp.spawn(_grad_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     got = torch.load(tmp_path / "g.pt")
     torch.manual_seed(0)

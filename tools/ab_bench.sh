@@ -5,7 +5,7 @@ mkdir -p gpurun_out/ab
 export PYTHONUNBUFFERED=1
 REPO=$(pwd); O=$REPO/gpurun_out/ab
 run() {
-  MPX_LIB_PATH=$2 timeout 300 python bench.py --steps 5 --warmup 1 --cpu-envs 0 --extra 0 --fast-steps 0 --pipeline-steps 0 --all-slots-steps 0 > $O/bench_$1.log 2>&1
+  MPX_LIB_PATH=$2 timeout 300 python bench.py --steps 5 --warmup 1 --cpu-envs 0 --extra 0 --fast-steps 0 --all-slots-steps 0 > $O/bench_$1.log 2>&1
   python - "$1" "$O/bench_$1.log" <<'PY'
 import json, sys
 l = [x for x in open(sys.argv[2]) if x.startswith("{")]

@@ -13,7 +13,7 @@ echo "pytest exit: $?" >> $O/pytest_gpu.log; tail -3 $O/pytest_gpu.log | cut -c1
 fi
 cp gpurun_out/soak_hashes.json gpurun_out/horizon_report.json $O/ 2>/dev/null
 timeout 1200 python bench.py --whole-batch-steps 1 > $O/bench.log 2> $O/bench.err; echo "bench exit: $?" >> $O/bench.err; tail -1 $O/bench.err; cut -c1-200 $O/bench.log
-HEAD_ARGS="--steps 3 --warmup 1 --cpu-envs 0 --extra 0 --fast-steps 0 --pipeline-steps 0 --all-slots-steps 0 --train-steps 0"
+HEAD_ARGS="--steps 3 --warmup 1 --cpu-envs 0 --extra 0 --fast-steps 0 --all-slots-steps 0 --train-steps 0"
 pmc() {  # tag, counters, command...
   tag=$1; ctr=$2; shift 2
   ( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/pmc_$tag && timeout 900 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/pmc_$tag -o run -- python $REPO/"$@" > $O/pmc_${tag}.log 2>&1
@@ -27,7 +27,7 @@ stats() {  # tag, command...
     find /tmp/st_$tag -name "*kernel_stats.csv" -exec cp {} $O/stats_${tag}_kernel_stats.csv \; )
 }
 stats head bench.py $HEAD_ARGS
-PARGS="--envs 8192 --steps 2 --warmup 1 --cpu-envs 0 --extra 0 --fast-steps 0 --pipeline-steps 0 --all-slots-steps 0 --train-steps 0"
+PARGS="--envs 8192 --steps 2 --warmup 1 --cpu-envs 0 --extra 0 --fast-steps 0 --all-slots-steps 0 --train-steps 0"
 pmc head1 "FETCH_SIZE" bench.py $PARGS
 pmc head2 "WRITE_SIZE" bench.py $PARGS
 pmc head3 "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE" bench.py $PARGS
