@@ -819,12 +819,21 @@ constexpr int W2_OFF = Cfg::O2 * TILE_BYTES;                 // first layer-2 st
 constexpr int W3_OFF = Cfg::O3 * TILE_BYTES;                 // first layer-3 step-tile (output tile major, s inner)
 constexpr int W3_BYTES = Cfg::ST3 * TILE_BYTES;              // 131072
 constexpr int LDS_BIAS2 = W3_BYTES, LDS_BIAS3 = LDS_BIAS2 + 4 * C2, LDS_CTR = LDS_BIAS3 + 4 * C3;
-constexpr int LDS_BYTES = LDS_CTR + WV * Q * C1 * 4;         // 148992
+constexpr int ROWQ = (Q * 128 + 64) / 4 + 16;                // 4-row groups of a unit's rows (nsample <= 128) + the index prefetch's overhang
+constexpr int LDS_ROWQ = LDS_CTR + WV * Q * C1 * 4;          // row group -> local query, one byte each, a strip per wave
+constexpr int LDS_BYTES = LDS_ROWQ + WV * ROWQ;              // 150144
 constexpr int RS = 8, RD = 7;  // layer-2 ring: stages, prefetch distance in K16 steps (7 x 192 pipe cycles of L2 latency cover)
 static_assert(Cfg::ST2 == 32 && Cfg::ST3 == 64 && Cfg::KS1 == 8 && Cfg::KS2 == 8 && Cfg::OT2 == 4 && Cfg::OT3 == 8, "shape");
 }  // namespace v2
 
 #define V2_FENCE() __builtin_amdgcn_sched_barrier(0)
+#ifndef MPX_V2_GAPMAP
+#define MPX_V2_GAPMAP 1  // the next tile's row -> (query, neighbour) map, the tile's boundary shape and pair B's biases ride in the
+                         // fetch-free gaps of layer 2's first output pair (0: round 4: all in front of the tile's first MFMA)
+#endif
+#ifndef MPX_V2_TWOACC
+#define MPX_V2_TWOACC 1  // tiles with ONE query boundary: branch-free two-way pooling, flush deferred into the next tile (0: round 4)
+#endif
 #ifndef MPX_V2_SMOOTH
 #define MPX_V2_SMOOTH 1  // fillers of the tile loop in half quanta, one piece per MFMA gap (0: round 3's placement)
 #endif
@@ -910,7 +919,10 @@ __global__ void __launch_bounds__(64 * v2::WV) __attribute__((amdgpu_waves_per_e
 #pragma unroll
   for (int ot = 0; ot < Cfg::OT3; ++ot) b3v[ot] = bias3_s[ot * 32 + col];
   float *ctr_w = reinterpret_cast<float *>(smem + LDS_CTR) + wave * Q * C1;
+  unsigned char *rowq = smem + LDS_ROWQ + wave * ROWQ;
   const unsigned char *w3_lane = smem + lane * 16;
+  int w3_off_hi = lane * 16 + 65536;
+  asm volatile("" : "+v"(w3_off_hi));  // (opaque: otherwise the compiler folds it back into w3_lane + a 17-bit constant)
 
   const __amdgpu_buffer_rsrc_t wrsrc =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(wpack), 0, (int)Cfg::TOTAL_BYTES, 0x00020000);
@@ -1018,14 +1030,17 @@ __global__ void __launch_bounds__(64 * v2::WV) __attribute__((amdgpu_waves_per_e
     }
     const int total = __builtin_amdgcn_readlane(pre, Q - 1);
     pre -= my_rows;
-    int s_pre[Q], s_cnt[Q], s_env[Q];
-#pragma unroll
-    for (int i = 0; i < Q; ++i) {
-      s_pre[i] = __builtin_amdgcn_readlane(pre, i);
-      s_cnt[i] = __builtin_amdgcn_readlane(my_cnt, i);
-      s_env[i] = __builtin_amdgcn_readlane(my_env, i);
-    }
     const int n_rows = total <= 32 ? 32 : ((total + 31) & ~31);
+    // group of 4 rows -> local query, one byte per group in this wave's LDS strip (a query's rows are whole groups; the
+    // groups past the end -- the index prefetch runs two tiles ahead -- belong to the last query): each query's lane
+    // writes its own groups, so a tile's row -> query map is one LDS read + three ds_bpermute instead of a compare /
+    // select chain over the Q queries in front of every tile (round 5; the chain also held 3 Q scalar registers)
+    {
+      const int g0 = pre >> 2, ng = my_rows >> 2;
+      for (int j = 0; j < ng; ++j) rowq[g0 + j] = (unsigned char)lane;
+      const int gt = total >> 2, ge = (n_rows + 64) >> 2;  // ge - gt <= 24
+      if (gt + lane < ge) rowq[gt + lane] = (unsigned char)(nq - 1);
+    }
     // this unit's per-query first-layer terms -> this wave's LDS rows (Q x 32 float4: Q / 2 per lane)
 #pragma unroll
     for (int u = 0; u < Q / 2; ++u) {
@@ -1035,20 +1050,20 @@ __global__ void __launch_bounds__(64 * v2::WV) __attribute__((amdgpu_waves_per_e
             *reinterpret_cast<const float4 *>(ctr + (q0 + qi) * C1 + 4 * c4);
     }
     __builtin_amdgcn_wave_barrier();
+    const int32_t *const idx_unit = idx + q0 * nsample;  // (uniform: a row's neighbour index is a 32-bit offset from here)
 
-    // row -> (local query, environment, neighbour slot); rows past the end repeat the last query's first slot
+    // row -> (local query, environment, neighbour slot); rows past the end repeat the last query's first slot.  In three
+    // steps so that the tile loop can spread them over three gaps: table read | the query's lane values | the slot
+    auto map_q = [&](int p) __attribute__((always_inline)) { return (int)rowq[p >> 2]; };
+    auto map_fetch = [&](int n, int &qpre, int &qcnt, int &env) __attribute__((always_inline)) {
+      qpre = __builtin_amdgcn_ds_bpermute(4 * n, pre);
+      qcnt = __builtin_amdgcn_ds_bpermute(4 * n, my_cnt);
+      env = __builtin_amdgcn_ds_bpermute(4 * n, my_env);
+    };
     auto map_row = [&](int p, int &qi, int &env, int &off) __attribute__((always_inline)) {
-      int qpre = 0, qcnt = s_cnt[0];
-      qi = 0;
-      env = s_env[0];
-#pragma unroll
-      for (int i = 1; i < Q; ++i) {
-        const bool ge = i < nq && p >= s_pre[i];
-        qi = ge ? i : qi;
-        env = ge ? s_env[i] : env;
-        qpre = ge ? s_pre[i] : qpre;
-        qcnt = ge ? s_cnt[i] : qcnt;
-      }
+      int qpre, qcnt;
+      qi = map_q(p);
+      map_fetch(qi, qpre, qcnt, env);
       const int slot = p - qpre;
       off = slot < qcnt ? slot : 0;
     };
@@ -1070,6 +1085,12 @@ __global__ void __launch_bounds__(64 * v2::WV) __attribute__((amdgpu_waves_per_e
 #pragma unroll
     for (int ot = 0; ot < Cfg::OT3; ++ot) run[ot] = -__builtin_inff();
     int cur = 0;  // local query being merged (wave-uniform)
+    // (round 5) A tile with exactly ONE query boundary -- every other tile -- pools both sides in one straight block per
+    // output tile: the lane's four group maxima are clipped against +-inf limits (limo[j] = +inf where group 2j + half
+    // belongs to the query that ends in this tile), the finished query's maximum is completed and stored (both lane
+    // halves store the same value: no exec mask), the rest starts the new query's running maximum.  Round 4's form -- up
+    // to eight flushes per output tile behind scalar branches -- cost such a tile ~3 k of its ~16 k cycles; it still
+    // serves tiles with two or more boundaries.
     // (the lane's eight layer-3 biases sit in registers and the unit's output rows start at one 64-bit base: a flush in
     // the middle of a tile -- a query boundary, every other tile -- used to wait for an LDS read and to rebuild a 64-bit
     // row address with quarter-rate integer multiplies, 3.3 k of a 12.7 k-cycle layer 3; s_memtime probe, round 4)
@@ -1122,16 +1143,98 @@ __global__ void __launch_bounds__(64 * v2::WV) __attribute__((amdgpu_waves_per_e
       }
     };
 
+    // ---- per-tile pooling state and pieces (declared once per unit: the tile loop's gap fillers refer to them) ----------
+    int ql_tile = 0;
+    int gq[8];
+    unsigned m_cur = 0, m_last = 0;
+    int g1 = 8, cur_off = 0;
+    bool one_b = false;
+    float limo[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // +inf where this lane's group 2j + half lies in front of the boundary, else -inf
+    // boundary shape of the tile (wave-uniform), from two ballots over the rows (row r = lane r): g1 = leading 4-row
+    // groups that still belong to `cur`; one_b = every other row belongs to the tile's last query (the local query
+    // index never decreases along the rows, so that is ONE boundary)
+    auto shape_a = [&]() __attribute__((always_inline)) {
+#pragma unroll
+      for (int g = 0; g < 8; ++g) gq[g] = __builtin_amdgcn_readlane(ql_tile, 4 * g);
+      m_cur = (unsigned)__builtin_amdgcn_ballot_w64(ql_tile == cur);
+    };
+    auto shape_b = [&]() __attribute__((always_inline)) {
+#if MPX_V2_TWOACC
+      m_last = (unsigned)__builtin_amdgcn_ballot_w64(ql_tile == gq[7]);
+      g1 = (m_cur == 0xffffffffu ? 32 : __builtin_ctz(~m_cur)) >> 2;
+      one_b = gq[7] != cur && (m_cur | m_last) == 0xffffffffu;
+      const int lim = g1 - half;  // group 2j + half is in front of the boundary <=> 2j < g1 - half
+#pragma unroll
+      for (int j = 0; j < 4; ++j) limo[j] = __uint_as_float((((unsigned)(lim - (2 * j + 1))) & 0x80000000u) | 0x7f800000u);
+      cur_off = cur * out_stride;  // (scalar: the finished query's output row, relative to the unit's first)
+      if constexpr (PROBE) {  // boundary shape of the tile beside its stamps: 0 none, 1 one boundary, 2 more
+        if (blockIdx.x == 100 && threadIdx.x == 0 && (pi >> 2) < 24) probe[96 + (pi >> 2)] = g1 == 8 ? 0 : (one_b ? 1 : 2);
+      }
+#endif
+    };
+    f32x16 a3[2][2];
+    auto pool = [&](int pr, int part) __attribute__((always_inline)) {  // output pair pr, tile o = part
+      const int ot = 2 * pr + part;
+      const f32x16 &a = a3[pr & 1][part];
+      float gm[4];
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj)
+        gm[jj] = fmaxf(fmaxf(a[4 * jj], a[4 * jj + 1]), fmaxf(a[4 * jj + 2], a[4 * jj + 3]));
+      if (gq[7] == cur) {  // the whole tile belongs to the query being merged (the common case)
+        run[ot] = fmaxf(run[ot], fmaxf(fmaxf(gm[0], gm[1]), fmaxf(gm[2], gm[3])));
+      } else {
+        int c = cur;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+          if (gq[g] != c) {
+            flush(ot, c);
+            c = gq[g];
+          }
+          run[ot] = fmaxf(run[ot], ((g & 1) == half) ? gm[g >> 1] : -__builtin_inff());
+        }
+      }
+    };
+    float gmb[2][4];  // group maxima of the output pair being pooled (pool_gm / pool_fin: pool() in five pieces)
+    auto pool_gm = [&](int pr, int part, int jj) __attribute__((always_inline)) {
+      const f32x16 &a = a3[pr & 1][part];
+      gmb[part][jj] = fmaxf(fmaxf(a[4 * jj], a[4 * jj + 1]), fmaxf(a[4 * jj + 2], a[4 * jj + 3]));
+      asm volatile("" : "+v"(gmb[part][jj]));
+    };
+    auto pool_fin = [&](int pr, int part) __attribute__((always_inline)) {
+      const int ot = 2 * pr + part;
+      const float *gm = gmb[part];
+      if (gq[7] == cur) {  // the whole tile belongs to the query being merged (the common case)
+        run[ot] = fmaxf(run[ot], fmaxf(fmaxf(gm[0], gm[1]), fmaxf(gm[2], gm[3])));
+#if MPX_V2_TWOACC
+      } else if (one_b) {  // one boundary: the finished query's side is completed and stored, the rest starts the new one
+        const float o0 = fminf(gm[0], limo[0]), o1 = fminf(gm[1], limo[1]), o2 = fminf(gm[2], limo[2]), o3 = fminf(gm[3], limo[3]);
+        const float n0 = fminf(gm[0], -limo[0]), n1 = fminf(gm[1], -limo[1]), n2 = fminf(gm[2], -limo[2]), n3 = fminf(gm[3], -limo[3]);
+        const float done = mpx_max_across_halves(fmaxf(fmaxf(run[ot], fmaxf(o0, o1)), fmaxf(o2, o3)));
+        out_unit[cur_off + ot * 32] = fmaxf(done + b3v[ot], 0.0f);
+        run[ot] = fmaxf(fmaxf(n0, n1), fmaxf(n2, n3));
+#endif
+      } else {
+        int c = cur;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+          if (gq[g] != c) {
+            flush(ot, c);
+            c = gq[g];
+          }
+          run[ot] = fmaxf(run[ot], ((g & 1) == half) ? gm[g >> 1] : -__builtin_inff());
+        }
+      }
+    };
     // row pipeline: the neighbour index of a tile's row is loaded a tile before its first-layer row is gathered (at the
     // end of layer 2 of the tile before), which is formed during layer 3 of that tile
     int ql_cur, ql_next = 0, env_next = 0, k_next = 0;
     {  // unit prologue: the first tile's rows, formed without cover (once per ~16 tiles)
       int env, off;
       map_row(col, ql_cur, env, off);
-      const int k0 = idx[(q0 + ql_cur) * nsample + off];
+      const int k0 = idx_unit[ql_cur * nsample + off];
       gather(env, k0);
       map_row(32 + col, ql_next, env_next, off);
-      k_next = idx[(q0 + ql_next) * nsample + off];
+      k_next = idx_unit[ql_next * nsample + off];
       const float *cqp = ctr_w + ql_cur * C1 + 4 * half;
 #pragma unroll
       for (int g = 0; g < 32; ++g) form_q(cqp, g);
@@ -1143,27 +1246,33 @@ __global__ void __launch_bounds__(64 * v2::WV) __attribute__((amdgpu_waves_per_e
       // kernel's fetch halved with this line, sa_mlp.hip)
       if (rt + 32 >= n_rows) j_next = next_unit();
       stamp();
-      const int ql_tile = ql_cur;
+      ql_tile = ql_cur;
       const int env_gather = env_next, k_gather = k_next;
       const float *cq_next = ctr_w + ql_next * C1 + 4 * half;  // LDS row of the next tile's query (this lane's row)
       ql_cur = ql_next;
       V2_FENCE();
+#if !MPX_V2_GAPMAP
       {  // index of the row after next: issued now, consumed a tile later (rows past the end are clamped by map_row)
         int off;
         map_row(rt + 64 + col, ql_next, env_next, off);
-        k_next = idx[(q0 + ql_next) * nsample + off];
+        k_next = idx_unit[ql_next * nsample + off];
       }
-      int gq[8];
-#pragma unroll
-      for (int g = 0; g < 8; ++g) gq[g] = __builtin_amdgcn_readlane(ql_tile, 4 * g);
+#endif
+      int mr_n = 0, mr_pre = 0, mr_cnt = 0, mr_env = 0;  // (GAPMAP: the map of row rt + 64 + col between its three steps)
+#if !MPX_V2_GAPMAP
+      shape_a();
+      shape_b();
+#endif
       V2_FENCE();
       // ---- layer 2: Ht = W . Xt, pair A then pair B; MFMA m of a pair = (s, pass, o) = (m / 6, (m % 6) / 2, m % 2) -----
       f32x16 a2[4];
       bf16x8 h2[4][2], l2[4][2];
       a2[0] = bias_tile_lds(bias2_s, 0, half);
       a2[1] = bias_tile_lds(bias2_s, 1, half);
+#if !MPX_V2_GAPMAP
       a2[2] = bias_tile_lds(bias2_s, 2, half);
       a2[3] = bias_tile_lds(bias2_s, 3, half);
+#endif
       V2_FENCE();
 #pragma unroll
       for (int m = 0; m < 96; ++m) {
@@ -1180,6 +1289,24 @@ __global__ void __launch_bounds__(64 * v2::WV) __attribute__((amdgpu_waves_per_e
           split_h(a2[q >> 3], h2[q >> 3], l2[q >> 3], q & 7, hh & 1);
         }
         if (pair == 1 && mm % 6 >= 4) gather_part(env_gather, k_gather, (mm / 6) * 2 + (mm % 6 - 4));
+#if MPX_V2_GAPMAP
+        // pair A's fetch-free gaps (mm % 6 >= 4; nothing else rides there): the map of the row after next in three
+        // steps an LDS round trip apart, the tile's boundary shape (needed from layer 3's second output pair on), pair
+        // B's biases
+        if (pair == 0) {
+          if (mm == 4) mr_n = map_q(rt + 64 + col);
+          if (mm == 10) map_fetch(mr_n, mr_pre, mr_cnt, mr_env);
+          if (mm == 5) shape_a();
+          if (mm == 11) shape_b();
+          if (mm == 22) {
+            const int slot = rt + 64 + col - mr_pre;
+            ql_next = mr_n, env_next = mr_env;
+            k_next = idx_unit[mr_n * nsample + (slot < mr_cnt ? slot : 0)];
+          }
+          if (mm == 28) a2[2] = bias_tile_lds(bias2_s, 2, half);
+          if (mm == 34) a2[3] = bias_tile_lds(bias2_s, 3, half);
+        }
+#endif
 #else
         // pair A's accumulators are final after MFMA 47: their relu + split rides behind pair B's MFMAs (16 quanta)
         if (pair == 1 && mm % 3 == 2) split_q(a2[(mm / 3) >> 3], h2[(mm / 3) >> 3], l2[(mm / 3) >> 3], (mm / 3) & 7);
@@ -1193,67 +1320,27 @@ __global__ void __launch_bounds__(64 * v2::WV) __attribute__((amdgpu_waves_per_e
       V2_FENCE();
       // ---- layer 3 (roles flipped: activations are A, weights B), output tiles in pairs, weights from LDS ------------
       bf16x8 w3r[3][4];  // operand stages: running step n3 = pr * 8 + s lives in stage n3 % 3, read two steps ahead
+      // (a ds_read's immediate offset is 16 bits: the upper 64 KB of the layer-3 weights are read from a second base
+      // register -- one address per kernel instead of a v_add_u32 in front of every other read, 64 per tile)
+      auto w3_at = [&](int off) __attribute__((always_inline)) {
+        return off < 65536 ? w3_lane + off : smem + w3_off_hi + (off - 65536);
+      };
       auto load3 = [&](int n3) __attribute__((always_inline)) {
         const int pr = n3 >> 3, s = n3 & 7;
 #pragma unroll
         for (int o = 0; o < 2; ++o) {
-          const unsigned char *p = w3_lane + ((2 * pr + o) * 8 + s) * TILE_BYTES;
+          const unsigned char *p = w3_at(((2 * pr + o) * 8 + s) * TILE_BYTES);
           w3r[n3 % 3][2 * o] = *reinterpret_cast<const bf16x8 *>(p);
           w3r[n3 % 3][2 * o + 1] = *reinterpret_cast<const bf16x8 *>(p + 1024);
         }
       };
       auto load3_part = [&](int n3, int j) __attribute__((always_inline)) {  // one of the step's four LDS reads
         const int pr = n3 >> 3, s = n3 & 7, o = j >> 1;
-        const unsigned char *p = w3_lane + ((2 * pr + o) * 8 + s) * TILE_BYTES + (j & 1) * 1024;
+        const unsigned char *p = w3_at(((2 * pr + o) * 8 + s) * TILE_BYTES + (j & 1) * 1024);
         w3r[n3 % 3][j] = *reinterpret_cast<const bf16x8 *>(p);
       };
       load3(0);
       load3(1);
-      f32x16 a3[2][2];
-      auto pool = [&](int pr, int part) __attribute__((always_inline)) {  // output pair pr, tile o = part
-        const int ot = 2 * pr + part;
-        const f32x16 &a = a3[pr & 1][part];
-        float gm[4];
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj)
-          gm[jj] = fmaxf(fmaxf(a[4 * jj], a[4 * jj + 1]), fmaxf(a[4 * jj + 2], a[4 * jj + 3]));
-        if (gq[7] == cur) {  // the whole tile belongs to the query being merged (the common case)
-          run[ot] = fmaxf(run[ot], fmaxf(fmaxf(gm[0], gm[1]), fmaxf(gm[2], gm[3])));
-        } else {
-          int c = cur;
-#pragma unroll
-          for (int g = 0; g < 8; ++g) {
-            if (gq[g] != c) {
-              flush(ot, c);
-              c = gq[g];
-            }
-            run[ot] = fmaxf(run[ot], ((g & 1) == half) ? gm[g >> 1] : -__builtin_inff());
-          }
-        }
-      };
-      float gmb[2][4];  // group maxima of the output pair being pooled (pool_gm / pool_fin: pool() in five pieces)
-      auto pool_gm = [&](int pr, int part, int jj) __attribute__((always_inline)) {
-        const f32x16 &a = a3[pr & 1][part];
-        gmb[part][jj] = fmaxf(fmaxf(a[4 * jj], a[4 * jj + 1]), fmaxf(a[4 * jj + 2], a[4 * jj + 3]));
-        asm volatile("" : "+v"(gmb[part][jj]));
-      };
-      auto pool_fin = [&](int pr, int part) __attribute__((always_inline)) {
-        const int ot = 2 * pr + part;
-        const float *gm = gmb[part];
-        if (gq[7] == cur) {  // the whole tile belongs to the query being merged (the common case)
-          run[ot] = fmaxf(run[ot], fmaxf(fmaxf(gm[0], gm[1]), fmaxf(gm[2], gm[3])));
-        } else {
-          int c = cur;
-#pragma unroll
-          for (int g = 0; g < 8; ++g) {
-            if (gq[g] != c) {
-              flush(ot, c);
-              c = gq[g];
-            }
-            run[ot] = fmaxf(run[ot], ((g & 1) == half) ? gm[g >> 1] : -__builtin_inff());
-          }
-        }
-      };
       V2_FENCE();
 #pragma unroll
       for (int m = 0; m < 192; ++m) {
@@ -1318,11 +1405,12 @@ __global__ void __launch_bounds__(64 * v2::WV) __attribute__((amdgpu_waves_per_e
         pool_fin(3, part);
       }
       (void)pool;
+      cur = gq[7];
 #else
       pool(3, 0);
       pool(3, 1);
-#endif
       cur = gq[7];
+#endif
       stamp();
       stamp();  // (back to back: the cost of a stamp itself)
       V2_FENCE();
@@ -1432,7 +1520,7 @@ MPX_EXPORT int mpx_sa_mlp_bf16x3_factored(const float *pre, const float *ctr, co
 }
 
 // measurement only (not in the header): route the next launches of the persistent kernel through its PROBE instantiation,
-// which writes s_memtime stamps of one wave into `probe` (>= 80 int64; nullptr = off)
+// which writes s_memtime stamps of one wave into `probe` (>= 128 int64; nullptr = off)
 MPX_EXPORT int mpx_sa2_bf16x3_set_probe(long long *probe) {
   g_sa2_probe = probe;
   return 0;

@@ -23,7 +23,7 @@ prob = make_problem_batch(B, seed=1000, device=dev, kinds=("tabletop", "cubby", 
 with torch.no_grad():
     mdl(prob["xyz"], prob["q_norm"])
     torch.cuda.synchronize()
-    probe = torch.zeros(96, dtype=torch.int64, device=dev)
+    probe = torch.zeros(128, dtype=torch.int64, device=dev)
     lib = ctypes.CDLL(_lib.LIB_PATH)
     lib.mpx_sa2_bf16x3_set_probe.argtypes = [ctypes.c_void_p]
     lib.mpx_sa2_bf16x3_set_probe(probe.data_ptr())
@@ -44,6 +44,7 @@ print("stamp cost (two stamps back to back):", own)
 print("layer 2 ticks per tile:", l2)
 print("layer 3 ticks per tile:", l3)
 print("between tiles:", gap)
+print("boundaries in the tile (0 / 1 / 2 = more):", [int(v) for v in t[96:96 + len(l2)]])
 if l2:
     import numpy as np
     print("medians: layer 2 %d (floor 3072 cycles), layer 3 %d (floor 6144), between %d" % (np.median(l2), np.median(l3), np.median(gap or [0])))
