@@ -29,7 +29,9 @@ typedef void *mpx_stream_t;
 
 #define MPX_NUM_FRAMES 15 /* link0..8, hand, leftfinger, rightfinger, l/r fingertip, right_gripper */
 
-int mpx_version(void); /* 310: struct mpx_policy_weights ends with sa3_pack (NULL = layer-by-layer group-all module at every
+int mpx_version(void); /* 320: mpx_linear_dact, mpx_segment_max_grad_act (additions only); mpx_franka_collision accepts
+                          frame pointers that are not 16-byte aligned;
+                          310: struct mpx_policy_weights ends with sa3_pack (NULL = layer-by-layer group-all module at every
                           batch size; a caller built against the 200 header must be rebuilt), MPX_VARIANT_UNIT_QUEUE,
                           mpx_ball_query_hits rejects nsample > 256;
                           300: mpx_set_variant / mpx_get_variant, mpx_sa_mlp_bf16x3_wants_order takes nsample */
@@ -186,6 +188,11 @@ int mpx_franka_cloud_grad(const float *q, int B, float finger, const float *tabl
  * workgroups; the splits' partial tiles go through `scratch` (mpx_linear_wgrad_scratch(M,N,K) floats) and are
  * added in a fixed order (deterministic).  N, K, ldx, lddy multiples of 4.                                  */
 int mpx_act_backward(const float *dy, const float *y, int64_t n, int act, float *dz, mpx_stream_t stream);
+/* dX with the previous layer's elementwise backward in the GEMM epilogue: y [M,N] = (x [M,K] . w [N,K]^T) * act'(dact_of)
+ * (dact_of [M,N] = that layer's OUTPUT rows, leading dimension lddact; dact = its activation; MPX_ACT_NONE: plain
+ * product).  Same arithmetic as mpx_linear(x, w) followed by mpx_act_backward.  loss.py / model.py:185-240 via autograd. */
+int mpx_linear_dact(const float *x, int ldx, const float *w, int M, int N, int K, const float *dact_of,
+                    int lddact, int dact, float *y, int ldy, mpx_stream_t stream);
 int64_t mpx_linear_wgrad_scratch(int M, int N, int K);
 int mpx_linear_wgrad(const float *dy, int lddy, const float *x, int ldx, int M, int N, int K, float *dw,
                      float *db, float *scratch, mpx_stream_t stream);
@@ -217,6 +224,10 @@ int mpx_segment_max(const float *y, int C, const int64_t *offsets, int64_t Q, fl
 /* backward: grad_y[arg[q,c], c] = grad_out[q,c] (grad_y pre-zeroed)                                  */
 int mpx_segment_max_grad(const float *grad_out, int grad_stride, const int64_t *arg, int64_t Q, int C,
                          float *grad_y, mpx_stream_t stream);
+/* the same with the backward of the activation in front of the pool folded in: out [Q, >= C] = the pooled rows
+ * (= the activation's output at the arg-max): grad_y[arg[q,c], c] = grad_out[q,c] * act'(out[q,c])             */
+int mpx_segment_max_grad_act(const float *grad_out, int grad_stride, const int64_t *arg, const float *out,
+                             int out_stride, int64_t Q, int C, int act, float *grad_y, mpx_stream_t stream);
 
 /* ---- batch assembly from the dataset arrays (row N2; mpinets/data_loader.py:141-280, 390-417) ------- */
 

@@ -42,7 +42,7 @@ template <int BK, bool POOL, bool DMA>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DMA ? 4 : 3, DMA ? 4 : 3)))
     linear_kernel(const float *__restrict__ x, int ldx, const float *__restrict__ w, int ldw,
                   const float *__restrict__ bias, int M, int N, int K, int act, float *__restrict__ y, int ldy,
-                  int kslice, size_t zstride) {
+                  int kslice, size_t zstride, const float *__restrict__ dact_of, int lddact, int dact) {
   static_assert(!DMA || BK == 16, "the DMA layout is written for 16-float slabs");
   constexpr int LDT = DMA ? BK : BK + 4;  // padded row (or xor-swizzled chunks): conflict-free 16-byte fragment reads
   constexpr int HK = BK / 2;        // k-values per lane-half per slab
@@ -231,8 +231,19 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DMA ? 
         const int rr = e >> 4, c4 = (e & 15) * 4;
         const int row = m0 + wm * 64 + i * 32 + rr;
         const int col = n0 + wn * 64 + c4;
-        const float4 v = *reinterpret_cast<const float4 *>(&stage[rr * LDC + c4]);
+        float4 v = *reinterpret_cast<const float4 *>(&stage[rr * LDC + c4]);
         if (row < M) {
+          if (dact_of != nullptr) {  // backward of the layer below (mpx_linear_dact): times act'(its output), as mpx_act_backward does
+            const float *mk = dact_of + (size_t)row * lddact + col;
+            const float m0_ = col + 0 < N ? mk[0] : 0.0f, m1_ = col + 1 < N ? mk[1] : 0.0f;
+            const float m2_ = col + 2 < N ? mk[2] : 0.0f, m3_ = col + 3 < N ? mk[3] : 0.0f;
+            if (dact == MPX_ACT_RELU) {
+              v.x = m0_ > 0.0f ? v.x : 0.0f, v.y = m1_ > 0.0f ? v.y : 0.0f, v.z = m2_ > 0.0f ? v.z : 0.0f, v.w = m3_ > 0.0f ? v.w : 0.0f;
+            } else if (dact == MPX_ACT_LEAKY) {
+              v.x = m0_ >= 0.0f ? v.x : 0.01f * v.x, v.y = m1_ >= 0.0f ? v.y : 0.01f * v.y;
+              v.z = m2_ >= 0.0f ? v.z : 0.01f * v.z, v.w = m3_ >= 0.0f ? v.w : 0.01f * v.w;
+            }
+          }
           float *dst = y + (size_t)row * ldy + col;
           if (vec_ok && col + 3 < N) {
             *reinterpret_cast<float4 *>(dst) = v;
@@ -441,11 +452,43 @@ MPX_EXPORT int mpx_linear(const float *x, int ldx, const float *w, const float *
   // 64-cycle fp32 MFMAs four waves per SIMD cover more than the leaner slab does.)
   if (dma_ok(M, N, K, ldx, K))
     hipLaunchKernelGGL((linear_kernel<16, false, true>), dim3(cdiv(N, BN), cdiv(M, BM)), dim3(256), 0, mpx_s(stream), x,
-                       ldx, w, K, bias, M, N, K, act, y, ldy, K, (size_t)0);
+                       ldx, w, K, bias, M, N, K, act, y, ldy, K, (size_t)0, static_cast<const float *>(nullptr), 0, 0);
   else
     hipLaunchKernelGGL((linear_kernel<16, false, false>), dim3(cdiv(N, BN), cdiv(M, BM)), dim3(256), 0, mpx_s(stream), x,
-                       ldx, w, K, bias, M, N, K, act, y, ldy, K, (size_t)0);
+                       ldx, w, K, bias, M, N, K, act, y, ldy, K, (size_t)0, static_cast<const float *>(nullptr), 0, 0);
   MPX_LAUNCH_CHECK("mpx_linear");
+}
+
+// dX of the layer above, already multiplied by act'(output) of the layer below: y = (x . w^T) * act'(dact_of) -- the
+// input-gradient GEMM of a dense layer (x = dZ of the layer, w = its weights transposed) with the elementwise backward
+// of the previous layer's activation in the epilogue (row N1; mpx_act_backward's arithmetic, one pass over the rows
+// instead of a GEMM store + a read-modify-write).  Every M takes the 128 x 128 tile kernel.
+MPX_EXPORT int mpx_linear_dact(const float *x, int ldx, const float *w, int M, int N, int K, const float *dact_of,
+                               int lddact, int dact, float *y, int ldy, mpx_stream_t stream) {
+  MPX_REQUIRE(M >= 0 && N >= 1 && K >= 1, "mpx_linear_dact: bad size");
+  MPX_REQUIRE(K % 4 == 0 && ldx % 4 == 0, "mpx_linear_dact: K and ldx must be multiples of 4 (got %d, %d)", K, ldx);
+  MPX_REQUIRE((((uintptr_t)x | (uintptr_t)w) & 15) == 0, "mpx_linear_dact: x and w must be 16-byte aligned");
+  MPX_REQUIRE(ldx >= K && ldy >= N, "mpx_linear_dact: leading dimension too small");
+  MPX_REQUIRE(dact == MPX_ACT_NONE || (dact_of != nullptr && lddact >= N && (dact == MPX_ACT_RELU || dact == MPX_ACT_LEAKY)),
+              "mpx_linear_dact: the activation's output rows are missing or too short, or the activation is unknown");
+  if (M == 0) return 0;
+  if (dact == MPX_ACT_NONE) dact_of = nullptr;
+  if (const int64_t slab = mpx_row_slab(BM, (int64_t)ldx * 4); M > slab) {  // more rows than one launch covers
+    for (int64_t m0 = 0; m0 < M; m0 += slab)
+      if (int rc = mpx_linear_dact(x + m0 * ldx, ldx, w, (int)(M - m0 < slab ? M - m0 : slab), N, K,
+                                   dact_of ? dact_of + m0 * lddact : nullptr, lddact, dact, y + m0 * ldy, ldy, stream))
+        return rc;
+    return 0;
+  }
+  if (dma_ok(M, N, K, ldx, K))
+    hipLaunchKernelGGL((linear_kernel<16, false, true>), dim3(cdiv(N, BN), cdiv(M, BM)), dim3(256), 0, mpx_s(stream), x,
+                       ldx, w, K, static_cast<const float *>(nullptr), M, N, K, MPX_ACT_NONE, y, ldy, K, (size_t)0, dact_of,
+                       lddact, dact);
+  else
+    hipLaunchKernelGGL((linear_kernel<16, false, false>), dim3(cdiv(N, BN), cdiv(M, BM)), dim3(256), 0, mpx_s(stream), x,
+                       ldx, w, K, static_cast<const float *>(nullptr), M, N, K, MPX_ACT_NONE, y, ldy, K, (size_t)0, dact_of,
+                       lddact, dact);
+  MPX_LAUNCH_CHECK("mpx_linear_dact");
 }
 
 // ---- split-K for skinny problems ------------------------------------------------------------------------
@@ -504,10 +547,10 @@ MPX_EXPORT int mpx_linear_ws(const float *x, int ldx, const float *w, const floa
   const size_t zstride = (size_t)M * N;
   if (dma_ok(M, N, K, ldx, K))  // (slices are multiples of the slab, so every slice keeps whole slabs too)
     hipLaunchKernelGGL((linear_kernel<16, false, true>), dim3(cdiv(N, BN), cdiv(M, BM), S), dim3(256), 0, mpx_s(stream), x,
-                       ldx, w, K, static_cast<const float *>(nullptr), M, N, K, MPX_ACT_NONE, part, N, kslice, zstride);
+                       ldx, w, K, static_cast<const float *>(nullptr), M, N, K, MPX_ACT_NONE, part, N, kslice, zstride, static_cast<const float *>(nullptr), 0, 0);
   else
     hipLaunchKernelGGL((linear_kernel<16, false, false>), dim3(cdiv(N, BN), cdiv(M, BM), S), dim3(256), 0, mpx_s(stream), x,
-                       ldx, w, K, static_cast<const float *>(nullptr), M, N, K, MPX_ACT_NONE, part, N, kslice, zstride);
+                       ldx, w, K, static_cast<const float *>(nullptr), M, N, K, MPX_ACT_NONE, part, N, kslice, zstride, static_cast<const float *>(nullptr), 0, 0);
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv((int64_t)M * N, 256)), dim3(256), 0, mpx_s(stream), part, S,
                      zstride, bias, M, N, act, y, ldy);
   MPX_LAUNCH_CHECK("mpx_linear_ws");
@@ -533,10 +576,10 @@ MPX_EXPORT int mpx_linear_rowmax(const float *x, int ldx, const float *w, const 
   MPX_REQUIRE(e == hipSuccess, "mpx_linear_rowmax: memset failed: %s", hipGetErrorString(e));
   if (dma_ok(M, N, K, ldx, K))
     hipLaunchKernelGGL((linear_kernel<16, true, true>), dim3(cdiv(N, BN), M / BM), dim3(256), 0, mpx_s(stream), x, ldx, w,
-                       K, bias, M, N, K, MPX_ACT_RELU, y, ldy, K, (size_t)0);
+                       K, bias, M, N, K, MPX_ACT_RELU, y, ldy, K, (size_t)0, static_cast<const float *>(nullptr), 0, 0);
   else
     hipLaunchKernelGGL((linear_kernel<16, true, false>), dim3(cdiv(N, BN), M / BM), dim3(256), 0, mpx_s(stream), x, ldx, w,
-                       K, bias, M, N, K, MPX_ACT_RELU, y, ldy, K, (size_t)0);
+                       K, bias, M, N, K, MPX_ACT_RELU, y, ldy, K, (size_t)0, static_cast<const float *>(nullptr), 0, 0);
   MPX_LAUNCH_CHECK("mpx_linear_rowmax");
 }
 

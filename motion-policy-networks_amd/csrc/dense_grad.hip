@@ -11,27 +11,34 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int WG_T = 128, WG_BK = 16, WG_LDT = WG_BK + 4;
+constexpr int WG_BK = 16, WG_LDT = WG_BK + 4;
 
+// T = 128: a 128 x 128 tile of dW per workgroup (four waves as 2 x 2, 64 x 64 each); T = 64 (layers of <= 64 inputs and
+// outputs -- the first set-abstraction module, whose three weight gradients reduce over ~2 M rows): a 64 x 64 tile, one
+// 32 x 32 MFMA tile per wave -- on the 128-wide kernel three quarters of such a layer's matrix work multiplied zeros.
+template <int T>
 __global__ void __launch_bounds__(256)
     linear_wgrad_kernel(const float *__restrict__ dy, int lddy, const float *__restrict__ x, int ldx, int M, int N,
                         int K, int rows_per_split, float *__restrict__ partial, int with_bias) {
-  __shared__ __attribute__((aligned(16))) float smem[2 * 2 * WG_T * WG_LDT];  // [As0 | As1 | Bs0 | Bs1]
-  float(*As)[WG_T * WG_LDT] = reinterpret_cast<float(*)[WG_T * WG_LDT]>(smem);
-  float(*Bs)[WG_T * WG_LDT] = reinterpret_cast<float(*)[WG_T * WG_LDT]>(smem + 2 * WG_T * WG_LDT);
+  static_assert(T == 128 || T == 64, "tile");
+  constexpr int NT = T / 64;                          // 32 x 32 MFMA tiles per wave and dimension
+  constexpr int CPR = T / 4, RPP = 256 / CPR, NP = WG_BK / RPP;  // staging: chunks per slab row, rows per pass, passes
+  __shared__ __attribute__((aligned(16))) float smem[2 * 2 * T * WG_LDT];  // [As0 | As1 | Bs0 | Bs1]
+  float(*As)[T * WG_LDT] = reinterpret_cast<float(*)[T * WG_LDT]>(smem);
+  float(*Bs)[T * WG_LDT] = reinterpret_cast<float(*)[T * WG_LDT]>(smem + 2 * T * WG_LDT);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
   const int wm = wave >> 1, wn = wave & 1;
-  const int k0 = blockIdx.x * WG_T, n0 = blockIdx.y * WG_T;  // tile of dW [N, K]: rows n, columns k
+  const int k0 = blockIdx.x * T, n0 = blockIdx.y * T;  // tile of dW [N, K]: rows n, columns k
   const int mb = blockIdx.z * rows_per_split, me = min(M, mb + rows_per_split);
 
-  // staging: a slab is 16 batch rows x 128 columns of dY (and of X); thread -> (row r, 4-column chunk c4)
-  const int sr = tid >> 5, sc = (tid & 31) * 4;
-  float4 pa[2], pb[2];
+  // staging: a slab is 16 batch rows x T columns of dY (and of X); thread -> (row r, 4-column chunk c4)
+  const int sr = tid / CPR, sc = (tid % CPR) * 4;
+  float4 pa[NP], pb[NP];
   auto gload = [&](int m0) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int m = m0 + sr + 8 * i;
+    for (int i = 0; i < NP; ++i) {
+      const int m = m0 + sr + RPP * i;
       pa[i] = pb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (m < me) {
         if (n0 + sc < N) pa[i] = *reinterpret_cast<const float4 *>(dy + (size_t)m * lddy + n0 + sc);
@@ -41,8 +48,8 @@ __global__ void __launch_bounds__(256)
   };
   auto sstore = [&](int buf) {  // transposed: LDS row = output index (n or k), LDS column = batch row of the slab
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int r = sr + 8 * i;
+    for (int i = 0; i < NP; ++i) {
+      const int r = sr + RPP * i;
       As[buf][(sc + 0) * WG_LDT + r] = pa[i].x, As[buf][(sc + 1) * WG_LDT + r] = pa[i].y;
       As[buf][(sc + 2) * WG_LDT + r] = pa[i].z, As[buf][(sc + 3) * WG_LDT + r] = pa[i].w;
       Bs[buf][(sc + 0) * WG_LDT + r] = pb[i].x, Bs[buf][(sc + 1) * WG_LDT + r] = pb[i].y;
@@ -50,14 +57,14 @@ __global__ void __launch_bounds__(256)
     }
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[NT][NT];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < NT; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
   // bias gradient = column sums of dY: the workgroups of the first k-tile add up the slabs they stage anyway
-  const bool do_bias = with_bias && blockIdx.x == 0 && tid < WG_T;
+  const bool do_bias = with_bias && blockIdx.x == 0 && tid < T;
   float bsum = 0.0f;
   const int nslab = (me - mb + WG_BK - 1) / WG_BK;
   if (nslab > 0) {
@@ -68,22 +75,22 @@ __global__ void __launch_bounds__(256)
   for (int kb = 0; kb < nslab; ++kb) {
     const int buf = kb & 1;
     if (kb + 1 < nslab) gload(mb + (kb + 1) * WG_BK);
-    float4 a[2][2], b[2][2];
+    float4 a[NT][2], b[NT][2];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int v = 0; v < 2; ++v) {
-        a[t][v] = *reinterpret_cast<const float4 *>(&As[buf][(wm * 64 + t * 32 + l31) * WG_LDT + 8 * half + 4 * v]);
-        b[t][v] = *reinterpret_cast<const float4 *>(&Bs[buf][(wn * 64 + t * 32 + l31) * WG_LDT + 8 * half + 4 * v]);
+        a[t][v] = *reinterpret_cast<const float4 *>(&As[buf][(wm * (T / 2) + t * 32 + l31) * WG_LDT + 8 * half + 4 * v]);
+        b[t][v] = *reinterpret_cast<const float4 *>(&Bs[buf][(wn * (T / 2) + t * 32 + l31) * WG_LDT + 8 * half + 4 * v]);
       }
 #pragma unroll
     for (int v = 0; v < 2; ++v)
 #pragma unroll
       for (int u = 0; u < 4; ++u)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < NT; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
+          for (int j = 0; j < NT; ++j) {
             const float av = u == 0 ? a[i][v].x : (u == 1 ? a[i][v].y : (u == 2 ? a[i][v].z : a[i][v].w));
             const float bv = u == 0 ? b[j][v].x : (u == 1 ? b[j][v].y : (u == 2 ? b[j][v].z : b[j][v].w));
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
@@ -102,26 +109,33 @@ __global__ void __launch_bounds__(256)
   float *dst = partial + (size_t)blockIdx.z * ((size_t)N * K + N);
   if (do_bias && n0 + tid < N) dst[(size_t)N * K + n0 + tid] = bsum;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < NT; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int k = k0 + wn * 64 + j * 32 + l31;
+    for (int j = 0; j < NT; ++j) {
+      const int k = k0 + wn * (T / 2) + j * 32 + l31;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int n = n0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int n = n0 + wm * (T / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
         if (n < N && k < K) dst[(size_t)n * K + k] = acc[i][j][r];
       }
     }
 }
 
-// out[i] = sum_s partial[s * stride + i], s ascending
+// out[i] = sum_s partial[s * stride + i] in a FIXED order: sixteen lanes per output element, lane l adds the splits l,
+// l + 16, ... in ascending order, then the sixteen sums are added pairwise in a fixed tree (deterministic; one thread
+// per element walked up to 1024 dependent loads -- 90 us per layer at the batch sizes of training)
 __global__ void __launch_bounds__(256)
     reduce_partials_kernel(const float *__restrict__ partial, int S, int64_t stride, int64_t n, float *__restrict__ out) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
+  const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
+  const int l = threadIdx.x & 15;
   float acc = 0.0f;
-  for (int s = 0; s < S; ++s) acc += partial[(size_t)s * stride + i];
-  out[i] = acc;
+  if (i < n)
+    for (int s = l; s < S; s += 16) acc += partial[(size_t)s * stride + i];
+  acc += __shfl_xor(acc, 8, 16);
+  acc += __shfl_xor(acc, 4, 16);
+  acc += __shfl_xor(acc, 2, 16);
+  acc += __shfl_xor(acc, 1, 16);
+  if (i < n && l == 0) out[i] = acc;
 }
 
 // dz = dy * act'(y): ReLU -> y > 0; LeakyReLU(0.01) -> y >= 0 ? 1 : 0.01 (sign of the output = sign of the input)
@@ -234,12 +248,16 @@ MPX_EXPORT int mpx_groupnorm_leaky_grad(const float *x, const float *gamma, cons
   MPX_LAUNCH_CHECK("mpx_groupnorm_leaky_grad");
 }
 
-MPX_EXPORT int64_t mpx_linear_wgrad_scratch(int M, int N, int K) {
-  const int tiles = cdiv(N, WG_T) * cdiv(K, WG_T);
+static int wgrad_tile(int N, int K) { return (N <= 64 && K <= 64) ? 64 : 128; }
+static int wgrad_splits(int M, int N, int K) {
+  const int T = wgrad_tile(N, K);
+  const int tiles = cdiv(N, T) * cdiv(K, T);
   int S = cdiv(1024, tiles);
   const int maxs = cdiv(M, 4 * WG_BK);
-  S = S < 1 ? 1 : (S > maxs ? (maxs < 1 ? 1 : maxs) : S);
-  return (int64_t)S * ((int64_t)N * K + N);  // floats: weight partials + bias partials
+  return S < 1 ? 1 : (S > maxs ? (maxs < 1 ? 1 : maxs) : S);
+}
+MPX_EXPORT int64_t mpx_linear_wgrad_scratch(int M, int N, int K) {
+  return (int64_t)wgrad_splits(M, N, K) * ((int64_t)N * K + N);  // floats: weight partials + bias partials
 }
 
 MPX_EXPORT int mpx_linear_wgrad(const float *dy, int lddy, const float *x, int ldx, int M, int N, int K, float *dw,
@@ -250,21 +268,25 @@ MPX_EXPORT int mpx_linear_wgrad(const float *dy, int lddy, const float *x, int l
   MPX_REQUIRE((((uintptr_t)dy | (uintptr_t)x) & 15) == 0, "mpx_linear_wgrad: operands must be 16-byte aligned");
   MPX_REQUIRE(dw && scratch, "mpx_linear_wgrad: NULL output / scratch");
   const int64_t per = (int64_t)N * K + N;
-  const int S = (int)(mpx_linear_wgrad_scratch(M, N, K) / per);
+  const int S = wgrad_splits(M, N, K), T = wgrad_tile(N, K);
   const int rps = cdiv(cdiv(M, S), WG_BK) * WG_BK;
-  MPX_REQUIRE(cdiv(N, WG_T) <= 65535 && S <= 65535, "mpx_linear_wgrad: grid too large");
-  hipLaunchKernelGGL(linear_wgrad_kernel, dim3(cdiv(K, WG_T), cdiv(N, WG_T), S), dim3(256), 0, mpx_s(stream), dy, lddy, x,
-                     ldx, M, N, K, rps, scratch, db ? 1 : 0);
+  MPX_REQUIRE(cdiv(N, T) <= 65535 && S <= 65535, "mpx_linear_wgrad: grid too large");
+  if (T == 64)
+    hipLaunchKernelGGL(linear_wgrad_kernel<64>, dim3(cdiv(K, T), cdiv(N, T), S), dim3(256), 0, mpx_s(stream), dy, lddy, x,
+                       ldx, M, N, K, rps, scratch, db ? 1 : 0);
+  else
+    hipLaunchKernelGGL(linear_wgrad_kernel<128>, dim3(cdiv(K, T), cdiv(N, T), S), dim3(256), 0, mpx_s(stream), dy, lddy, x,
+                       ldx, M, N, K, rps, scratch, db ? 1 : 0);
   // dw [N*K] and db [N] are adjacent in every split's slice: one reduction (db lands right behind dw if the caller
   // laid them out that way, else two launches)
   if (db == dw + (size_t)N * K) {
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(per, 256)), dim3(256), 0, mpx_s(stream), scratch, S, per, per, dw);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(per * 16, 256)), dim3(256), 0, mpx_s(stream), scratch, S, per, per, dw);
   } else {
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv((int64_t)N * K, 256)), dim3(256), 0, mpx_s(stream), scratch, S,
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv((int64_t)N * K * 16, 256)), dim3(256), 0, mpx_s(stream), scratch, S,
                        per, (int64_t)N * K, dw);
     if (db)
-      hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(N, 256)), dim3(256), 0, mpx_s(stream), scratch + (size_t)N * K,
-                         S, per, (int64_t)N, db);
+      hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv((int64_t)N * 16, 256)), dim3(256), 0, mpx_s(stream),
+                         scratch + (size_t)N * K, S, per, (int64_t)N, db);
   }
   MPX_LAUNCH_CHECK("mpx_linear_wgrad");
 }

@@ -69,6 +69,20 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// dy[arg[q,c], c] = dout[q,c] * act'(out[q,c])  (the pooled value IS the activation output at the arg-max row: the
+// elementwise backward of the layer in front of the pool costs nothing extra here)
+__global__ void __launch_bounds__(256)
+    segment_max_grad_act_kernel(const float *__restrict__ dout, int ds, const int64_t *__restrict__ arg,
+                                const float *__restrict__ out, int os, int64_t total, int C, int act,
+                                float *__restrict__ dy) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int64_t q = i / C;
+  const int c = (int)(i - q * C);
+  const float g = dout[q * ds + c], o = out[q * os + c];
+  dy[arg[i] * C + c] = act == MPX_ACT_RELU ? (o > 0.0f ? g : 0.0f) : (act == MPX_ACT_LEAKY ? (o >= 0.0f ? g : 0.01f * g) : g);
+}
+
 // dy[arg[q,c], c] = dout[q,c]  (dy zero-filled by the caller; every (q,c) owns a distinct element)
 __global__ void __launch_bounds__(256)
     segment_max_grad_kernel(const float *__restrict__ dout, int ds, const int64_t *__restrict__ arg, int64_t total,
@@ -120,4 +134,14 @@ MPX_EXPORT int mpx_segment_max_grad(const float *grad_out, int grad_stride, cons
   hipLaunchKernelGGL(segment_max_grad_kernel, dim3(cdiv(Q * C, 256)), dim3(256), 0, mpx_s(stream), grad_out,
                      grad_stride, arg, Q * C, C, grad_y);
   MPX_LAUNCH_CHECK("mpx_segment_max_grad");
+}
+
+MPX_EXPORT int mpx_segment_max_grad_act(const float *grad_out, int grad_stride, const int64_t *arg, const float *out,
+                                        int out_stride, int64_t Q, int C, int act, float *grad_y, mpx_stream_t stream) {
+  MPX_REQUIRE(Q >= 0 && C > 0 && grad_stride >= C && out_stride >= C, "mpx_segment_max_grad_act: bad size");
+  MPX_REQUIRE(act >= 0 && act <= 2 && out != nullptr, "mpx_segment_max_grad_act: bad activation / missing pooled rows");
+  if (Q == 0) return 0;
+  hipLaunchKernelGGL(segment_max_grad_act_kernel, dim3(cdiv(Q * C, 256)), dim3(256), 0, mpx_s(stream), grad_out,
+                     grad_stride, arg, out, out_stride, Q * C, C, act, grad_y);
+  MPX_LAUNCH_CHECK("mpx_segment_max_grad_act");
 }

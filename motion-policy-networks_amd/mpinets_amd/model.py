@@ -23,7 +23,7 @@ from torch import nn
 
 from . import _lib
 from .pointnet2 import (FACTORED_SHAPE, PRECISIONS, PointnetSAModule, SplitWeights, groupnorm_leaky, groupnorm_leaky_train,
-                        launch_sa, linear, linear_train, linear_x3, sa_mlp_factored)
+                        launch_sa, linear, linear_train, linear_x3, mlp_chain_train, sa_mlp_factored)
 from .utils import unnormalize_franka_joints
 
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
@@ -191,8 +191,7 @@ class MPiNetsPointNet(nn.Module):
         f2 = sa_module_train(sa2.convs(), xyz1, 3, xyz2, 3, f1, f1.size(2), f1.size(2), nbr2, cnt2,
                              (B, sa1.npoint, sa2.npoint, sa2.nsample))
         h = torch.cat((xyz2, f2), dim=2)  # group-all: absolute coordinates | features
-        for conv in sa3.convs():
-            h = linear_train(h, conv.weight.view(conv.out_channels, -1), conv.bias, ACT_RELU)
+        h = mlp_chain_train(h, [(c.weight.view(c.out_channels, -1), c.bias) for c in sa3.convs()], [ACT_RELU] * 3)
         pooled = h.max(dim=1).values
         self.last_counts = (cnt1, cnt2)
         if aux is not None:
@@ -555,11 +554,10 @@ class MotionPolicyNetwork(nn.Module):
         if self.training and torch.is_grad_enabled():  # differentiable path (training_step)
             pc_encoding = self.point_cloud_encoder(xyz, aux=aux)
 
-            def mlp(seq, x):  # Linear + LeakyReLU stacks: every layer is one fused forward / backward pair
+            def mlp(seq, x):  # Linear + LeakyReLU stacks: one autograd node, activation backward in the GEMM epilogues
                 layers = [m for m in seq if isinstance(m, nn.Linear)]
-                for i, lin in enumerate(layers):
-                    x = linear_train(x, lin.weight, lin.bias, ACT_LEAKY if i + 1 < len(layers) else ACT_NONE)
-                return x
+                return mlp_chain_train(x, [(lin.weight, lin.bias) for lin in layers],
+                                       [ACT_LEAKY] * (len(layers) - 1) + [ACT_NONE])
 
             return mlp(self.decoder, torch.cat((pc_encoding, mlp(self.feature_encoder, _lib.f32c(q))), dim=1))
         cat = torch.empty((B, 2048 + 64), dtype=torch.float32, device=dev)

@@ -414,6 +414,122 @@ class _SegmentMax(torch.autograd.Function):
         return gy, None, None
 
 
+def _pad4(t: torch.Tensor, rows: bool = False) -> torch.Tensor:
+    """Zero-pad the last (or with ``rows`` the first) dimension of a matrix to a multiple of 4."""
+    n = t.size(0 if rows else 1)
+    n4 = (n + 3) // 4 * 4
+    if n4 == n:
+        return t
+    return torch.nn.functional.pad(t, (0, 0, 0, n4 - n) if rows else (0, n4 - n))
+
+
+class _MLPChainFn(torch.autograd.Function):
+    """A stack of dense layers ``h <- act_i(h @ W_i.T + b_i)`` as ONE autograd node (row N1).
+
+    Versus one ``_LinearFn`` per layer the backward never materialises ``dY * act'(y)`` in a pass of its own: the
+    input-gradient GEMM of layer i+1 applies the elementwise backward of layer i's activation in its epilogue
+    (``mpx_linear_dact``), and when the stack feeds a segment max-pool (``offsets`` given: the set-abstraction modules)
+    the pool's backward applies the last activation's (``mpx_segment_max_grad_act``) -- the last layer's output rows are
+    then not kept at all, only the pooled rows and their arg-max.  Arithmetic per element is that of
+    ``mpx_act_backward``; gradients equal the per-layer form bit for bit where that form takes the same GEMM kernel (the
+    input-gradient product here is always the 128 x 128 tile kernel; ``linear`` splits K or takes its few-row kernel for
+    skinny problems: a different summation order).
+    Arguments: x [M, K0], acts (tuple of activation codes), offsets (int64 [Q+1] or None), then W_0, b_0, W_1, b_1, ...
+    Returns the last layer's rows [M, N_last], or the pooled rows [Q, N_last] with ``offsets``.
+    """
+
+    @staticmethod
+    def forward(ctx, x, acts, offsets, *wb):
+        L = len(acts)
+        assert len(wb) == 2 * L and x.ndim == 2
+        M, K0 = x.shape
+        h = _pad4(_lib.f32c(x.detach()))
+        xs, ws, meta = [], [], []
+        for i in range(L):
+            w, b = wb[2 * i], wb[2 * i + 1]
+            N, K = w.shape
+            wp = _pad4(_lib.f32c(w.detach()))
+            assert h.size(1) == wp.size(1), "layer widths do not chain"
+            y = linear(h, wp, None if b is None else _lib.f32c(b.detach()), acts[i])
+            xs.append(h)
+            ws.append(wp)
+            meta.append((N, K, b is not None))
+            h = _pad4(y) if (i + 1 < L and N % 4) else y
+        pooled = arg = None
+        if offsets is not None:
+            Q = offsets.numel() - 1
+            C = h.size(1)
+            pooled = torch.empty((Q, C), dtype=torch.float32, device=h.device)
+            arg = torch.empty((Q, C), dtype=torch.int64, device=h.device)
+            _lib.call("mpx_segment_max", _lib.ptr(h), C, _lib.ptr(offsets), Q, _lib.ptr(pooled), C, _lib.ptr(arg))
+            ctx.save_for_backward(*xs, *ws, pooled, arg)  # (the last layer's rows are not needed again)
+        else:
+            ctx.save_for_backward(*xs, *ws, h)
+        ctx.meta = (tuple(acts), tuple(meta), M, K0, offsets is not None)
+        return pooled if offsets is not None else h
+
+    @staticmethod
+    def backward(ctx, g):
+        acts, meta, M, K0, pooled_out = ctx.meta
+        L = len(acts)
+        saved = ctx.saved_tensors
+        xs, ws = saved[:L], saved[L:2 * L]
+        g = _lib.f32c(g)
+        dev = g.device
+        N_last = meta[-1][0]
+        if pooled_out:
+            pooled, arg = saved[2 * L], saved[2 * L + 1]
+            Q, C = pooled.shape
+            dz = torch.zeros((M, C), dtype=torch.float32, device=dev)
+            _lib.call("mpx_segment_max_grad_act", _lib.ptr(g), g.stride(0), _lib.ptr(arg), _lib.ptr(pooled), C, Q, C, acts[-1],
+                      _lib.ptr(dz))
+        else:
+            y_last = saved[2 * L]
+            if acts[-1]:
+                dz = torch.empty_like(g)
+                _lib.call("mpx_act_backward", _lib.ptr(g), _lib.ptr(y_last), g.numel(), acts[-1], _lib.ptr(dz))
+            else:
+                dz = g
+        grads = [None] * (2 * L)
+        for i in range(L - 1, -1, -1):
+            N, K, has_bias = meta[i]
+            Np, Kp = (N + 3) // 4 * 4, ws[i].size(1)
+            dz = _pad4(dz) if dz.size(1) != Np else dz
+            if ctx.needs_input_grad[3 + 2 * i] or (has_bias and ctx.needs_input_grad[4 + 2 * i]):
+                both = torch.empty(Np * Kp + Np, dtype=torch.float32, device=dev)  # dw | db: one reduction launch
+                dw = both[:Np * Kp].view(Np, Kp)
+                db = both[Np * Kp:] if has_bias else None
+                scratch = torch.empty(_lib.load().mpx_linear_wgrad_scratch(M, Np, Kp), dtype=torch.float32, device=dev)
+                _lib.call("mpx_linear_wgrad", _lib.ptr(dz), dz.stride(0), _lib.ptr(xs[i]), xs[i].stride(0), M, Np, Kp,
+                          _lib.ptr(dw), _lib.ptr(db), _lib.ptr(scratch))
+                grads[2 * i] = dw[:N, :K]
+                grads[2 * i + 1] = db[:N] if has_bias else None
+            if i > 0 or ctx.needs_input_grad[0]:
+                wt = _pad4(ws[i], rows=True).t().contiguous()  # [Kp, Np]
+                gx = torch.empty((M, Kp), dtype=torch.float32, device=dev)
+                below = acts[i - 1] if i > 0 else 0
+                # xs[i] IS the output of layer i - 1 (zero-padded columns: their gradient columns are dropped below)
+                _lib.call("mpx_linear_dact", _lib.ptr(dz), dz.stride(0), _lib.ptr(wt), M, Kp, Np,
+                          _lib.ptr(xs[i]) if below else None, xs[i].stride(0), below, _lib.ptr(gx), Kp)
+                dz = gx
+            else:
+                dz = None
+        gx0 = dz[:, :K0] if (dz is not None and ctx.needs_input_grad[0]) else None
+        return (gx0, None, None) + tuple(grads)
+
+
+def mlp_chain_train(x: torch.Tensor, layers, acts, offsets: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Differentiable stack of dense layers on the engine's kernels (one autograd node, see ``_MLPChainFn``).
+    ``layers``: sequence of (weight [N,K], bias or None); ``acts``: one activation code per layer; ``x`` may have leading
+    batch dimensions (flattened; not with ``offsets``)."""
+    lead = x.shape[:-1]
+    wb = []
+    for w, b in layers:
+        wb += [w, b]
+    y = _MLPChainFn.apply(x.reshape(-1, x.size(-1)), tuple(int(a) for a in acts), offsets, *wb)
+    return y if offsets is not None else y.reshape(lead + (y.size(-1),))
+
+
 def sa_module_train(convs: List[nn.Conv2d], xyz: torch.Tensor, xyz_stride: int, new_xyz: torch.Tensor,
                     new_stride: int, feat: torch.Tensor, feat_stride: int, C: int, idx: torch.Tensor,
                     cnt: torch.Tensor, dims: Tuple[int, int, int, int]) -> torch.Tensor:
@@ -424,9 +540,8 @@ def sa_module_train(convs: List[nn.Conv2d], xyz: torch.Tensor, xyz_stride: int, 
     torch.cumsum(cnt.reshape(-1).clamp(min=1), 0, out=offsets[1:])
     R = int(offsets[-1].item())  # one host sync per module and step: the row count sizes the activations
     h = _PackRows.apply(feat, xyz, xyz_stride, new_xyz, new_stride, feat_stride, C, idx, cnt, offsets, R, dims)
-    for conv in convs:
-        h = linear_train(h, conv.weight.view(conv.out_channels, -1), conv.bias, 1)
-    return _SegmentMax.apply(h, offsets, B * npoint).view(B, npoint, -1)
+    layers = [(conv.weight.view(conv.out_channels, -1), conv.bias) for conv in convs]
+    return mlp_chain_train(h, layers, [1] * len(layers), offsets=offsets).view(B, npoint, -1)
 
 
 class PointnetSAModule(nn.Module):

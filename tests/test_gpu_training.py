@@ -173,6 +173,70 @@ def test_linear_train_matches_torch_autograd():
     assert torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("pooled", [False, True])
+def test_mlp_chain_is_the_per_layer_backward_without_the_activation_passes(pooled):
+    """``mlp_chain_train`` (one autograd node for a stack of dense layers; the activation's elementwise backward rides in
+    the input-gradient GEMM's epilogue, mpx_linear_dact, or in the max-pool's backward, mpx_segment_max_grad_act) vs the
+    per-layer nodes (``linear_train`` + ``_SegmentMax``): the same kernels' arithmetic per element -- gradients equal bit
+    for bit at sizes where both take the 128 x 128 tile GEMM -- and vs torch autograd in float64.
+    Widths as in the set-abstraction modules (67 -> 128 -> 128 -> 256; a 7-wide output for the decoder's shape)."""
+    from mpinets_amd.pointnet2 import _SegmentMax, linear_train, mlp_chain_train
+
+    rng = np.random.default_rng(3)
+    M = 3000
+    widths, acts = ((67, 128, 128, 256), (1, 1, 1)) if pooled else ((132, 512, 64, 7), (2, 2, 0))
+    mk = lambda *sh, s=1.0: torch.tensor(rng.normal(size=sh) * s, dtype=torch.float32, device=dev())
+    x0 = mk(M, widths[0])
+    ws = [mk(widths[i + 1], widths[i], s=1 / np.sqrt(widths[i])) for i in range(3)]
+    bs = [mk(widths[i + 1]) for i in range(3)]
+    offsets = None
+    if pooled:
+        seg = rng.integers(1, 40, size=400)
+        seg = seg[np.cumsum(seg) <= M]  # segments of 1..39 rows, the last one takes the remainder
+        seg[-1] += M - seg.sum()
+        offsets = torch.tensor(np.concatenate([[0], np.cumsum(seg)]), dtype=torch.int64, device=dev())
+    n_out = (offsets.numel() - 1) if pooled else M
+    g = mk(n_out, widths[-1])
+
+    def run(kind):
+        x = x0.clone().requires_grad_(True)
+        w = [t.clone().requires_grad_(True) for t in ws]
+        b = [t.clone().requires_grad_(True) for t in bs]
+        if kind == "chain":
+            y = mlp_chain_train(x, list(zip(w, b)), acts, offsets=offsets)
+        else:
+            h = x
+            for i in range(3):
+                h = linear_train(h, w[i], b[i], acts[i])
+            y = _SegmentMax.apply(h, offsets, n_out) if pooled else h
+        (y * g).sum().backward()
+        return y.detach(), [x.grad] + [t.grad for t in w] + [t.grad for t in b]
+
+    y_c, g_c = run("chain")
+    y_l, g_l = run("layers")
+    assert torch.equal(y_c, y_l)
+    for a, b_ in zip(g_c, g_l):
+        assert torch.equal(a, b_)
+    # float64 reference
+    xd = x0.double().requires_grad_(True)
+    wd = [t.double().requires_grad_(True) for t in ws]
+    bd = [t.double().requires_grad_(True) for t in bs]
+    h = xd
+    for i in range(3):
+        z = torch.nn.functional.linear(h, wd[i], bd[i])
+        h = z if acts[i] == 0 else (torch.relu(z) if acts[i] == 1 else torch.nn.functional.leaky_relu(z, 0.01))
+    if pooled:
+        h = torch.stack([h[offsets[q]:offsets[q + 1]].max(dim=0).values for q in range(n_out)])
+    (h * g.double()).sum().backward()
+    for got, ref in zip(g_c, [xd.grad] + [t.grad for t in wd] + [t.grad for t in bd]):
+        assert (got.double() - ref).abs().max() <= 3e-5 * max(ref.abs().max().item(), 1e-6) * np.sqrt(M / 64)
+    # a stack whose input needs no gradient (the first module: its rows are data) returns none for it
+    xn = x0.clone()
+    w = [t.clone().requires_grad_(True) for t in ws]
+    mlp_chain_train(xn, [(w[i], None) for i in range(3)], acts, offsets=offsets).sum().backward()
+    assert all(t.grad is not None and torch.isfinite(t.grad).all() for t in w)
+
+
 def test_groupnorm_leaky_backward_matches_torch():
     from mpinets_amd.pointnet2 import groupnorm_leaky_train
 
