@@ -29,7 +29,7 @@ typedef void *mpx_stream_t;
 
 #define MPX_NUM_FRAMES 15 /* link0..8, hand, leftfinger, rightfinger, l/r fingertip, right_gripper */
 
-int mpx_version(void); /* 320: mpx_linear_dact, mpx_segment_max_grad_act (additions only); mpx_franka_collision accepts
+int mpx_version(void); /* 320: mpx_linear_dact, mpx_segment_max_grad_act, mpx_linear_bf16x3_dact, mpx_linear_wgrad_bf16x3 (additions only); mpx_franka_collision accepts
                           frame pointers that are not 16-byte aligned;
                           310: struct mpx_policy_weights ends with sa3_pack (NULL = layer-by-layer group-all module at every
                           batch size; a caller built against the 200 header must be rebuilt), MPX_VARIANT_UNIT_QUEUE,
@@ -193,6 +193,14 @@ int mpx_act_backward(const float *dy, const float *y, int64_t n, int act, float 
  * product).  Same arithmetic as mpx_linear(x, w) followed by mpx_act_backward.  loss.py / model.py:185-240 via autograd. */
 int mpx_linear_dact(const float *x, int ldx, const float *w, int M, int N, int K, const float *dact_of,
                     int lddact, int dact, float *y, int ldy, mpx_stream_t stream);
+/* The training GEMMs in the split-bf16 arithmetic of the `bf16x3` mode (three bf16 MFMAs per fp32 product, fp32
+ * accumulate, fp32 master weights: the engine's form of the reference's precision=16, run_training.py:112): the forward is
+ * mpx_linear_bf16x3; dX = mpx_linear_bf16x3_dact (w_pairs = mpx_split_bf16 of the TRANSPOSED weights); dW / db =
+ * mpx_linear_wgrad_bf16x3 (same arguments, scratch and split reduction as mpx_linear_wgrad).                           */
+int mpx_linear_bf16x3_dact(const float *x, int ldx, const void *w_pairs, int M, int N, int K, const float *dact_of,
+                           int lddact, int dact, float *y, int ldy, mpx_stream_t stream);
+int mpx_linear_wgrad_bf16x3(const float *dy, int lddy, const float *x, int ldx, int M, int N, int K, float *dw,
+                            float *db, float *scratch, mpx_stream_t stream);
 int64_t mpx_linear_wgrad_scratch(int M, int N, int K);
 int mpx_linear_wgrad(const float *dy, int lddy, const float *x, int ldx, int M, int N, int K, float *dw,
                      float *db, float *scratch, mpx_stream_t stream);

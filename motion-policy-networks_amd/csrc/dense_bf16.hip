@@ -51,14 +51,25 @@ __global__ void __launch_bounds__(256)
 // plane).
 constexpr int HB_LDC = 64 + 4;
 __device__ __forceinline__ void hb_store_rows(const float *stage, int lane, int row0, int col0, int M, int N, float *y,
-                                              int ldy, bool vec_ok, __bf16 *yp, int ldp) {
+                                              int ldy, bool vec_ok, __bf16 *yp, int ldp, const float *dact_of = nullptr,
+                                              int lddact = 0, int dact = 0) {
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
     const int e = t * 64 + lane;
     const int rr = e >> 4, c4 = (e & 15) * 4;
     const int row = row0 + rr, col = col0 + c4;
-    const float4 v = *reinterpret_cast<const float4 *>(&stage[rr * HB_LDC + c4]);
+    float4 v = *reinterpret_cast<const float4 *>(&stage[rr * HB_LDC + c4]);
     if (row >= M || col >= N) continue;
+    if (dact_of != nullptr) {  // (mpx_linear_bf16x3_dact: times act'(output of the layer below), as mpx_act_backward does)
+      const float *mk = dact_of + (size_t)row * lddact + col;
+      const float m0 = mk[0], m1 = col + 1 < N ? mk[1] : 0.0f, m2 = col + 2 < N ? mk[2] : 0.0f, m3 = col + 3 < N ? mk[3] : 0.0f;
+      if (dact == MPX_ACT_RELU) {
+        v.x = m0 > 0.0f ? v.x : 0.0f, v.y = m1 > 0.0f ? v.y : 0.0f, v.z = m2 > 0.0f ? v.z : 0.0f, v.w = m3 > 0.0f ? v.w : 0.0f;
+      } else if (dact == MPX_ACT_LEAKY) {
+        v.x = m0 >= 0.0f ? v.x : 0.01f * v.x, v.y = m1 >= 0.0f ? v.y : 0.01f * v.y;
+        v.z = m2 >= 0.0f ? v.z : 0.01f * v.z, v.w = m3 >= 0.0f ? v.w : 0.01f * v.w;
+      }
+    }
     if (yp != nullptr) {  // (launcher: N is a multiple of 4; the pad columns of the last 16-group are written by the
                           // caller's zero fill or never read: K of the next layer = N)
       const float f[4] = {v.x, v.y, v.z, v.w};
@@ -89,7 +100,7 @@ template <bool POOL>
 __global__ void __launch_bounds__(256)
     linear_bf16x3_kernel(const float *__restrict__ x, int ldx, const __bf16 *__restrict__ w, int ldw,
                          const float *__restrict__ bias, int M, int N, int K, int Kp, int act, float *__restrict__ y,
-                         int ldy, __bf16 *__restrict__ yp, int ldp) {
+                         int ldy, __bf16 *__restrict__ yp, int ldp, const float *__restrict__ dact_of, int lddact, int dact) {
   // [stage][plane: A_hi, A_lo, B_hi, B_lo][128 rows x LDT]
   __shared__ __attribute__((aligned(16))) __bf16 smem[2 * 4 * HB_BM * HB_LDT];
   auto plane = [&](int stage, int p) { return smem + ((stage * 4 + p) * HB_BM) * HB_LDT; };
@@ -210,7 +221,7 @@ __global__ void __launch_bounds__(256)
         for (int r = 0; r < 16; ++r)
           stage[((r & 3) + 8 * (r >> 2) + 4 * half) * LDC + j * 32 + l31] = hb_act(acc[i][j][r] + bv, act);
       }
-      hb_store_rows(stage, lane, m0 + wm * 64 + i * 32, n0 + wn * 64, M, N, y, ldy, vec_ok, yp, ldp);
+      hb_store_rows(stage, lane, m0 + wm * 64 + i * 32, n0 + wn * 64, M, N, y, ldy, vec_ok, yp, ldp, dact_of, lddact, dact);
     }
   }
 }
@@ -416,7 +427,7 @@ MPX_EXPORT int mpx_linear_bf16x3(const float *x, int ldx, const void *w_pairs, c
   }
   hipLaunchKernelGGL((linear_bf16x3_kernel<false>), dim3(cdiv(N, HB_BN), cdiv(M, HB_BM)), dim3(256), 0, mpx_s(stream), x,
                      ldx, reinterpret_cast<const __bf16 *>(w_pairs), 2 * hb_kp(K), bias, M, N, K, hb_kp(K), act, y, ldy,
-                     (__bf16 *)nullptr, 0);
+                     (__bf16 *)nullptr, 0, (const float *)nullptr, 0, 0);
   MPX_LAUNCH_CHECK("mpx_linear_bf16x3");
 }
 
@@ -435,7 +446,7 @@ MPX_EXPORT int mpx_linear_bf16x3_to_pairs(const float *x, int ldx, const void *w
   }
   hipLaunchKernelGGL((linear_bf16x3_kernel<false>), dim3(cdiv(N, HB_BN), cdiv(M, HB_BM)), dim3(256), 0, mpx_s(stream), x,
                      ldx, reinterpret_cast<const __bf16 *>(w_pairs), 2 * hb_kp(K), bias, M, N, K, hb_kp(K), act,
-                     (float *)nullptr, 0, reinterpret_cast<__bf16 *>(y_pairs), ldp);
+                     (float *)nullptr, 0, reinterpret_cast<__bf16 *>(y_pairs), ldp, (const float *)nullptr, 0, 0);
   MPX_LAUNCH_CHECK("mpx_linear_bf16x3_to_pairs");
 }
 
@@ -456,7 +467,7 @@ MPX_EXPORT int mpx_linear_rowmax_bf16x3(const float *x, int ldx, const void *w_p
   MPX_REQUIRE(e == hipSuccess, "mpx_linear_rowmax_bf16x3: memset failed: %s", hipGetErrorString(e));
   hipLaunchKernelGGL((linear_bf16x3_kernel<true>), dim3(cdiv(N, HB_BN), M / HB_BM), dim3(256), 0, mpx_s(stream), x, ldx,
                      reinterpret_cast<const __bf16 *>(w_pairs), 2 * hb_kp(K), bias, M, N, K, hb_kp(K), (int)MPX_ACT_RELU, y,
-                     ldy, (__bf16 *)nullptr, 0);
+                     ldy, (__bf16 *)nullptr, 0, (const float *)nullptr, 0, 0);
   MPX_LAUNCH_CHECK("mpx_linear_rowmax_bf16x3");
 }
 
@@ -534,4 +545,141 @@ MPX_EXPORT int mpx_linear_rowmax_bf16x3_pairs(const void *a_pairs, int lda, cons
     PB_LAUNCH(3, grid, mpx_s(stream), ap, lda, wp, 2 * K, K, bias, M, N, (int)MPX_ACT_RELU, (float *)nullptr, 0,
               reinterpret_cast<__bf16 *>(y_pairs), ldp);
   MPX_LAUNCH_CHECK("mpx_linear_rowmax_bf16x3_pairs");
+}
+
+// ---- training (row N1) in the split-bf16 arithmetic ("AMP" of the reference, run_training.py:112 precision=16, with fp32
+// master weights and fp32 accumulation) ------------------------------------------------------------------------------
+// dX with the elementwise backward of the layer below in the epilogue (dense.hip: mpx_linear_dact): y = (x . w^T) * act'(dact_of)
+MPX_EXPORT int mpx_linear_bf16x3_dact(const float *x, int ldx, const void *w_pairs, int M, int N, int K, const float *dact_of,
+                                      int lddact, int dact, float *y, int ldy, mpx_stream_t stream) {
+  if (hb_check("mpx_linear_bf16x3_dact", x, ldx, w_pairs, M, N, K, ldy)) return 1;
+  MPX_REQUIRE(dact == MPX_ACT_NONE || (dact_of != nullptr && lddact >= N && (dact == MPX_ACT_RELU || dact == MPX_ACT_LEAKY)),
+              "mpx_linear_bf16x3_dact: the activation's output rows are missing or too short, or the activation is unknown");
+  if (M == 0) return 0;
+  if (dact == MPX_ACT_NONE) dact_of = nullptr;
+  if (const int64_t slab = mpx_row_slab(HB_BM, 0); M > slab) {
+    for (int64_t m0 = 0; m0 < M; m0 += slab)
+      if (int rc = mpx_linear_bf16x3_dact(x + m0 * ldx, ldx, w_pairs, (int)(M - m0 < slab ? M - m0 : slab), N, K,
+                                          dact_of ? dact_of + m0 * lddact : nullptr, lddact, dact, y + m0 * ldy, ldy, stream))
+        return rc;
+    return 0;
+  }
+  hipLaunchKernelGGL((linear_bf16x3_kernel<false>), dim3(cdiv(N, HB_BN), cdiv(M, HB_BM)), dim3(256), 0, mpx_s(stream), x,
+                     ldx, reinterpret_cast<const __bf16 *>(w_pairs), 2 * hb_kp(K), (const float *)nullptr, M, N, K, hb_kp(K),
+                     (int)MPX_ACT_NONE, y, ldy, (__bf16 *)nullptr, 0, dact_of, lddact, dact);
+  MPX_LAUNCH_CHECK("mpx_linear_bf16x3_dact");
+}
+
+// dW [N, K] = dY^T . X, db = column sums of dY: dense_grad.hip's linear_wgrad_kernel<128> with every product as three
+// bf16 MFMAs.  A slab of 16 batch rows is ONE K16 step of v_mfma_f32_32x32x16_bf16; both operands are split hi / lo while
+// they are staged transposed into LDS (a thread holds two adjacent batch rows of four columns: each column's pair goes out
+// as one packed 4-byte store per plane; rows of 16 bf16 padded to 48 bytes: the 16-byte fragment reads of a quarter wave
+// touch every bank once).  Same split reduction over the rows and the same partial layout as the fp32 kernel.
+constexpr int WB_T = 128, WB_LDT = 24;  // tile; bf16 elements per padded LDS row (16 used)
+__device__ __forceinline__ void wb_split2(float v0, float v1, unsigned &hi, unsigned &lo) {
+  const __bf16 h0 = (__bf16)v0, h1 = (__bf16)v1;
+  const __bf16 l0 = (__bf16)(v0 - (float)h0), l1 = (__bf16)(v1 - (float)h1);
+  hi = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+  lo = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+}
+__global__ void __launch_bounds__(256)
+    linear_wgrad_bf16x3_kernel(const float *__restrict__ dy, int lddy, const float *__restrict__ x, int ldx, int M, int N,
+                               int K, int rows_per_split, float *__restrict__ partial, int with_bias) {
+  // [buffer][plane: A_hi, A_lo, B_hi, B_lo][128 rows x WB_LDT]
+  __shared__ __attribute__((aligned(16))) __bf16 smem[2 * 4 * WB_T * WB_LDT];
+  auto plane = [&](int buf, int p) { return smem + ((buf * 4 + p) * WB_T) * WB_LDT; };
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int k0 = blockIdx.x * WB_T, n0 = blockIdx.y * WB_T;  // tile of dW [N, K]: rows n, columns k
+  const int mb = blockIdx.z * rows_per_split, me = min(M, mb + rows_per_split);
+  // staging: thread -> batch rows (2 rp, 2 rp + 1) of the slab, columns sc .. sc + 3 of the tile
+  const int rp = tid >> 5, sc = (tid & 31) * 4;
+  float4 pa[2], pb[2];
+  auto gload = [&](int m0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = m0 + 2 * rp + i;
+      pa[i] = pb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m < me) {
+        if (n0 + sc < N) pa[i] = *reinterpret_cast<const float4 *>(dy + (size_t)m * lddy + n0 + sc);
+        if (k0 + sc < K) pb[i] = *reinterpret_cast<const float4 *>(x + (size_t)m * ldx + k0 + sc);
+      }
+    }
+  };
+  auto sstore = [&](int buf) {  // transposed: LDS row = output index (n or k), elements 2 rp, 2 rp + 1 of the row
+    const float a0[4] = {pa[0].x, pa[0].y, pa[0].z, pa[0].w}, a1[4] = {pa[1].x, pa[1].y, pa[1].z, pa[1].w};
+    const float b0[4] = {pb[0].x, pb[0].y, pb[0].z, pb[0].w}, b1[4] = {pb[1].x, pb[1].y, pb[1].z, pb[1].w};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      unsigned hi, lo;
+      wb_split2(a0[c], a1[c], hi, lo);
+      *reinterpret_cast<unsigned *>(plane(buf, 0) + (sc + c) * WB_LDT + 2 * rp) = hi;
+      *reinterpret_cast<unsigned *>(plane(buf, 1) + (sc + c) * WB_LDT + 2 * rp) = lo;
+      wb_split2(b0[c], b1[c], hi, lo);
+      *reinterpret_cast<unsigned *>(plane(buf, 2) + (sc + c) * WB_LDT + 2 * rp) = hi;
+      *reinterpret_cast<unsigned *>(plane(buf, 3) + (sc + c) * WB_LDT + 2 * rp) = lo;
+    }
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const bool do_bias = with_bias && blockIdx.x == 0 && tid < WB_T;
+  float bsum = 0.0f;
+  const int nslab = (me - mb + 15) / 16;
+  if (nslab > 0) {
+    gload(mb);
+    sstore(0);
+  }
+  __syncthreads();
+  for (int kb = 0; kb < nslab; ++kb) {
+    const int buf = kb & 1;
+    if (kb + 1 < nslab) gload(mb + (kb + 1) * 16);
+    bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {  // operand element e of lane-half h: batch row 8 h + e of the slab
+      const int ra = (wm * 64 + t * 32 + l31) * WB_LDT + 8 * half, rb = (wn * 64 + t * 32 + l31) * WB_LDT + 8 * half;
+      ah[t] = *reinterpret_cast<const bf16x8 *>(plane(buf, 0) + ra);
+      al[t] = *reinterpret_cast<const bf16x8 *>(plane(buf, 1) + ra);
+      bh[t] = *reinterpret_cast<const bf16x8 *>(plane(buf, 2) + rb);
+      bl[t] = *reinterpret_cast<const bf16x8 *>(plane(buf, 3) + rb);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+      }
+    if (do_bias) {  // column sums of dY from the staged split (hi + lo = the value to 2^-17 relative)
+      const __bf16 *rh = plane(buf, 0) + tid * WB_LDT, *rl = plane(buf, 1) + tid * WB_LDT;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) bsum += (float)rh[e] + (float)rl[e];
+    }
+    if (kb + 1 < nslab) sstore(buf ^ 1);
+    __syncthreads();
+  }
+  // per split: [N*K weight partials | N bias partials]; C[row][col]: col = lane&31 (k), row = (r&3) + 8*(r>>2) + 4*half (n)
+  float *dst = partial + (size_t)blockIdx.z * ((size_t)N * K + N);
+  if (do_bias && n0 + tid < N) dst[(size_t)N * K + n0 + tid] = bsum;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int k = k0 + wn * 64 + j * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (n < N && k < K) dst[(size_t)n * K + k] = acc[i][j][r];
+      }
+    }
+}
+// (host helper for dense_grad.hip's mpx_linear_wgrad_bf16x3: the split reduction and its partial layout live there)
+void mpx_wgrad_bf16x3_launch(const float *dy, int lddy, const float *x, int ldx, int M, int N, int K, int rows_per_split,
+                             int S, float *partial, int with_bias, hipStream_t stream) {
+  hipLaunchKernelGGL(linear_wgrad_bf16x3_kernel, dim3(cdiv(K, WB_T), cdiv(N, WB_T), S), dim3(256), 0, stream, dy, lddy, x,
+                     ldx, M, N, K, rows_per_split, partial, with_bias);
 }

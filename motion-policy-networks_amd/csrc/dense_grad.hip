@@ -260,18 +260,34 @@ MPX_EXPORT int64_t mpx_linear_wgrad_scratch(int M, int N, int K) {
   return (int64_t)wgrad_splits(M, N, K) * ((int64_t)N * K + N);  // floats: weight partials + bias partials
 }
 
+void mpx_wgrad_bf16x3_launch(const float *dy, int lddy, const float *x, int ldx, int M, int N, int K, int rows_per_split,
+                             int S, float *partial, int with_bias, hipStream_t stream);  // dense_bf16.hip
+static int wgrad_run(const char *name, bool x3, const float *dy, int lddy, const float *x, int ldx, int M, int N, int K,
+                     float *dw, float *db, float *scratch, mpx_stream_t stream);
 MPX_EXPORT int mpx_linear_wgrad(const float *dy, int lddy, const float *x, int ldx, int M, int N, int K, float *dw,
                                 float *db, float *scratch, mpx_stream_t stream) {
-  MPX_REQUIRE(M >= 1 && N >= 1 && K >= 1, "mpx_linear_wgrad: bad size");
+  return wgrad_run("mpx_linear_wgrad", false, dy, lddy, x, ldx, M, N, K, dw, db, scratch, stream);
+}
+// the same in the split-bf16 arithmetic (three bf16 MFMAs per fp32 product, fp32 accumulate; dense_bf16.hip); layers of
+// <= 64 inputs and outputs keep the fp32 kernel (their 64-wide tile)
+MPX_EXPORT int mpx_linear_wgrad_bf16x3(const float *dy, int lddy, const float *x, int ldx, int M, int N, int K, float *dw,
+                                       float *db, float *scratch, mpx_stream_t stream) {
+  return wgrad_run("mpx_linear_wgrad_bf16x3", true, dy, lddy, x, ldx, M, N, K, dw, db, scratch, stream);
+}
+static int wgrad_run(const char *name, bool x3, const float *dy, int lddy, const float *x, int ldx, int M, int N, int K,
+                     float *dw, float *db, float *scratch, mpx_stream_t stream) {
+  MPX_REQUIRE(M >= 1 && N >= 1 && K >= 1, "%s: bad size", name);
   MPX_REQUIRE(N % 4 == 0 && K % 4 == 0 && lddy % 4 == 0 && ldx % 4 == 0,
-              "mpx_linear_wgrad: N, K and the leading dimensions must be multiples of 4");
-  MPX_REQUIRE((((uintptr_t)dy | (uintptr_t)x) & 15) == 0, "mpx_linear_wgrad: operands must be 16-byte aligned");
-  MPX_REQUIRE(dw && scratch, "mpx_linear_wgrad: NULL output / scratch");
+              "%s: N, K and the leading dimensions must be multiples of 4", name);
+  MPX_REQUIRE((((uintptr_t)dy | (uintptr_t)x) & 15) == 0, "%s: operands must be 16-byte aligned", name);
+  MPX_REQUIRE(dw && scratch, "%s: NULL output / scratch", name);
   const int64_t per = (int64_t)N * K + N;
   const int S = wgrad_splits(M, N, K), T = wgrad_tile(N, K);
   const int rps = cdiv(cdiv(M, S), WG_BK) * WG_BK;
-  MPX_REQUIRE(cdiv(N, T) <= 65535 && S <= 65535, "mpx_linear_wgrad: grid too large");
-  if (T == 64)
+  MPX_REQUIRE(cdiv(N, T) <= 65535 && S <= 65535, "%s: grid too large", name);
+  if (x3 && T == 128)
+    mpx_wgrad_bf16x3_launch(dy, lddy, x, ldx, M, N, K, rps, S, scratch, db ? 1 : 0, mpx_s(stream));
+  else if (T == 64)
     hipLaunchKernelGGL(linear_wgrad_kernel<64>, dim3(cdiv(K, T), cdiv(N, T), S), dim3(256), 0, mpx_s(stream), dy, lddy, x,
                        ldx, M, N, K, rps, scratch, db ? 1 : 0);
   else
@@ -288,7 +304,7 @@ MPX_EXPORT int mpx_linear_wgrad(const float *dy, int lddy, const float *x, int l
       hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv((int64_t)N * 16, 256)), dim3(256), 0, mpx_s(stream),
                          scratch + (size_t)N * K, S, per, (int64_t)N, db);
   }
-  MPX_LAUNCH_CHECK("mpx_linear_wgrad");
+  MPX_LAUNCH_CHECK(name);
 }
 
 MPX_EXPORT int mpx_act_backward(const float *dy, const float *y, int64_t n, int act, float *dz, mpx_stream_t stream) {

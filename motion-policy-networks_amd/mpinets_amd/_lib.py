@@ -81,6 +81,8 @@ PROTOTYPES = {
     "mpx_groupnorm_leaky_grad": [P, P, P, P, I, I, I, F, P, P, P, P, P],
     "mpx_act_backward": [P, P, L, I, P, P],
     "mpx_linear_dact": [P, I, P, I, I, I, P, I, I, P, I, P],
+    "mpx_linear_bf16x3_dact": [P, I, P, I, I, I, P, I, I, P, I, P],
+    "mpx_linear_wgrad_bf16x3": [P, I, P, I, I, I, I, P, P, P, P],
     "mpx_linear_wgrad_scratch": [I, I, I],
     "mpx_linear_wgrad": [P, I, P, I, I, I, I, P, P, P, P],
     "mpx_groupnorm_leaky": [P, P, P, I, I, I, F, P, P],

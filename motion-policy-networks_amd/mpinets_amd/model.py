@@ -72,6 +72,7 @@ class MPiNetsPointNet(nn.Module):
         self._sa3_w0 = None  # first group-all layer with K padded 259 -> 272 (whole 16-float slabs: direct-to-LDS GEMM)
         self._sa3_pk = None  # (key, mpx_sa3_pack_weights of the group-all module)
         self.dense_precision = "fp32"  # "bf16x3": the large dense layers on the bf16 matrix cores (set_precision)
+        self.train_precision = "fp32"  # "bf16x3": the grouped / group-all MLPs' training GEMMs in split bf16 (set_training_precision)
         self._split = SplitWeights()
         # bf16x3 only: keep the group-all MLP's activations in the split "pairs" form between layers (default) or as
         # fp32 rows that every layer splits again on its way in -- bit-identical results (tests), pairs are faster
@@ -179,7 +180,8 @@ class MPiNetsPointNet(nn.Module):
         lib.call("mpx_ball_query", lib.ptr(xyz1), 3, lib.ptr(pc), 4, B, N, sa1.npoint, float(sa1.radius),
                  sa1.nsample, lib.ptr(nbr1), lib.ptr(cnt1))
         # the slab is read in place: coordinates at stride 4, label column = the one input feature (no gradient)
-        f1 = sa_module_train(sa1.convs(), pc, 4, xyz1, 3, pc[:, :, 3:], 4, 1, nbr1, cnt1, (B, N, sa1.npoint, sa1.nsample))
+        tp = self.train_precision
+        f1 = sa_module_train(sa1.convs(), pc, 4, xyz1, 3, pc[:, :, 3:], 4, 1, nbr1, cnt1, (B, N, sa1.npoint, sa1.nsample), tp)
         idx2 = torch.empty((B, sa2.npoint), dtype=torch.int32, device=dev)
         xyz2 = torch.empty((B, sa2.npoint, 3), dtype=torch.float32, device=dev)
         lib.call("mpx_fps", lib.ptr(xyz1), B, sa1.npoint, 3, sa2.npoint, lib.ptr(idx2), lib.ptr(xyz2), 3)
@@ -189,9 +191,9 @@ class MPiNetsPointNet(nn.Module):
                  sa2.nsample, lib.ptr(nbr2), lib.ptr(cnt2))
         f1 = f1.contiguous()
         f2 = sa_module_train(sa2.convs(), xyz1, 3, xyz2, 3, f1, f1.size(2), f1.size(2), nbr2, cnt2,
-                             (B, sa1.npoint, sa2.npoint, sa2.nsample))
+                             (B, sa1.npoint, sa2.npoint, sa2.nsample), tp)
         h = torch.cat((xyz2, f2), dim=2)  # group-all: absolute coordinates | features
-        h = mlp_chain_train(h, [(c.weight.view(c.out_channels, -1), c.bias) for c in sa3.convs()], [ACT_RELU] * 3)
+        h = mlp_chain_train(h, [(c.weight.view(c.out_channels, -1), c.bias) for c in sa3.convs()], [ACT_RELU] * 3, precision=tp)
         pooled = h.max(dim=1).values
         self.last_counts = (cnt1, cnt2)
         if aux is not None:
@@ -428,6 +430,16 @@ class MotionPolicyNetwork(nn.Module):
         for sa in self.point_cloud_encoder.SA_modules:
             sa.precision = precision
         self.point_cloud_encoder.dense_precision = precision
+        return self
+
+    def set_training_precision(self, precision: str) -> "MotionPolicyNetwork":
+        """Arithmetic of the training GEMMs of the grouped / group-all MLPs (forward, input gradient, weight gradient of the
+        layers with >= 128 outputs over >= 1024 rows): ``"fp32"`` (default) or ``"bf16x3"`` -- split bf16 on the bf16 matrix
+        cores with fp32 accumulation, fp32 master weights and fp32 activations in memory: this engine's form of the
+        reference's mixed-precision training (``precision=16``, run_training.py:112), with gradients within ~1e-4 relative
+        of the fp32 path instead of fp16's ~1e-3.  Sampling, grouping, losses, GroupNorm and the optimizer stay fp32."""
+        assert precision in PRECISIONS, precision
+        self.point_cloud_encoder.train_precision = precision
         return self
 
     def set_factored(self, on: bool) -> "MotionPolicyNetwork":

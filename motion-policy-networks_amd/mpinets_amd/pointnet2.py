@@ -434,12 +434,19 @@ class _MLPChainFn(torch.autograd.Function):
     ``mpx_act_backward``; gradients equal the per-layer form bit for bit where that form takes the same GEMM kernel (the
     input-gradient product here is always the 128 x 128 tile kernel; ``linear`` splits K or takes its few-row kernel for
     skinny problems: a different summation order).
-    Arguments: x [M, K0], acts (tuple of activation codes), offsets (int64 [Q+1] or None), then W_0, b_0, W_1, b_1, ...
-    Returns the last layer's rows [M, N_last], or the pooled rows [Q, N_last] with ``offsets``.
+    Arguments: x [M, K0], acts (tuple of activation codes), offsets (int64 [Q+1] or None), x3 (bool), then W_0, b_0, W_1,
+    b_1, ...  Returns the last layer's rows [M, N_last], or the pooled rows [Q, N_last] with ``offsets``.
+    ``x3``: the three GEMMs of every layer with >= 128 outputs and >= 1024 rows run in the split-bf16 arithmetic of the
+    ``bf16x3`` mode (``mpx_linear_bf16x3`` / ``_dact`` / ``mpx_linear_wgrad_bf16x3``; fp32 master weights, fp32
+    accumulation, fp32 activations in memory) -- the engine's form of the reference's ``precision=16`` (run_training.py:112).
     """
 
     @staticmethod
-    def forward(ctx, x, acts, offsets, *wb):
+    def _use_x3(x3, M, N, K):
+        return bool(x3) and M >= 1024 and N >= 128 and K >= 16
+
+    @staticmethod
+    def forward(ctx, x, acts, offsets, x3, *wb):
         L = len(acts)
         assert len(wb) == 2 * L and x.ndim == 2
         M, K0 = x.shape
@@ -450,7 +457,13 @@ class _MLPChainFn(torch.autograd.Function):
             N, K = w.shape
             wp = _pad4(_lib.f32c(w.detach()))
             assert h.size(1) == wp.size(1), "layer widths do not chain"
-            y = linear(h, wp, None if b is None else _lib.f32c(b.detach()), acts[i])
+            bias = None if b is None else _lib.f32c(b.detach())
+            if _MLPChainFn._use_x3(x3, M, N, wp.size(1)):
+                y = torch.empty((M, N), dtype=torch.float32, device=h.device)
+                _lib.call("mpx_linear_bf16x3", _lib.ptr(h), h.stride(0), _lib.ptr(split_pairs(wp)), _lib.ptr(bias), M, N,
+                          wp.size(1), acts[i], _lib.ptr(y), N)
+            else:
+                y = linear(h, wp, bias, acts[i])
             xs.append(h)
             ws.append(wp)
             meta.append((N, K, b is not None))
@@ -465,12 +478,12 @@ class _MLPChainFn(torch.autograd.Function):
             ctx.save_for_backward(*xs, *ws, pooled, arg)  # (the last layer's rows are not needed again)
         else:
             ctx.save_for_backward(*xs, *ws, h)
-        ctx.meta = (tuple(acts), tuple(meta), M, K0, offsets is not None)
+        ctx.meta = (tuple(acts), tuple(meta), M, K0, offsets is not None, bool(x3))
         return pooled if offsets is not None else h
 
     @staticmethod
     def backward(ctx, g):
-        acts, meta, M, K0, pooled_out = ctx.meta
+        acts, meta, M, K0, pooled_out, x3 = ctx.meta
         L = len(acts)
         saved = ctx.saved_tensors
         xs, ws = saved[:L], saved[L:2 * L]
@@ -495,13 +508,14 @@ class _MLPChainFn(torch.autograd.Function):
             N, K, has_bias = meta[i]
             Np, Kp = (N + 3) // 4 * 4, ws[i].size(1)
             dz = _pad4(dz) if dz.size(1) != Np else dz
-            if ctx.needs_input_grad[3 + 2 * i] or (has_bias and ctx.needs_input_grad[4 + 2 * i]):
+            lx3 = _MLPChainFn._use_x3(x3, M, N, Kp)
+            if ctx.needs_input_grad[4 + 2 * i] or (has_bias and ctx.needs_input_grad[5 + 2 * i]):
                 both = torch.empty(Np * Kp + Np, dtype=torch.float32, device=dev)  # dw | db: one reduction launch
                 dw = both[:Np * Kp].view(Np, Kp)
                 db = both[Np * Kp:] if has_bias else None
                 scratch = torch.empty(_lib.load().mpx_linear_wgrad_scratch(M, Np, Kp), dtype=torch.float32, device=dev)
-                _lib.call("mpx_linear_wgrad", _lib.ptr(dz), dz.stride(0), _lib.ptr(xs[i]), xs[i].stride(0), M, Np, Kp,
-                          _lib.ptr(dw), _lib.ptr(db), _lib.ptr(scratch))
+                _lib.call("mpx_linear_wgrad_bf16x3" if lx3 else "mpx_linear_wgrad", _lib.ptr(dz), dz.stride(0), _lib.ptr(xs[i]),
+                          xs[i].stride(0), M, Np, Kp, _lib.ptr(dw), _lib.ptr(db), _lib.ptr(scratch))
                 grads[2 * i] = dw[:N, :K]
                 grads[2 * i + 1] = db[:N] if has_bias else None
             if i > 0 or ctx.needs_input_grad[0]:
@@ -509,30 +523,34 @@ class _MLPChainFn(torch.autograd.Function):
                 gx = torch.empty((M, Kp), dtype=torch.float32, device=dev)
                 below = acts[i - 1] if i > 0 else 0
                 # xs[i] IS the output of layer i - 1 (zero-padded columns: their gradient columns are dropped below)
-                _lib.call("mpx_linear_dact", _lib.ptr(dz), dz.stride(0), _lib.ptr(wt), M, Kp, Np,
-                          _lib.ptr(xs[i]) if below else None, xs[i].stride(0), below, _lib.ptr(gx), Kp)
+                _lib.call("mpx_linear_bf16x3_dact" if lx3 else "mpx_linear_dact", _lib.ptr(dz), dz.stride(0),
+                          _lib.ptr(split_pairs(wt) if lx3 else wt), M, Kp, Np, _lib.ptr(xs[i]) if below else None,
+                          xs[i].stride(0), below, _lib.ptr(gx), Kp)
                 dz = gx
             else:
                 dz = None
         gx0 = dz[:, :K0] if (dz is not None and ctx.needs_input_grad[0]) else None
-        return (gx0, None, None) + tuple(grads)
+        return (gx0, None, None, None) + tuple(grads)
 
 
-def mlp_chain_train(x: torch.Tensor, layers, acts, offsets: Optional[torch.Tensor] = None) -> torch.Tensor:
+def mlp_chain_train(x: torch.Tensor, layers, acts, offsets: Optional[torch.Tensor] = None,
+                    precision: str = "fp32") -> torch.Tensor:
     """Differentiable stack of dense layers on the engine's kernels (one autograd node, see ``_MLPChainFn``).
     ``layers``: sequence of (weight [N,K], bias or None); ``acts``: one activation code per layer; ``x`` may have leading
-    batch dimensions (flattened; not with ``offsets``)."""
+    batch dimensions (flattened; not with ``offsets``); ``precision``: "fp32" or "bf16x3" (the large GEMMs of forward and
+    backward in split bf16, see ``_MLPChainFn``)."""
+    assert precision in PRECISIONS
     lead = x.shape[:-1]
     wb = []
     for w, b in layers:
         wb += [w, b]
-    y = _MLPChainFn.apply(x.reshape(-1, x.size(-1)), tuple(int(a) for a in acts), offsets, *wb)
+    y = _MLPChainFn.apply(x.reshape(-1, x.size(-1)), tuple(int(a) for a in acts), offsets, precision == "bf16x3", *wb)
     return y if offsets is not None else y.reshape(lead + (y.size(-1),))
 
 
 def sa_module_train(convs: List[nn.Conv2d], xyz: torch.Tensor, xyz_stride: int, new_xyz: torch.Tensor,
                     new_stride: int, feat: torch.Tensor, feat_stride: int, C: int, idx: torch.Tensor,
-                    cnt: torch.Tensor, dims: Tuple[int, int, int, int]) -> torch.Tensor:
+                    cnt: torch.Tensor, dims: Tuple[int, int, int, int], precision: str = "fp32") -> torch.Tensor:
     """Differentiable set-abstraction MLP + max-pool -> [B, npoint, C_out].  ``feat`` is any tensor whose storage
     holds the point-major features (``feat_stride`` floats between points); it receives the gradient."""
     B, N, npoint, nsample = dims
@@ -541,7 +559,7 @@ def sa_module_train(convs: List[nn.Conv2d], xyz: torch.Tensor, xyz_stride: int, 
     R = int(offsets[-1].item())  # one host sync per module and step: the row count sizes the activations
     h = _PackRows.apply(feat, xyz, xyz_stride, new_xyz, new_stride, feat_stride, C, idx, cnt, offsets, R, dims)
     layers = [(conv.weight.view(conv.out_channels, -1), conv.bias) for conv in convs]
-    return mlp_chain_train(h, layers, [1] * len(layers), offsets=offsets).view(B, npoint, -1)
+    return mlp_chain_train(h, layers, [1] * len(layers), offsets=offsets, precision=precision).view(B, npoint, -1)
 
 
 class PointnetSAModule(nn.Module):
