@@ -137,12 +137,8 @@ def cpu_baseline(prob, model, n_env: int):
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector peak (64 FLOP / clk / SIMD)
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak at 2.4 GHz
-# what the chip SUSTAINS on a bare v_mfma_f32_32x32x16_bf16 stream (256 CUs x 4 waves, nothing in the gaps): the stream
-# issues at its 32-cycle floor while the clock falls to 1.48 GHz -- measured on the bench box, tools/probes/
-# mfma_bf16_stream.hip, profiles/r04_other_measurements.md (the fp32 pipe holds 155 of its 157.3 TF: mfma_f32_peak.hip)
-BF16_MFMA_SUSTAINED_TFLOPS = 1550.0
-TRAFFIC_RECORD = "r04_traffic.json"  # written by tools/pmc_traffic.py from the PMC passes of this round
-FAST_RECORD = "r04_fast_traffic.json"  # the same for the bf16x3 kernels (tools/pmc_fast.py)
+TRAFFIC_RECORD = "r05_traffic.json"  # written by tools/pmc_traffic.py from the PMC passes of this round
+FAST_RECORD = "r05_fast_traffic.json"  # the same for the bf16x3 kernels (tools/pmc_fast.py)
 
 # FLOPs per (collision sphere, unmasked primitive) pair, counted from csrc/sdf_device.h (one fma = 2): cuboid =
 # projection 18 + 3 abs-sub + 3 max + 5 (norm) + sqrt + 3 (max3, min) + 2 (add, min-select) = 35; cylinder = 18 + 4 (rho)
@@ -223,8 +219,6 @@ def fast_roofline(B, live_ms, live_flops):
     out = {"kernel": "sa2_bf16x3_persistent_kernel", "bound": "mfma", "achieved": live_flops / (live_ms * 1e-3) / 1e12,
            "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": live_flops / (live_ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS,
            "ms_per_launch": live_ms, "flops_per_launch": live_flops, "clock_ghz": None, "mfma_busy_frac": None,
-           "sustained_stream_tflops": BF16_MFMA_SUSTAINED_TFLOPS,
-           "frac_of_sustained_stream": live_flops / (live_ms * 1e-3) / 1e12 / BF16_MFMA_SUSTAINED_TFLOPS,
            "frac_of_clock_adjusted_peak": None, "traffic": None}
     try:
         rec = json.load(open(os.path.join(ROOT, "profiles", FAST_RECORD)))
@@ -492,8 +486,9 @@ def main():
         tm = TrainingMotionPolicyNetwork(2048, 1.0, 5.0).to(dev)  # (loss weights of jobconfig.yaml)
         opt = tm.configure_optimizers()
         training = {}
-        for tb in (10, 256):
+        for tb, prec in ((10, "fp32"), (256, "fp32"), (256, "bf16x3")):
             nb = min(tb, B)
+            tm.set_training_precision(prec)
             g = torch.Generator(device="cpu").manual_seed(100 + rank)
             sup = torch.clamp(prob["q_norm"][:nb] + 0.05 * torch.randn(nb, 7, generator=g).to(dev), -1, 1)
             batch = {"xyz": prob["xyz"][:nb].clone(), "configuration": prob["q_norm"][:nb].clone(), "supervision": sup,
@@ -512,14 +507,17 @@ def main():
             rows1, rows2 = int(c1t.clamp(min=1).sum()), int(c2t.clamp(min=1).sum())
             # executed matrix work: forward over the hit rows only (the differentiable path packs them), backward = 2x
             fwd = 2.0 * (rows1 * 8448 + rows2 * 57728 + nb * (128 * 919040 + HEAD_MACS))
-            training[f"batch_{tb}"] = {
+            training[f"batch_{tb}" + ("" if prec == "fp32" else "_" + prec)] = {
                 "samples_per_gpu": nb, "steps": args.train_steps, "ms_per_step": el_t / args.train_steps * 1e3,
-                "samples_per_s": nb * n_gpus * args.train_steps / el_t, "loss": float(loss.item()),
+                "samples_per_s": nb * n_gpus * args.train_steps / el_t, "loss": float(loss.item()), "dtype": prec,
                 "executed_tflops": 3 * fwd / (el_t / args.train_steps) / 1e12,
                 "frac_of_fp32_mfma_peak": 3 * fwd / (el_t / args.train_steps) / 1e12 / FP32_MFMA_PEAK_TFLOPS}
+        tm.set_training_precision("fp32")
         training["what"] = ("TrainingMotionPolicyNetwork.training_step + backward + bucketed gradient all-reduce + clip(1.0) + Adam "
-                            "(mpinets_amd.training.train_step), fp32; batch_10 = jobconfig.yaml's batch size per GPU; FLOPs = 3 x "
-                            "the forward's executed matrix work (hit rows only)")
+                            "(mpinets_amd.training.train_step); batch_10 = jobconfig.yaml's batch size per GPU; batch_256_bf16x3 = the same step "
+                            "with set_training_precision('bf16x3') (the grouped MLPs' GEMMs in split bf16, fp32 accumulate and master "
+                            "weights: the engine's form of the reference's precision=16); FLOPs = 3 x the forward's executed matrix "
+                            "work (hit rows only), always against the fp32 MFMA peak")
         training["allreduce_ranks"] = n_gpus if dist_backend is not None else 1
         del tm, opt, batch
         model.eval()
@@ -605,7 +603,7 @@ def main():
                          "unit": "TFLOP/s", "frac": c4_flop / (c4_ms * 1e-3) / 1e12 / (FP32_VALU_PEAK_TFLOPS * n_gpus),
                          "executed_gflop": c4_flop / 1e9,
                          "note": "executed FLOPs: unmasked primitives only (35 per sphere-cuboid, 33 per sphere-cylinder pair, "
-                                 "csrc/sdf_device.h) vs the fp32 VALU peak of all ranks; counters: profiles/r04_collision_pmc_pass*.csv"},
+                                 "csrc/sdf_device.h) vs the fp32 VALU peak of all ranks; counters: profiles/r05_collision_pmc_pass*.csv"},
             "what": "FK + 56-sphere SDF vs 40 cuboids + 16 cylinders (zero-padded), has_collision[B] (model.py:293-314)"}
         extra["c2_fk_sdf_1024"] = {
             "envs": c2_envs, "envs_per_rank": [r["c2_envs"] for r in recs], "ms": c2_ms, "ms_per_rank": [r["c2_ms"] for r in recs],

@@ -1,7 +1,7 @@
 #!/bin/bash
-# gpurun_out/<round>ev/ (tools/evidence.sh <round>) -> profiles/<round>_* (tracked).  usage: bash tools/collect.sh r04
+# gpurun_out/<round>ev/ (tools/evidence.sh <round>) -> profiles/<round>_* (tracked).  usage: bash tools/collect.sh r05
 set -e
-R=${1:-r04}
+R=${1:-r05}
 S=gpurun_out/${R}ev; P=profiles
 tail -1 $S/bench.log > $P/${R}_bench_n1.json
 cp $S/stats_head_kernel_stats.csv $P/${R}_bench_kernel_stats.csv
@@ -17,5 +17,7 @@ cp $S/collision_c4.json $P/${R}_collision_c4.json; cp $S/collision_c2.json $P/${
 [ -f $S/pytest_gpu.log ] && cp $S/pytest_gpu.log $P/${R}_pytest_gpu.log
 cp $S/soak_hashes.json $P/${R}_soak_hashes.json; cp $S/horizon_report.json $P/${R}_horizon_report.json
 cp $S/stats_train_kernel_stats.csv $P/${R}_train_step_kernel_stats.csv; cat $S/train_10.log $S/train_256.log > $P/${R}_train_step.log
+cp $S/stats_trainx3_kernel_stats.csv $P/${R}_train_step_bf16x3_kernel_stats.csv
+grep -v amdgpu.ids $S/sa2_bf16_phase_probe.log > $P/${R}_sa2_bf16_phase_probe.log
 cp $S/box.log $P/${R}_box.log
 ls -la $P/${R}_* | awk '{print $5, $9}'

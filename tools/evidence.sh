@@ -1,8 +1,8 @@
 #!/bin/bash
 # Evidence run of a round (one MI355X): GPU tests, bench line (+ whole configs[4] extra), kernel stats, PMC passes of the
-# fp32 headline and of the bf16x3 mode, collision counters.  usage (on the box): bash tools/evidence.sh r04 [notests]
+# fp32 headline and of the bf16x3 mode, collision counters.  usage (on the box): bash tools/evidence.sh r05 [notests]
 # Everything lands in gpurun_out/<round>ev/; tools/collect.sh <round> copies the summaries into profiles/.
-R=${1:-r04}
+R=${1:-r05}
 mkdir -p gpurun_out/${R}ev
 export PYTHONUNBUFFERED=1
 REPO=$(pwd); O=$REPO/gpurun_out/${R}ev
@@ -47,4 +47,7 @@ pmc col3 "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_SALU SQ_INSTS_SMEM" tools/collision_t
 stats col tools/collision_timing.py 8192 50 5
 stats train tools/train_timing.py 256 5
 python tools/train_timing.py 256 5 > $O/train_256.log 2>&1; python tools/train_timing.py 10 10 > $O/train_10.log 2>&1
+python tools/train_timing.py 256 5 bf16x3 >> $O/train_256.log 2>&1
+stats trainx3 tools/train_timing.py 256 5 bf16x3
+python tools/probes/sa2_bf16_phase_probe.py > $O/sa2_bf16_phase_probe.log 2>&1
 echo done
