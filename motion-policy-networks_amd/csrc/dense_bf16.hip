@@ -248,7 +248,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                                const float *__restrict__ bias, int M, int N, int act, float *__restrict__ y, int ldy,
                                __bf16 *__restrict__ yp, int ldp) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char ysm[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (scalar: the DMA loads' LDS addresses stay on the scalar unit)
   const int half = lane >> 5, l31 = lane & 31;
   const int wm = wave >> 1, wn = wave & 1;
   int bx = blockIdx.x, by = blockIdx.y;
@@ -290,10 +291,26 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     for (int i = 0; i < 2; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(r_w, (lds_void *)(sb + 16 * i * Y_ROWB), 16, wvoff[i], kb * 64, 0, 0);
   };
-  // fragment: row r of A (isb = 0) or B (1), logical chunk c = 2 * plane + half
-  auto frag = [&](int stage, int isb, int r, int c) __attribute__((always_inline)) {
-    return *reinterpret_cast<const bf16x8 *>(ysm + stage * Y_STAGE + isb * (Y_BM * Y_ROWB) + r * Y_ROWB +
-                                             (((c ^ (r >> 2)) & 3) << 4));
+  // fragment addresses, once per kernel: row r of A (isb = 0) or B (1), logical chunk c = 2 * plane + half sits at
+  // physical chunk c ^ (r >> 2) -- the lo plane is the hi address with bit 5 flipped, so both get a register; the stage is
+  // an immediate of the read (round 5: the slab loop carried 22 address VALU + 6 v_readfirstlane per 24 MFMAs and read
+  // its fragments only after the slab's barrier -- an LDS round trip in front of every slab's first MFMA)
+  int fa_hi[4], fa_lo[4], fb_hi[2], fb_lo[2];
+  auto faddr = [&](int isb, int r, int c) __attribute__((always_inline)) {
+    return isb * (Y_BM * Y_ROWB) + r * Y_ROWB + (((c ^ (r >> 2)) & 3) << 4);
+  };
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    fa_hi[t] = faddr(0, wm * 128 + t * 32 + l31, half);
+    fa_lo[t] = faddr(0, wm * 128 + t * 32 + l31, 2 + half);
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    fb_hi[t] = faddr(1, wn * 64 + t * 32 + l31, half);
+    fb_lo[t] = faddr(1, wn * 64 + t * 32 + l31, 2 + half);
+  }
+  auto frag_at = [&](int stage, int off) __attribute__((always_inline)) {
+    return *reinterpret_cast<const bf16x8 *>(ysm + off + stage * Y_STAGE);
   };
   f32x16 acc[4][2];
 #pragma unroll
@@ -301,41 +318,68 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   const int nk = K / 16;
-  constexpr int D = Y_STAGES - 1, LPS = 6;
-  constexpr int WAIT_NEXT = 0x0070 | ((D - 1) * LPS);
-#pragma unroll
-  for (int d = 0; d < D; ++d)
-    if (d < nk) dma(d, d);
-  if (nk >= D) __builtin_amdgcn_s_waitcnt(WAIT_NEXT); else __builtin_amdgcn_s_waitcnt(0x0070);
-  __builtin_amdgcn_s_barrier();
-  int st = 0, st_in = D % Y_STAGES;
-  for (int kb = 0; kb < nk; ++kb) {
-    const bool more = kb + D < nk;
-    if (more) dma(kb + D, st_in);
-    bf16x8 fah[4], fal[4], fbh[2], fbl[2];
+  constexpr int LPS = 6;                       // DMA loads per wave and slab
+  constexpr int WAIT_ONE = 0x0070 | LPS;       // vmcnt(6), lgkmcnt(0): everything but the youngest slab has landed
+  constexpr int WAIT_ALL = 0x0070;             // vmcnt(0), lgkmcnt(0)
+  // Software pipeline of a slab (24 MFMAs per wave): the B fragments and A tiles 0-1 of slab k+1 are read into a second
+  // register set in the MIDDLE of slab k (behind the one barrier of the slab, which also covers the DMA of slab k+1 --
+  // each wave waits for its own loads first), A tiles 2-3 of slab k at its top: every LDS read has half a slab of MFMAs
+  // between issue and use.  Three LDS stages: slab k+2 is requested at the top of slab k into the stage slab k-1 was read
+  // from -- all waves finished those reads before the barrier in the middle of slab k-1 (lgkmcnt(0) in front of it).
+  // (two register sets for the prefetched fragments, alternating by slab: the loop is unrolled over 3 stages x 2 sets)
+  bf16x8 bh[2][2], bl[2][2], a01h[2][2], a01l[2][2], a23h[2], a23l[2];
+  auto read_front = [&](int stage, int set) __attribute__((always_inline)) {
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      fbh[t] = frag(st, 1, wn * 64 + t * 32 + l31, half);
-      fbl[t] = frag(st, 1, wn * 64 + t * 32 + l31, 2 + half);
+      bh[set][t] = frag_at(stage, fb_hi[t]);
+      bl[set][t] = frag_at(stage, fb_lo[t]);
+      a01h[set][t] = frag_at(stage, fa_hi[t]);
+      a01l[set][t] = frag_at(stage, fa_lo[t]);
+    }
+  };
+  auto mfma3 = [&](f32x16 &c, const bf16x8 &xh, const bf16x8 &xl, const bf16x8 &wh, const bf16x8 &wl) __attribute__((always_inline)) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, wh, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, wl, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, wh, c, 0, 0, 0);
+  };
+  if (nk > 0) dma(0, 0);
+  if (nk > 1) dma(1, 1);
+  if (nk > 1) __builtin_amdgcn_s_waitcnt(WAIT_ONE); else __builtin_amdgcn_s_waitcnt(WAIT_ALL);
+  __builtin_amdgcn_s_barrier();
+  if (nk > 0) read_front(0, 0);
+  auto slab = [&](int kb, int stage, int set) __attribute__((always_inline)) {  // stage = kb % 3, set = kb % 2 (compile-time)
+    const int st1 = stage == 2 ? 0 : stage + 1, st2 = stage == 0 ? 2 : stage - 1;  // stages of slabs kb + 1, kb + 2
+    if (kb + 2 < nk) dma(kb + 2, st2);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      a23h[t] = frag_at(stage, fa_hi[2 + t]);
+      a23l[t] = frag_at(stage, fa_lo[2 + t]);
     }
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      fah[t] = frag(st, 0, wm * 128 + t * 32 + l31, half);
-      fal[t] = frag(st, 0, wm * 128 + t * 32 + l31, 2 + half);
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) mfma3(acc[i][j], a01h[set][i], a01l[set][i], bh[set][j], bl[set][j]);
+    if (kb + 1 < nk) {
+      // own loads of slab kb + 1 landed, own reads done
+      if (kb + 2 < nk) __builtin_amdgcn_s_waitcnt(WAIT_ONE); else __builtin_amdgcn_s_waitcnt(WAIT_ALL);
+      __builtin_amdgcn_s_barrier();
+      read_front(st1, set ^ 1);
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[i], fbh[j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[i], fbl[j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[i], fbh[j], acc[i][j], 0, 0, 0);
-      }
-    if (more) __builtin_amdgcn_s_waitcnt(WAIT_NEXT); else __builtin_amdgcn_s_waitcnt(0x0070);
-    __builtin_amdgcn_s_barrier();
-    st = st + 1 == Y_STAGES ? 0 : st + 1;
-    st_in = st_in + 1 == Y_STAGES ? 0 : st_in + 1;
+      for (int j = 0; j < 2; ++j) mfma3(acc[2 + i][j], a23h[i], a23l[i], bh[set][j], bl[set][j]);
+  };
+  for (int kb = 0; kb < nk; kb += 6) {
+    slab(kb, 0, 0);
+    if (kb + 1 < nk) slab(kb + 1, 1, 1);
+    if (kb + 2 < nk) slab(kb + 2, 2, 0);
+    if (kb + 3 < nk) slab(kb + 3, 0, 1);
+    if (kb + 4 < nk) slab(kb + 4, 1, 0);
+    if (kb + 5 < nk) slab(kb + 5, 2, 1);
   }
+  __builtin_amdgcn_s_waitcnt(WAIT_ALL);
+  __builtin_amdgcn_s_barrier();  // (the epilogue reuses the ring as its staging area)
   if (OUT >= 2) {  // max over the wave's 128 rows (one pooled group), plain stores: no other wave owns these columns
     const int grp = by * 2 + wm;
     if ((int64_t)grp * 128 < M) {
