@@ -661,11 +661,12 @@ def main():
     total_envsteps = global_envs * args.steps
     # HBM traffic of the dominant kernel comes from committed PMC passes (it cannot be read live).  The record
     # carries the SHA-256 of the kernel source it was measured on: a changed kernel file -> traffic null
-    traffic, traffic_note = None, None
+    traffic, traffic_note, traffic_step = None, None, None
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_RECORD)))
         if tj["envs_per_gpu"] == B and tj["kernel_source_sha256"] == kernel_source_hash():
             traffic, traffic_note = tj["hbm_bytes_per_launch"], tj["source"] + "; " + tj["correction"]
+            traffic_step = tj.get("whole_step")  # every kernel of the step: corrected HBM bytes vs SURVEY 8(d)'s algorithmic bytes
         else:
             traffic_note = f"profiles/{TRAFFIC_RECORD} is stale (kernel source or batch size changed since the PMC passes)"
     except Exception as e:
@@ -712,7 +713,7 @@ def main():
             # it skips ball-query padding and evaluates layer 1 per point.  Scene-density dependent; `frac` is the
             # executed-work fraction, `all_slots` the density-independent floor of the whole step.
             "frac_nominal": SA2_FLOPS * B / (sa2_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
-            "traffic": traffic, "traffic_source": traffic_note,
+            "traffic": traffic, "traffic_source": traffic_note, "traffic_whole_step": traffic_step,
             "ms_per_launch": sa2_ms, "flops_per_launch": sa2_exec,
             "note": "achieved = FLOPs of the 32-row MFMA tiles actually issued / time; ball-query padding "
                     "(repeats of the first neighbour) is not re-evaluated (bit-identical result)",

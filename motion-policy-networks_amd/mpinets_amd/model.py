@@ -684,3 +684,13 @@ class TrainingMotionPolicyNetwork(MotionPolicyNetwork):
         B = traj.size(0)
         return {"avg_target_error": torch.mean(position_error),
                 "avg_collision_rate": torch.count_nonzero(has_collision) / B}
+
+    def validation_step_end(self, batch_parts: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        """model.py:320-334 (Lightning's per-step aggregation over devices): the mean of each statistic's parts."""
+        return {"avg_target_error": torch.mean(batch_parts["avg_target_error"]),
+                "avg_collision_rate": torch.mean(batch_parts["avg_collision_rate"])}
+
+    def validation_epoch_end(self, validation_step_outputs) -> None:
+        """model.py:336-352: epoch means of the two statistics, through ``log`` (here: kept in ``self.logged``)."""
+        self.log("avg_target_error", torch.mean(torch.stack([x["avg_target_error"] for x in validation_step_outputs])))
+        self.log("avg_collision_rate", torch.mean(torch.stack([x["avg_collision_rate"] for x in validation_step_outputs])))

@@ -254,6 +254,12 @@ def test_validation_step_closed_loop(model_golden, mdl, monkeypatch):
     assert err[1] <= TOL and err.max() <= 1e-4
     assert abs(float(res["avg_collision_rate"]) - float(g["v_rate"])) < 1e-7
     assert abs(float(res["avg_target_error"]) - float(g["v_target_error"])) < 5e-3
+    # Lightning's aggregators (model.py:320-352): per-step mean over device parts, epoch mean through `log`
+    parts = {k: torch.stack([v, v + 2]) for k, v in res.items()}
+    step = mdl.validation_step_end(parts)
+    assert all(torch.allclose(step[k], res[k] + 1) for k in res)
+    mdl.validation_epoch_end([res, step])
+    assert all(torch.allclose(mdl.logged[k], res[k] + 0.5) for k in res)
 
 
 @pytest.mark.parametrize("prec", PRECISIONS)
