@@ -233,9 +233,11 @@ int mpx_segment_max(const float *y, int C, const int64_t *offsets, int64_t Q, fl
 int mpx_segment_max_grad(const float *grad_out, int grad_stride, const int64_t *arg, int64_t Q, int C,
                          float *grad_y, mpx_stream_t stream);
 /* the same with the backward of the activation in front of the pool folded in: out [Q, >= C] = the pooled rows
- * (= the activation's output at the arg-max): grad_y[arg[q,c], c] = grad_out[q,c] * act'(out[q,c])             */
+ * (= the activation's output at the arg-max): grad_y[r, c] = (r == arg[q,c]) ? grad_out[q,c] * act'(out[q,c]) : 0 for
+ * EVERY row r of segment q -- grad_y needs no zero fill                                                         */
 int mpx_segment_max_grad_act(const float *grad_out, int grad_stride, const int64_t *arg, const float *out,
-                             int out_stride, int64_t Q, int C, int act, float *grad_y, mpx_stream_t stream);
+                             int out_stride, const int64_t *offsets, int64_t Q, int C, int act, float *grad_y,
+                             mpx_stream_t stream);
 
 /* ---- batch assembly from the dataset arrays (row N2; mpinets/data_loader.py:141-280, 390-417) ------- */
 

@@ -50,6 +50,7 @@ __global__ void __launch_bounds__(256)
 }
 
 // out[q,c] = max_r y[off[q]+r, c];  arg[q,c] = first row attaining it (torch.max keeps the first index)
+// (four rows are loaded before they are compared in order: one wave per query has nothing else to hide a load behind)
 __global__ void __launch_bounds__(256)
     segment_max_kernel(const float *__restrict__ y, int C, const int64_t *__restrict__ off, int64_t Q,
                        float *__restrict__ out, int os, int64_t *__restrict__ arg) {
@@ -60,7 +61,15 @@ __global__ void __launch_bounds__(256)
   for (int c = lane; c < C; c += 64) {
     float best = y[r0 * C + c];
     int64_t at = r0;
-    for (int64_t r = r0 + 1; r < r1; ++r) {
+    int64_t r = r0 + 1;
+    for (; r + 4 <= r1; r += 4) {
+      const float v0 = y[r * C + c], v1 = y[(r + 1) * C + c], v2 = y[(r + 2) * C + c], v3 = y[(r + 3) * C + c];
+      if (v0 > best) best = v0, at = r;
+      if (v1 > best) best = v1, at = r + 1;
+      if (v2 > best) best = v2, at = r + 2;
+      if (v3 > best) best = v3, at = r + 3;
+    }
+    for (; r < r1; ++r) {
       const float v = y[r * C + c];
       if (v > best) best = v, at = r;
     }
@@ -69,18 +78,23 @@ __global__ void __launch_bounds__(256)
   }
 }
 
-// dy[arg[q,c], c] = dout[q,c] * act'(out[q,c])  (the pooled value IS the activation output at the arg-max row: the
-// elementwise backward of the layer in front of the pool costs nothing extra here)
+// dy[r, c] = (r == arg[q,c]) ? dout[q,c] * act'(out[q,c]) : 0 for every row r of segment q  (the pooled value IS the
+// activation output at the arg-max row: the elementwise backward of the layer in front of the pool costs nothing extra
+// here; a query's wave writes ALL rows of its segment, so the caller needs no zero-fill pass over the [R, C] gradient)
 __global__ void __launch_bounds__(256)
     segment_max_grad_act_kernel(const float *__restrict__ dout, int ds, const int64_t *__restrict__ arg,
-                                const float *__restrict__ out, int os, int64_t total, int C, int act,
-                                float *__restrict__ dy) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= total) return;
-  const int64_t q = i / C;
-  const int c = (int)(i - q * C);
-  const float g = dout[q * ds + c], o = out[q * os + c];
-  dy[arg[i] * C + c] = act == MPX_ACT_RELU ? (o > 0.0f ? g : 0.0f) : (act == MPX_ACT_LEAKY ? (o >= 0.0f ? g : 0.01f * g) : g);
+                                const float *__restrict__ out, int os, const int64_t *__restrict__ off, int64_t Q, int C,
+                                int act, float *__restrict__ dy) {
+  const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= Q) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t r0 = off[q], r1 = off[q + 1];
+  for (int c = lane; c < C; c += 64) {
+    const float g = dout[q * ds + c], o = out[q * os + c];
+    const float v = act == MPX_ACT_RELU ? (o > 0.0f ? g : 0.0f) : (act == MPX_ACT_LEAKY ? (o >= 0.0f ? g : 0.01f * g) : g);
+    const int64_t at = arg[q * C + c];
+    for (int64_t r = r0; r < r1; ++r) dy[r * C + c] = r == at ? v : 0.0f;
+  }
 }
 
 // dy[arg[q,c], c] = dout[q,c]  (dy zero-filled by the caller; every (q,c) owns a distinct element)
@@ -137,11 +151,13 @@ MPX_EXPORT int mpx_segment_max_grad(const float *grad_out, int grad_stride, cons
 }
 
 MPX_EXPORT int mpx_segment_max_grad_act(const float *grad_out, int grad_stride, const int64_t *arg, const float *out,
-                                        int out_stride, int64_t Q, int C, int act, float *grad_y, mpx_stream_t stream) {
+                                        int out_stride, const int64_t *offsets, int64_t Q, int C, int act, float *grad_y,
+                                        mpx_stream_t stream) {
   MPX_REQUIRE(Q >= 0 && C > 0 && grad_stride >= C && out_stride >= C, "mpx_segment_max_grad_act: bad size");
-  MPX_REQUIRE(act >= 0 && act <= 2 && out != nullptr, "mpx_segment_max_grad_act: bad activation / missing pooled rows");
+  MPX_REQUIRE(act >= 0 && act <= 2 && out != nullptr && offsets != nullptr,
+              "mpx_segment_max_grad_act: bad activation / missing pooled rows or offsets");
   if (Q == 0) return 0;
-  hipLaunchKernelGGL(segment_max_grad_act_kernel, dim3(cdiv(Q * C, 256)), dim3(256), 0, mpx_s(stream), grad_out,
-                     grad_stride, arg, out, out_stride, Q * C, C, act, grad_y);
+  hipLaunchKernelGGL(segment_max_grad_act_kernel, dim3(cdiv(Q, 4)), dim3(256), 0, mpx_s(stream), grad_out, grad_stride, arg,
+                     out, out_stride, offsets, Q, C, act, grad_y);
   MPX_LAUNCH_CHECK("mpx_segment_max_grad_act");
 }

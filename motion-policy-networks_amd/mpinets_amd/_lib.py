@@ -42,7 +42,7 @@ PROTOTYPES = {
     "mpx_pack_rows_grad": [P, I, P, P, P, I, I, I, I, P, I, P],
     "mpx_segment_max": [P, I, P, L, P, I, P, P],
     "mpx_segment_max_grad": [P, I, P, L, I, P, P],
-    "mpx_segment_max_grad_act": [P, I, P, P, I, L, I, I, P, P],
+    "mpx_segment_max_grad_act": [P, I, P, P, I, P, L, I, I, P, P],
     "mpx_batch_configs": [P, L, I, P, P, P, F, ctypes.c_uint64, L, I, I, F, P, P, P, P, P, P],
     "mpx_gather_rows": [P, P, I, I, P, P],
     "mpx_depth_render": [P, F, F, F, F, I, I, I, P, P, I, P, P, P, I, P, P, I, F, P, P],

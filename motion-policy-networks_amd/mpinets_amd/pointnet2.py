@@ -434,7 +434,8 @@ class _MLPChainFn(torch.autograd.Function):
     ``mpx_act_backward``; gradients equal the per-layer form bit for bit where that form takes the same GEMM kernel (the
     input-gradient product here is always the 128 x 128 tile kernel; ``linear`` splits K or takes its few-row kernel for
     skinny problems: a different summation order).
-    Arguments: x [M, K0], acts (tuple of activation codes), offsets (int64 [Q+1] or None), x3 (bool), then W_0, b_0, W_1,
+    Arguments: x [M, K0], acts (tuple of activation codes), offsets (int64 [Q+1] with offsets[0] = 0 and offsets[Q] = M: the
+    segments tile the rows; or None), x3 (bool), then W_0, b_0, W_1,
     b_1, ...  Returns the last layer's rows [M, N_last], or the pooled rows [Q, N_last] with ``offsets``.
     ``x3``: the three GEMMs of every layer with >= 128 outputs and >= 1024 rows run in the split-bf16 arithmetic of the
     ``bf16x3`` mode (``mpx_linear_bf16x3`` / ``_dact`` / ``mpx_linear_wgrad_bf16x3``; fp32 master weights, fp32
@@ -475,7 +476,7 @@ class _MLPChainFn(torch.autograd.Function):
             pooled = torch.empty((Q, C), dtype=torch.float32, device=h.device)
             arg = torch.empty((Q, C), dtype=torch.int64, device=h.device)
             _lib.call("mpx_segment_max", _lib.ptr(h), C, _lib.ptr(offsets), Q, _lib.ptr(pooled), C, _lib.ptr(arg))
-            ctx.save_for_backward(*xs, *ws, pooled, arg)  # (the last layer's rows are not needed again)
+            ctx.save_for_backward(*xs, *ws, pooled, arg, offsets)  # (the last layer's rows are not needed again)
         else:
             ctx.save_for_backward(*xs, *ws, h)
         ctx.meta = (tuple(acts), tuple(meta), M, K0, offsets is not None, bool(x3))
@@ -491,11 +492,11 @@ class _MLPChainFn(torch.autograd.Function):
         dev = g.device
         N_last = meta[-1][0]
         if pooled_out:
-            pooled, arg = saved[2 * L], saved[2 * L + 1]
+            pooled, arg, offsets = saved[2 * L], saved[2 * L + 1], saved[2 * L + 2]
             Q, C = pooled.shape
-            dz = torch.zeros((M, C), dtype=torch.float32, device=dev)
-            _lib.call("mpx_segment_max_grad_act", _lib.ptr(g), g.stride(0), _lib.ptr(arg), _lib.ptr(pooled), C, Q, C, acts[-1],
-                      _lib.ptr(dz))
+            dz = torch.empty((M, C), dtype=torch.float32, device=dev)  # (every row is written: the segments tile [0, M))
+            _lib.call("mpx_segment_max_grad_act", _lib.ptr(g), g.stride(0), _lib.ptr(arg), _lib.ptr(pooled), C,
+                      _lib.ptr(offsets), Q, C, acts[-1], _lib.ptr(dz))
         else:
             y_last = saved[2 * L]
             if acts[-1]:
