@@ -810,10 +810,6 @@ __global__ void __launch_bounds__(64 * res::WV) __attribute__((amdgpu_waves_per_
 //     2 | pair B + the split of pair A's accumulators | output pair 0 of layer 3 + the split of pair B | output pairs
 //     1-3 + the pooling of the pair before + the NEXT tile's relu(pre - ctr) + split, whose rows were requested when
 //     layer 2 ended.
-// Round 5 (profiles/r05_other_measurements.md: a tile costs 288 x 32 cycles + 1.8 per instruction beside the MFMAs + ~6
-// per instruction outside the stream): the row -> query map is an LDS byte table, the per-tile set-up rides in pair A's
-// fetch-free gaps (151 -> 38 instructions in front of a tile's first MFMA), a tile with ONE query boundary (46 % of
-// them) is pooled in one straight block per output tile, the upper half of the layer-3 weights has its own LDS base.
 // Arithmetic, operand layouts and the weight pack are exactly those of sa_mlp_bf16_kernel<64,128,128,256,Q,true>.
 namespace v2 {
 using Cfg = BCfg<64, 128, 128, 256>;
@@ -836,7 +832,7 @@ static_assert(Cfg::ST2 == 32 && Cfg::ST3 == 64 && Cfg::KS1 == 8 && Cfg::KS2 == 8
                          // fetch-free gaps of layer 2's first output pair (0: round 4: all in front of the tile's first MFMA)
 #endif
 #ifndef MPX_V2_TWOACC
-#define MPX_V2_TWOACC 1  // tiles with ONE query boundary: both sides pooled in one straight block per output tile (0: round 4's flush loop)
+#define MPX_V2_TWOACC 1  // tiles with ONE query boundary: branch-free two-way pooling, flush deferred into the next tile (0: round 4)
 #endif
 #ifndef MPX_V2_SMOOTH
 #define MPX_V2_SMOOTH 1  // fillers of the tile loop in half quanta, one piece per MFMA gap (0: round 3's placement)
