@@ -285,7 +285,7 @@ def main():
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak (default): --envs environments per GPU; strong: --global-envs environments split evenly over the GPUs")
     ap.add_argument("--global-envs", type=int, default=8192, help="total environments of a --scaling strong run")
-    ap.add_argument("--train-steps", type=int, default=3, help="steps of the row-N1 training-step extra (0 = skip)")
+    ap.add_argument("--train-steps", type=int, default=10, help="timed steps of the row-N1 training-step extra (0 = skip); the figure is the MEDIAN step, after 3 untimed ones")
     ap.add_argument("--scene-pool", type=int, default=1024, help="distinct host-generated primitive sets tiled over the batch (clouds are drawn per env on the device)")
     args = ap.parse_args()
     shared_devices = spawn_ranks_if_needed(args)
@@ -493,25 +493,38 @@ def main():
             sup = torch.clamp(prob["q_norm"][:nb] + 0.05 * torch.randn(nb, 7, generator=g).to(dev), -1, 1)
             batch = {"xyz": prob["xyz"][:nb].clone(), "configuration": prob["q_norm"][:nb].clone(), "supervision": sup,
                      **{k: prob[k][:nb] for k in scene_keys}}
-            for _ in range(2):
+            # Three untimed steps size the caching allocator's pools for this batch (the first steps at a new batch size
+            # pay hipMalloc for every activation: the round-5 driver record took 42 ms / step over 3 timed steps where the
+            # settled step is 22 ms); every timed step is then bracketed by its own pair of HIP events on the step's
+            # stream, so one stalled step shows as `ms_max` instead of moving the figure.  `ms_per_step` = MEDIAN step,
+            # max over ranks; `ms_wall_mean` = wall clock / steps around the same loop (host gaps included).
+            for _ in range(3):
                 train_step(tm, opt, batch)
             torch.cuda.synchronize()
             shard.barrier()
+            n_t = args.train_steps
+            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_t)]
             tt0 = time.perf_counter()
-            for _ in range(args.train_steps):
+            for e0, e1 in evs:
+                e0.record()
                 loss = train_step(tm, opt, batch)
+                e1.record()
             torch.cuda.synchronize()
             shard.barrier()
-            el_t = shard.max_over_ranks(time.perf_counter() - tt0, dev)
+            wall_t = shard.max_over_ranks(time.perf_counter() - tt0, dev)
+            per_step = sorted(e0.elapsed_time(e1) for e0, e1 in evs)  # ms
+            el_t = shard.max_over_ranks(per_step[len(per_step) // 2] * 1e-3, dev) * n_t  # (median step) x steps
+            ms_max = shard.max_over_ranks(per_step[-1] * 1e-3, dev) * 1e3
             c1t, c2t = tm.point_cloud_encoder.last_counts
             rows1, rows2 = int(c1t.clamp(min=1).sum()), int(c2t.clamp(min=1).sum())
             # executed matrix work: forward over the hit rows only (the differentiable path packs them), backward = 2x
             fwd = 2.0 * (rows1 * 8448 + rows2 * 57728 + nb * (128 * 919040 + HEAD_MACS))
             training[f"batch_{tb}" + ("" if prec == "fp32" else "_" + prec)] = {
-                "samples_per_gpu": nb, "steps": args.train_steps, "ms_per_step": el_t / args.train_steps * 1e3,
-                "samples_per_s": nb * n_gpus * args.train_steps / el_t, "loss": float(loss.item()), "dtype": prec,
-                "executed_tflops": 3 * fwd / (el_t / args.train_steps) / 1e12,
-                "frac_of_fp32_mfma_peak": 3 * fwd / (el_t / args.train_steps) / 1e12 / FP32_MFMA_PEAK_TFLOPS}
+                "samples_per_gpu": nb, "steps": n_t, "ms_per_step": el_t / n_t * 1e3, "ms_min": per_step[0],
+                "ms_max": ms_max, "ms_wall_mean": wall_t / n_t * 1e3,
+                "samples_per_s": nb * n_gpus * n_t / el_t, "loss": float(loss.item()), "dtype": prec,
+                "executed_tflops": 3 * fwd / (el_t / n_t) / 1e12,
+                "frac_of_fp32_mfma_peak": 3 * fwd / (el_t / n_t) / 1e12 / FP32_MFMA_PEAK_TFLOPS}
         tm.set_training_precision("fp32")
         training["what"] = ("TrainingMotionPolicyNetwork.training_step + backward + bucketed gradient all-reduce + clip(1.0) + Adam "
                             "(mpinets_amd.training.train_step); batch_10 = jobconfig.yaml's batch size per GPU; batch_256_bf16x3 = the same step "

@@ -377,7 +377,8 @@ int mpx_sa_mlp_factored(const float *pre, const float *ctr, const int32_t *idx, 
                         int N, int npoint, int nsample, const float *wpack, int C, int c1, int c2, int c3,
                         float *out, int out_stride, mpx_stream_t stream);
 /* mpx_sa_mlp_factored on the bf16 matrix cores (split products, see mpx_sa_mlp_bf16x3): wpack from
- * mpx_sa_pack_bf16x3 (its layer-1 blocks are not read); order (optional) from mpx_sort_queries.          */
+ * mpx_sa_pack_bf16x3 (its layer-1 blocks are not read); order (optional) from mpx_sort_queries.
+ * nsample <= 128 (the kernel's row -> query table is sized for it; larger neighbourhoods are refused). */
 /* host query: does mpx_sa_mlp_bf16x3_factored use `order`?  Always 0 since version 300: its one kernel is persistent
  * and takes units of 8 queries from a device-side queue (`order` is ignored; pass NULL).  The queue is 32 bytes of
  * library-image memory per (device, stream), zeroed on the launch stream in front of the kernel: concurrent calls on
@@ -589,6 +590,16 @@ int mpx_rollout(const mpx_policy_weights *w, const mpx_rollout_scene *scene, con
 int mpx_rollout_step(const mpx_policy_weights *w, const mpx_rollout_scene *scene, float *xyz, int N,
                      float *q_norm, float *q, int B, int32_t *flags, float *min_sdf, void *workspace,
                      int64_t workspace_bytes, mpx_stream_t stream);
+
+/* ---- measurement hooks (tools/probes/*.py; no product path calls them) ------------------------------------------
+ * The same launches as mpx_sa3_chain / mpx_sa_mlp_bf16x3_factored through instantiations that write s_memtime stamps
+ * of one wave at the kernel's phase boundaries.                                                                    */
+/* probe: int64 [>= 32]; B >= 301 (workgroup 300's wave 0 is the one stamped) */
+int mpx_sa3_chain_probe(const float *x, int ldx, int B, const float *pack, float *out, int ldo, long long *probe,
+                        mpx_stream_t stream);
+/* probe: int64 [>= 128] or NULL (off): while set, every mpx_sa_mlp_bf16x3_factored call first runs the stamped
+ * instantiation (process-wide switch, not thread-safe) */
+int mpx_sa2_bf16x3_set_probe(long long *probe);
 
 #ifdef __cplusplus
 }

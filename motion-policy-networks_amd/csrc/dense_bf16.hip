@@ -318,7 +318,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   const int nk = K / 16;
-  constexpr int LPS = 6;                       // DMA loads per wave and slab
+  constexpr int LPS = 6;                       // DMA loads per wave and slab (dma(): 4 of A + 2 of B)
+  static_assert(Y_STAGES == 3, "the slab loop is written for a three-stage ring (st1 / st2 arithmetic, the 6-way unroll, kb % 3)");
+  static_assert(LPS == Y_BM / 64 + Y_BN / 64 && Y_BM == 256 && Y_BN == 128,
+                "WAIT_ONE counts the loads one dma() issues per wave: 16 rows each, a wave brings 64 rows of A and 32 of B");
   constexpr int WAIT_ONE = 0x0070 | LPS;       // vmcnt(6), lgkmcnt(0): everything but the youngest slab has landed
   constexpr int WAIT_ALL = 0x0070;             // vmcnt(0), lgkmcnt(0)
   // Software pipeline of a slab (24 MFMAs per wave): the B fragments and A tiles 0-1 of slab k+1 are read into a second
@@ -651,9 +654,18 @@ __global__ void __launch_bounds__(256)
       }
     }
   };
+  // db = column sums of dY, from the fp32 values as they pass through the staging registers (a plain sum: no matrix
+  // cores, no reason to take the 2^-17-accurate split): a thread adds its two batch rows of four columns per slab, the
+  // eight row groups of a column are added in a fixed order at the end
+  const bool do_bias = with_bias && blockIdx.x == 0;
+  float bsum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   auto sstore = [&](int buf) {  // transposed: LDS row = output index (n or k), elements 2 rp, 2 rp + 1 of the row
     const float a0[4] = {pa[0].x, pa[0].y, pa[0].z, pa[0].w}, a1[4] = {pa[1].x, pa[1].y, pa[1].z, pa[1].w};
     const float b0[4] = {pb[0].x, pb[0].y, pb[0].z, pb[0].w}, b1[4] = {pb[1].x, pb[1].y, pb[1].z, pb[1].w};
+    if (do_bias) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) bsum[c] += a0[c] + a1[c];
+    }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       unsigned hi, lo;
@@ -670,8 +682,6 @@ __global__ void __launch_bounds__(256)
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  const bool do_bias = with_bias && blockIdx.x == 0 && tid < WB_T;
-  float bsum = 0.0f;
   const int nslab = (me - mb + 15) / 16;
   if (nslab > 0) {
     gload(mb);
@@ -698,17 +708,24 @@ __global__ void __launch_bounds__(256)
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
       }
-    if (do_bias) {  // column sums of dY from the staged split (hi + lo = the value to 2^-17 relative)
-      const __bf16 *rh = plane(buf, 0) + tid * WB_LDT, *rl = plane(buf, 1) + tid * WB_LDT;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) bsum += (float)rh[e] + (float)rl[e];
-    }
     if (kb + 1 < nslab) sstore(buf ^ 1);
     __syncthreads();
   }
   // per split: [N*K weight partials | N bias partials]; C[row][col]: col = lane&31 (k), row = (r&3) + 8*(r>>2) + 4*half (n)
   float *dst = partial + (size_t)blockIdx.z * ((size_t)N * K + N);
-  if (do_bias && n0 + tid < N) dst[(size_t)N * K + n0 + tid] = bsum;
+  if (do_bias) {  // (the operand planes are free: every wave passed the slab loop's last barrier)
+    float *red = reinterpret_cast<float *>(smem);  // [8 row groups][128 columns]
+    static_assert(8 * WB_T * 4 <= sizeof(smem), "the bias reduction fits the operand planes");
+#pragma unroll
+    for (int c = 0; c < 4; ++c) red[rp * WB_T + sc + c] = bsum[c];
+    __syncthreads();
+    if (tid < WB_T && n0 + tid < N) {
+      float t = red[tid];
+#pragma unroll
+      for (int g = 1; g < 8; ++g) t += red[g * WB_T + tid];
+      dst[(size_t)N * K + n0 + tid] = t;
+    }
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll

@@ -140,8 +140,8 @@ __global__ void __launch_bounds__(256)
 
 // dz = dy * act'(y): ReLU -> y > 0; LeakyReLU(0.01) -> y >= 0 ? 1 : 0.01 (sign of the output = sign of the input)
 __global__ void __launch_bounds__(256)
-    act_backward_kernel(const float *__restrict__ dy, const float *__restrict__ y, int64_t n, int act,
-                        float *__restrict__ dz) {
+    act_backward_kernel(const float *dy, const float *__restrict__ y, int64_t n, int act,  // (dy may be dz: in place)
+                        float *dz) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const float g = dy[i], o = y[i];

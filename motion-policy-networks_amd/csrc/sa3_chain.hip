@@ -324,7 +324,7 @@ MPX_EXPORT int mpx_sa3_pack_weights(const float *w1, int k1_real, const float *b
 #undef CALL
 }
 
-// measurement only (not in the header): the same launch with s_memtime stamps of workgroup 300, wave 0 at the phase
+// measurement only: the same launch with s_memtime stamps of workgroup 300, wave 0 at the phase
 // boundaries -> probe[0..16] (tools/probes/sa3_phase_probe.py)
 MPX_EXPORT int mpx_sa3_chain_probe(const float *x, int ldx, int B, const float *pack, float *out, int ldo, long long *probe,
                                    mpx_stream_t stream) {

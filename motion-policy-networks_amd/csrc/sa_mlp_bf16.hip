@@ -819,7 +819,8 @@ constexpr int W2_OFF = Cfg::O2 * TILE_BYTES;                 // first layer-2 st
 constexpr int W3_OFF = Cfg::O3 * TILE_BYTES;                 // first layer-3 step-tile (output tile major, s inner)
 constexpr int W3_BYTES = Cfg::ST3 * TILE_BYTES;              // 131072
 constexpr int LDS_BIAS2 = W3_BYTES, LDS_BIAS3 = LDS_BIAS2 + 4 * C2, LDS_CTR = LDS_BIAS3 + 4 * C3;
-constexpr int ROWQ = (Q * 128 + 64) / 4 + 16;                // 4-row groups of a unit's rows (nsample <= 128) + the index prefetch's overhang
+constexpr int MAX_NSAMPLE = 128;                             // the launcher refuses larger neighbourhoods: ROWQ below is sized for this
+constexpr int ROWQ = (Q * MAX_NSAMPLE + 64) / 4 + 16;        // 4-row groups of a unit's rows (nsample <= MAX_NSAMPLE) + the index prefetch's overhang
 constexpr int LDS_ROWQ = LDS_CTR + WV * Q * C1 * 4;          // row group -> local query, one byte each, a strip per wave
 constexpr int LDS_BYTES = LDS_ROWQ + WV * ROWQ;              // 150144
 constexpr int RS = 8, RD = 7;  // layer-2 ring: stages, prefetch distance in K16 steps (7 x 192 pipe cycles of L2 latency cover)
@@ -1481,6 +1482,10 @@ MPX_EXPORT int mpx_sa_mlp_bf16x3_factored(const float *pre, const float *ctr, co
   MPX_REQUIRE(C == 64 && c1 == 128 && c2 == 128 && c3 == 256,
               "mpx_sa_mlp_bf16x3_factored: built for the (64+3, 128, 128, 256) module (C=%d, %d, %d, %d)", C, c1, c2, c3);
   MPX_REQUIRE(B >= 0 && N >= 1 && npoint >= 0 && nsample > 0, "mpx_sa_mlp_bf16x3_factored: bad size");
+  // (the persistent kernel maps a unit's rows to its queries through an LDS byte table of Q * MAX_NSAMPLE rows per wave)
+  static_assert(v2::ROWQ * 4 >= v2::Q * v2::MAX_NSAMPLE + 64, "the row map must hold a unit of Q full neighbourhoods");
+  MPX_REQUIRE(nsample <= v2::MAX_NSAMPLE, "mpx_sa_mlp_bf16x3_factored: nsample %d exceeds the %d slots per neighbourhood this kernel is built for",
+              nsample, v2::MAX_NSAMPLE);
   MPX_REQUIRE(pre && ctr && idx && cnt, "mpx_sa_mlp_bf16x3_factored: NULL operand (hit counts are required)");
   MPX_REQUIRE(out_stride >= c3, "mpx_sa_mlp_bf16x3_factored: bad stride");
   MPX_REQUIRE((((uintptr_t)wpack | (uintptr_t)pre | (uintptr_t)ctr) & 15) == 0,
@@ -1506,7 +1511,7 @@ MPX_EXPORT int mpx_sa_mlp_bf16x3_factored(const float *pre, const float *ctr, co
   MPX_REQUIRE(queue != nullptr, exhausted ? "mpx_sa_mlp_bf16x3_factored: no unit-queue slot left for this stream (256 "
                                             "distinct streams per process; reuse streams)"
                                           : "mpx_sa_mlp_bf16x3_factored: cannot reset the unit queue");
-  if (g_sa2_probe) {  // (measurement only: mpx_sa2_bf16x3_set_probe, not in the header)
+  if (g_sa2_probe) {  // (measurement only: mpx_sa2_bf16x3_set_probe)
     MPX_LDS_LIMIT_ONCE(sa2_bf16x3_persistent_kernel<true>, v2::LDS_BYTES, "mpx_sa_mlp_bf16x3_factored");
     hipLaunchKernelGGL(sa2_bf16x3_persistent_kernel<true>, dim3(grid), dim3(64 * v2::WV), v2::LDS_BYTES, mpx_s(stream), idx, cnt,
                        nq, N, npoint, nsample, static_cast<const unsigned char *>(wpack), out, out_stride, pre, ctr, xcd_aware,
@@ -1519,7 +1524,7 @@ MPX_EXPORT int mpx_sa_mlp_bf16x3_factored(const float *pre, const float *ctr, co
   MPX_LAUNCH_CHECK("mpx_sa_mlp_bf16x3_factored");
 }
 
-// measurement only (not in the header): route the next launches of the persistent kernel through its PROBE instantiation,
+// measurement only: route the next launches of the persistent kernel through its PROBE instantiation,
 // which writes s_memtime stamps of one wave into `probe` (>= 128 int64; nullptr = off)
 MPX_EXPORT int mpx_sa2_bf16x3_set_probe(long long *probe) {
   g_sa2_probe = probe;

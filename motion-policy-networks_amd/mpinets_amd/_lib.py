@@ -68,6 +68,8 @@ PROTOTYPES = {
     "mpx_sa3_pack_size": [I, I, I, I],
     "mpx_sa3_pack_weights": [P, I, P, P, P, P, P, I, I, I, I, P, P],
     "mpx_sa3_chain": [P, I, I, I, P, I, I, I, I, P, I, P],
+    "mpx_sa3_chain_probe": [P, I, I, P, P, I, P, P],
+    "mpx_sa2_bf16x3_set_probe": [P],
     "mpx_linear": [P, I, P, P, I, I, I, I, P, I, P],
     "mpx_linear_workspace": [I, I, I],
     "mpx_linear_ws": [P, I, P, P, I, I, I, I, P, I, P, L, P],

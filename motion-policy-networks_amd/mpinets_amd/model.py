@@ -22,8 +22,8 @@ import torch
 from torch import nn
 
 from . import _lib
-from .pointnet2 import (FACTORED_SHAPE, PRECISIONS, PointnetSAModule, SplitWeights, groupnorm_leaky, groupnorm_leaky_train,
-                        launch_sa, linear, linear_train, linear_x3, mlp_chain_train, sa_mlp_factored)
+from .pointnet2 import (PRECISIONS, PointnetSAModule, SplitWeights, groupnorm_leaky, groupnorm_leaky_train,
+                        launch_sa, linear, linear_train, linear_x3, mlp_chain_train, sa_mlp_factored, use_factored)
 from .utils import unnormalize_franka_joints
 
 ACT_NONE, ACT_RELU, ACT_LEAKY = 0, 1, 2
@@ -318,7 +318,7 @@ class MPiNetsPointNet(nn.Module):
                                              tuple(c.out_channels for c in c1), lib.ptr(f1), f1.stride(1),
                                              append_centre=want_rows)
 
-        want_rows = bool(sa2.factored and (C1o,) + tuple(c.out_channels for c in c2) == FACTORED_SHAPE)
+        want_rows = use_factored(sa2, C1o, c2)
         state = {"centre_done": False}
         keep = None
         if B <= OVERLAP_MAX_BATCH:  # two independent chains, two streams (buffers were allocated above, on `main`)

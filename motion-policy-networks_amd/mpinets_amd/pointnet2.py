@@ -275,6 +275,16 @@ def sa_mlp_factored(point_rows: torch.Tensor, centre_rows: torch.Tensor, idx: to
 
 
 FACTORED_SHAPE = (64, 128, 128, 256)
+FACTORED_BF16X3_MAX_NSAMPLE = 128  # (= csrc/sa_mlp_bf16.hip v2::MAX_NSAMPLE: the persistent kernel's row -> query table)
+
+
+def use_factored(module: "PointnetSAModule", C: int, convs) -> bool:
+    """Does this module run with its first layer factored per point / per query?  Only the (64+3, 128, 128, 256) shape has
+    the kernels, and the ``bf16x3`` one is built for <= 128 slots per neighbourhood (larger ones take the unfactored
+    kernel, which has no such limit)."""
+    if not module.factored or (C,) + tuple(c.out_channels for c in convs) != FACTORED_SHAPE:
+        return False
+    return module.precision != "bf16x3" or module.nsample <= FACTORED_BF16X3_MAX_NSAMPLE
 
 
 # ---- module -------------------------------------------------------------------------------------------
@@ -524,9 +534,16 @@ class _MLPChainFn(torch.autograd.Function):
                 gx = torch.empty((M, Kp), dtype=torch.float32, device=dev)
                 below = acts[i - 1] if i > 0 else 0
                 # xs[i] IS the output of layer i - 1 (zero-padded columns: their gradient columns are dropped below)
-                _lib.call("mpx_linear_bf16x3_dact" if lx3 else "mpx_linear_dact", _lib.ptr(dz), dz.stride(0),
-                          _lib.ptr(split_pairs(wt) if lx3 else wt), M, Kp, Np, _lib.ptr(xs[i]) if below else None,
-                          xs[i].stride(0), below, _lib.ptr(gx), Kp)
+                if not lx3 and _lib.load().mpx_linear_workspace(M, Kp, Np) > 0:
+                    # skinny problem (the reference's batch of 10: a handful of 128 x 128 tiles walking K alone): the
+                    # split-K GEMM over the whole chip + the elementwise backward beats the fused epilogue on 8 CUs
+                    linear(dz, wt, None, 0, out=gx)
+                    if below:
+                        _lib.call("mpx_act_backward", _lib.ptr(gx), _lib.ptr(xs[i]), gx.numel(), below, _lib.ptr(gx))
+                else:
+                    _lib.call("mpx_linear_bf16x3_dact" if lx3 else "mpx_linear_dact", _lib.ptr(dz), dz.stride(0),
+                              _lib.ptr(split_pairs(wt) if lx3 else wt), M, Kp, Np, _lib.ptr(xs[i]) if below else None,
+                              xs[i].stride(0), below, _lib.ptr(gx), Kp)
                 dz = gx
             else:
                 dz = None
@@ -535,12 +552,19 @@ class _MLPChainFn(torch.autograd.Function):
 
 
 def mlp_chain_train(x: torch.Tensor, layers, acts, offsets: Optional[torch.Tensor] = None,
-                    precision: str = "fp32") -> torch.Tensor:
+                    precision: str = "fp32", offsets_checked: bool = False) -> torch.Tensor:
     """Differentiable stack of dense layers on the engine's kernels (one autograd node, see ``_MLPChainFn``).
     ``layers``: sequence of (weight [N,K], bias or None); ``acts``: one activation code per layer; ``x`` may have leading
     batch dimensions (flattened; not with ``offsets``); ``precision``: "fp32" or "bf16x3" (the large GEMMs of forward and
-    backward in split bf16, see ``_MLPChainFn``)."""
+    backward in split bf16, see ``_MLPChainFn``).  ``offsets`` (int64 [Q+1]) must tile the rows: offsets[0] = 0, ascending,
+    offsets[Q] = number of rows -- the pool's backward writes whole segments into an uninitialised buffer, so a gap would
+    leak garbage into the gradients; checked here (one host sync) unless the caller vouches with ``offsets_checked``."""
     assert precision in PRECISIONS
+    if offsets is not None and not offsets_checked:
+        assert x.ndim == 2 and offsets.ndim == 1 and offsets.numel() >= 2, "offsets: int64 [Q+1] over 2-D rows"
+        ends = offsets[[0, -1]].tolist()
+        assert ends == [0, x.size(0)] and bool((offsets[1:] >= offsets[:-1]).all()), \
+            f"offsets must tile the {x.size(0)} rows (got [{ends[0]} .. {ends[1]}], ascending required)"
     lead = x.shape[:-1]
     wb = []
     for w, b in layers:
@@ -560,7 +584,9 @@ def sa_module_train(convs: List[nn.Conv2d], xyz: torch.Tensor, xyz_stride: int, 
     R = int(offsets[-1].item())  # one host sync per module and step: the row count sizes the activations
     h = _PackRows.apply(feat, xyz, xyz_stride, new_xyz, new_stride, feat_stride, C, idx, cnt, offsets, R, dims)
     layers = [(conv.weight.view(conv.out_channels, -1), conv.bias) for conv in convs]
-    return mlp_chain_train(h, layers, [1] * len(layers), offsets=offsets, precision=precision).view(B, npoint, -1)
+    # (offsets = cumsum of the clamped counts, R = its last entry = the rows _PackRows made: the segments tile them)
+    return mlp_chain_train(h, layers, [1] * len(layers), offsets=offsets, precision=precision,
+                           offsets_checked=True).view(B, npoint, -1)
 
 
 class PointnetSAModule(nn.Module):
@@ -611,7 +637,7 @@ class PointnetSAModule(nn.Module):
                 fpm = features.transpose(1, 2).contiguous() if features.requires_grad else feat_pm
                 out = sa_module_train(convs, xyz, 3, new_xyz, 3, fpm, C, C, nbr, cnt, (B, N, self.npoint, self.nsample))
                 return new_xyz, out.transpose(1, 2).contiguous()
-            if self.factored and (C,) + tuple(c.out_channels for c in convs) == FACTORED_SHAPE:
+            if use_factored(self, C, convs):
                 full = cnt if self.elide_padding else torch.full_like(cnt, self.nsample)
                 rows = torch.cat((feat_pm, xyz, torch.zeros_like(xyz[:, :, :1])), dim=2).view(B * N, C + 4)
                 ctr_rows = torch.nn.functional.pad(new_xyz, (0, 1)).view(B * self.npoint, 4)

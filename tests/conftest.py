@@ -39,6 +39,13 @@ def model_golden():
 
 
 @pytest.fixture(scope="session")
+def dense_golden():
+    """The reference's model.py run on clouds built to OVERFLOW both ball queries (tests/golden/gen_dense_golden.py)."""
+    path = os.path.join(ROOT, "tests", "golden", "dense_golden.npz")
+    return dict(np.load(path, allow_pickle=False))
+
+
+@pytest.fixture(scope="session")
 def caller_golden():
     """Vectors made by running the reference's data_loader.py / run_inference.py (tests/golden/gen_caller_golden.py)."""
     path = os.path.join(ROOT, "tests", "golden", "caller_golden.npz")
