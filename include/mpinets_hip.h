@@ -591,15 +591,15 @@ int mpx_rollout_step(const mpx_policy_weights *w, const mpx_rollout_scene *scene
                      float *q_norm, float *q, int B, int32_t *flags, float *min_sdf, void *workspace,
                      int64_t workspace_bytes, mpx_stream_t stream);
 
-/* ---- measurement hooks (tools/probes/*.py; no product path calls them) ------------------------------------------
+/* ---- measurement hooks (the scripts under tools/probes; no product path calls them) ------------------------------------------
  * The same launches as mpx_sa3_chain / mpx_sa_mlp_bf16x3_factored through instantiations that write s_memtime stamps
  * of one wave at the kernel's phase boundaries.                                                                    */
 /* probe: int64 [>= 32]; B >= 301 (workgroup 300's wave 0 is the one stamped) */
-int mpx_sa3_chain_probe(const float *x, int ldx, int B, const float *pack, float *out, int ldo, long long *probe,
+int mpx_sa3_chain_probe(const float *x, int ldx, int B, const float *pack, float *out, int ldo, int64_t *probe,
                         mpx_stream_t stream);
 /* probe: int64 [>= 128] or NULL (off): while set, every mpx_sa_mlp_bf16x3_factored call first runs the stamped
  * instantiation (process-wide switch, not thread-safe) */
-int mpx_sa2_bf16x3_set_probe(long long *probe);
+int mpx_sa2_bf16x3_set_probe(int64_t *probe);
 
 #ifdef __cplusplus
 }

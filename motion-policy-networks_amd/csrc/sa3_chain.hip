@@ -326,12 +326,12 @@ MPX_EXPORT int mpx_sa3_pack_weights(const float *w1, int k1_real, const float *b
 
 // measurement only: the same launch with s_memtime stamps of workgroup 300, wave 0 at the phase
 // boundaries -> probe[0..16] (tools/probes/sa3_phase_probe.py)
-MPX_EXPORT int mpx_sa3_chain_probe(const float *x, int ldx, int B, const float *pack, float *out, int ldo, long long *probe,
+MPX_EXPORT int mpx_sa3_chain_probe(const float *x, int ldx, int B, const float *pack, float *out, int ldo, int64_t *probe,
                                    mpx_stream_t stream) {
   using C = sa3::Cfg<272, 512, 512, 1024>;
   MPX_LDS_LIMIT_ONCE((sa3_chain_kernel<272, 512, 512, 1024, true>), C::LDS_BYTES, "mpx_sa3_chain_probe");
   hipLaunchKernelGGL((sa3_chain_kernel<272, 512, 512, 1024, true>), dim3((unsigned)B), dim3(64 * sa3::WV), C::LDS_BYTES,
-                     mpx_s(stream), x, ldx, pack, out, ldo, probe);
+                     mpx_s(stream), x, ldx, pack, out, ldo, reinterpret_cast<long long *>(probe));
   MPX_LAUNCH_CHECK("mpx_sa3_chain_probe");
 }
 

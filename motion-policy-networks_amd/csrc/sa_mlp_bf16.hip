@@ -1526,8 +1526,8 @@ MPX_EXPORT int mpx_sa_mlp_bf16x3_factored(const float *pre, const float *ctr, co
 
 // measurement only: route the next launches of the persistent kernel through its PROBE instantiation,
 // which writes s_memtime stamps of one wave into `probe` (>= 128 int64; nullptr = off)
-MPX_EXPORT int mpx_sa2_bf16x3_set_probe(long long *probe) {
-  g_sa2_probe = probe;
+MPX_EXPORT int mpx_sa2_bf16x3_set_probe(int64_t *probe) {
+  g_sa2_probe = reinterpret_cast<long long *>(probe);
   return 0;
 }
 
