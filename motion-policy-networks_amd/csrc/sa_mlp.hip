@@ -46,6 +46,12 @@ constexpr int SA_MAX_NSAMPLE = 256;  // slots per neighbourhood the packed kerne
 #ifndef MPX_SA_SPREAD
 #define MPX_SA_SPREAD 1
 #endif
+// narrow module: pool through LDS float-max atomics into a [Q][C3] block that is written out once per unit, instead of
+// merging the row groups in registers with a flush at every query boundary (round 6: 10.06 -> 9.61 ms at 8192 environments;
+// 0 = the register merge, which also serves neighbourhoods of more than 128 slots and unaligned output rows)
+#ifndef MPX_SA1_LDSPOOL
+#define MPX_SA1_LDSPOOL 1
+#endif
 
 template <int CF, int C1, int C2, int C3>
 struct SaCfg {
@@ -307,7 +313,7 @@ __global__ void __launch_bounds__(256, 2)
 // once per QUERY (`ctr` [B*npoint, C1]); the kernel then starts at relu(pre[j] - ctr[i]) -- a gather, a
 // subtraction -- and skips the layer-1 MFMAs of every (query, neighbour) row (15 % of SA2's matrix work).
 // Same arithmetic up to the order of that one sum (tolerance-level, not bit-level, vs the direct form).
-template <int CF, int C1, int C2, int C3, int Q, bool FACT>
+template <int CF, int C1, int C2, int C3, int Q, bool FACT, int MAXNS = SA_MAX_NSAMPLE>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CF == 1 ? 4 : 2, CF == 1 ? 4 : 2)))
     sa_mlp_packed_kernel(const float *__restrict__ xyz, int stride, const float *__restrict__ new_xyz,
                          int new_stride, const float *__restrict__ feat, int feat_stride,
@@ -322,7 +328,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CF == 1
   constexpr int GR = CF == 1 ? MPX_SA1_GR : 4, NGRP = 32 / GR;
   static_assert(GR == 2 || GR == 4, "pooling groups of 2 or 4 rows");
   __shared__ float ctr_s[FACT ? Q * C1 : 1];
-  __shared__ unsigned char qmap_s[Q * SA_MAX_NSAMPLE / GR + 32];  // (row group -> query; rows per query <= nsample <= 256)
+  // LPOOL: a lane's row groups go to their query's row of pool_s by ds_max_f32 (16 rows x 2 output tiles of the narrow
+  // module = 2.1 queries per tile on the bench scenes: the register merge below walked 16 groups with a readlane, a compare
+  // and a select each and flushed at every boundary -- 3 VALU per MFMA on the counters against 0.8 inside the stream)
+  constexpr bool LPOOL = CF == 1 && !FACT && MPX_SA1_LDSPOOL != 0 && MAXNS <= 128;
+  __shared__ __attribute__((aligned(16))) float pool_s[LPOOL ? Q * C3 : 1];
+  __shared__ __attribute__((aligned(16))) unsigned char qmap_s[Q * MAXNS / GR + 32];  // (row group -> query; rows per query <= nsample <= MAXNS)
   // biases in LDS: they initialise the accumulators at every tile and are added at every flush -- as global loads
   // their latency sits on the critical path of each tile
   __shared__ __attribute__((aligned(16))) float b1_s[C1], b2_s[C2], b3_s[C3];
@@ -397,6 +408,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CF == 1
   }
   const int64_t q0 = wg * Q;
   const int nq = (int)min((int64_t)Q, n_query - q0);
+  if constexpr (LPOOL) {  // (one wave per workgroup: its LDS operations execute in program order -- the previous unit's
+                          // read-out below is complete before these stores land)
+    const float ninf = -__builtin_inff();
+#pragma unroll
+    for (int e = lane; e < Q * C3 / 4; e += 64) *reinterpret_cast<float4 *>(pool_s + 4 * e) = make_float4(ninf, ninf, ninf, ninf);
+  }
   if constexpr (FACT) {  // this wave's per-query terms -> LDS (read back per row at every tile start)
 #pragma unroll
     for (int i = threadIdx.x; i < Q * C1 / 4; i += 64) {
@@ -595,6 +612,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CF == 1
       else return __builtin_amdgcn_readlane(q_tile, GR * grp);
     };
     const int cur0 = cur;
+    // LPOOL: the queries of the tile's 16 row groups, one byte each (the same 16 bytes in every lane); whether one query
+    // owns the whole tile is wave-uniform
+    static_assert(!LPOOL || (GR == 2 && NGRP == 16), "a tile's group -> query bytes are one 16-byte LDS read");
     const int q_gather = q_next, k_gather = k_next;
     q_cur = q_next;
     if (rt + 64 < total) {
@@ -685,7 +705,28 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CF == 1
               gm[2 * j + 1] = fmaxf(a3[4 * j + 2], a3[4 * j + 3]);
             }
           }
-          if (gq(NGRP - 1) == cur0) {  // the whole tile belongs to the query being merged (the wide module's common case): no flush
+          if constexpr (LPOOL) {
+            // this lane's 8 groups: gm[2 j + ii] = rows 8 j + 4 half + 2 ii .. + 1 = group 4 j + 2 half + ii of the tile
+            // (read where it is used, once per output tile: four registers held across the tile's MFMA stream spill)
+            const u32x4 qmv = *reinterpret_cast<const u32x4 *>(qmap_s + rt / GR);
+            const bool one_query =
+                __builtin_amdgcn_readfirstlane((int)(qmv.x & 0xffu)) == __builtin_amdgcn_readfirstlane((int)(qmv.w >> 24));
+            float *prow = pool_s + ot * 32 + col;
+            if (one_query) {
+              float m = gm[0];
+#pragma unroll
+              for (int j = 1; j < 8; ++j) m = fmaxf(m, gm[j]);
+              (void)__hip_atomic_fetch_max(prow + (qmv.x & 0xffu) * C3, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                const unsigned w = (j == 0 ? qmv.x : j == 1 ? qmv.y : j == 2 ? qmv.z : qmv.w) >> (16 * half);
+                (void)__hip_atomic_fetch_max(prow + (w & 0xffu) * C3, gm[2 * j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                (void)__hip_atomic_fetch_max(prow + ((w >> 8) & 0xffu) * C3, gm[2 * j + 1], __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_WORKGROUP);
+              }
+            }
+          } else if (gq(NGRP - 1) == cur0) {  // the whole tile belongs to the query being merged (the wide module's common case): no flush
             float m = gm[0];
 #pragma unroll
             for (int j = 1; j < 16 / GR; ++j) m = fmaxf(m, gm[j]);
@@ -736,10 +777,23 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CF == 1
         }
       }
     }
-    cur = gq(NGRP - 1);
+    if constexpr (!LPOOL) cur = gq(NGRP - 1);
   }
+  if constexpr (LPOOL) {
+    // the unit's pooled rows: relu(max + b3), 16 bytes per lane (the launcher checked the output rows' alignment)
+#pragma unroll 2
+    for (int e = lane; e < Q * C3 / 4; e += 64) {
+      const int qi = (4 * e) / C3, ch = (4 * e) % C3;
+      if (qi < nq) {
+        const float4 v = *reinterpret_cast<const float4 *>(pool_s + 4 * e), bb = *reinterpret_cast<const float4 *>(b3_s + ch);
+        *reinterpret_cast<float4 *>(out + (int64_t)(qbase + qi) * out_stride + ch) =
+            make_float4(fmaxf(v.x + bb.x, 0.0f), fmaxf(v.y + bb.y, 0.0f), fmaxf(v.z + bb.z, 0.0f), fmaxf(v.w + bb.w, 0.0f));
+      }
+    }
+  } else {
 #pragma unroll
-  for (int ot = 0; ot < Cfg::OT3; ++ot) flush(ot, cur);
+    for (int ot = 0; ot < Cfg::OT3; ++ot) flush(ot, cur);
+  }
   }  // units
 }
 
@@ -789,9 +843,20 @@ static int launch_sa(const float *xyz, int stride, const float *new_xyz, int new
         }
         if (queue) nw = slots;  // (no private slot left for this stream: one unit per wave, no queue)
       }
-      hipLaunchKernelGGL((sa_mlp_packed_kernel<CF, C1, C2, C3, Q, false>), dim3((unsigned)nw), dim3(64), 0,
-                         mpx_s(stream), xyz, stride, new_xyz, new_stride, feat, feat_stride, idx, cnt, nq, N, npoint,
-                         nsample, wpack, out, out_stride, bpe, nullptr, nullptr, append_centre, queue);
+      // (the narrow module with <= 128 slots per neighbourhood and 16-byte aligned output rows: the form with the small
+      // row map that pools through LDS, see LPOOL in the kernel)
+      bool lpool = false;
+      if constexpr (CF == 1 && MPX_SA1_LDSPOOL != 0) {
+        lpool = nsample <= 128 && out_stride % 4 == 0 && ((uintptr_t)out & 15) == 0;
+        if (lpool)
+          hipLaunchKernelGGL((sa_mlp_packed_kernel<CF, C1, C2, C3, Q, false, 128>), dim3((unsigned)nw), dim3(64), 0,
+                             mpx_s(stream), xyz, stride, new_xyz, new_stride, feat, feat_stride, idx, cnt, nq, N, npoint,
+                             nsample, wpack, out, out_stride, bpe, nullptr, nullptr, append_centre, queue);
+      }
+      if (!lpool)
+        hipLaunchKernelGGL((sa_mlp_packed_kernel<CF, C1, C2, C3, Q, false>), dim3((unsigned)nw), dim3(64), 0,
+                           mpx_s(stream), xyz, stride, new_xyz, new_stride, feat, feat_stride, idx, cnt, nq, N, npoint,
+                           nsample, wpack, out, out_stride, bpe, nullptr, nullptr, append_centre, queue);
     };
     if (nq >= 1024 * QL) go(std::integral_constant<int, QL>{});
     else go(std::integral_constant<int, QS>{});
