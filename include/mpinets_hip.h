@@ -155,6 +155,22 @@ int mpx_linear_rowmax_bf16x3_pairs(const void *a_pairs, int lda, const void *w_p
                                    int N, int K, int rows, float *y, int ldy, void *y_pairs, int ldp,
                                    mpx_stream_t stream);
 
+/* The group-all module's first two layers (272 -> 512 -> 512, ReLU each; model.py:377-383) in bf16x3 as ONE kernel: a
+ * workgroup per environment, the rows divided among its waves, activations in registers from layer to layer, the weights
+ * streamed through an LDS ring once per environment (csrc/sa3_front_bf16.hip).  x: fp32 rows [B * 128, ldx >= 272]
+ * ([xyz | f | 0], 16-byte aligned); y_pairs: [B * 128, ldp >= 1024] bf16 in the pairs form with the k-steps in the KERNEL's
+ * channel order -- the operand of mpx_linear_rowmax_bf16x3_pairs with the weight pairs of mpx_sa3_front_bf16x3_w3_pairs
+ * (the same columns permuted).  Equal to mpx_linear_bf16x3_to_pairs + mpx_linear_bf16x3_pairs to rounding (the 16 products
+ * of a k-step enter the MFMA in another order, the bias is added first), not bit for bit.
+ * pack: mpx_sa3_front_bf16x3_pack_size bytes (host call; -1: unsupported widths), written by mpx_sa3_front_bf16x3_pack from
+ * the fp32 weights w1 [c1, k1_real <= K1], w2 [c2, c1] and biases.                                                    */
+int64_t mpx_sa3_front_bf16x3_pack_size(int K1, int c1, int c2);
+int mpx_sa3_front_bf16x3_pack(const float *w1, int k1_real, const float *b1, const float *w2, const float *b2, int K1,
+                              int c1, int c2, void *pack, mpx_stream_t stream);
+int mpx_sa3_front_bf16x3_w3_pairs(const float *w3, int c3, int c2, void *w3_pairs, mpx_stream_t stream);
+int mpx_sa3_front_bf16x3(const float *x, int ldx, int B, int rows, const void *pack, void *y_pairs, int ldp,
+                         mpx_stream_t stream);
+
 /* ---- training losses with analytic gradients (row N1; mpinets/loss.py:31-166) -------------------- */
 
 /* collision_loss (loss.py:48-95) on points [B,N,3] (strides in floats): per environment
@@ -600,6 +616,9 @@ int mpx_sa3_chain_probe(const float *x, int ldx, int B, const float *pack, float
 /* probe: int64 [>= 128] or NULL (off): while set, every mpx_sa_mlp_bf16x3_factored call first runs the stamped
  * instantiation (process-wide switch, not thread-safe) */
 int mpx_sa2_bf16x3_set_probe(int64_t *probe);
+/* mpx_sa3_front_bf16x3 with stamps (probe: int64 [>= 64]; B > 300) */
+int mpx_sa3_front_bf16x3_probe(const float *x, int ldx, int B, const void *pack, void *y_pairs, int ldp, int64_t *probe,
+                               mpx_stream_t stream);
 
 #ifdef __cplusplus
 }

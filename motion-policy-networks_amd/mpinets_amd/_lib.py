@@ -80,6 +80,11 @@ PROTOTYPES = {
     "mpx_linear_bf16x3_to_pairs": [P, I, P, P, I, I, I, I, P, I, P],
     "mpx_linear_bf16x3_pairs": [P, I, P, P, I, I, I, I, P, I, P, I, P],
     "mpx_linear_rowmax_bf16x3_pairs": [P, I, P, P, I, I, I, I, P, I, P, I, P],
+    "mpx_sa3_front_bf16x3_pack_size": [I, I, I],
+    "mpx_sa3_front_bf16x3_pack": [P, I, P, P, P, I, I, I, P, P],
+    "mpx_sa3_front_bf16x3_w3_pairs": [P, I, I, P, P],
+    "mpx_sa3_front_bf16x3": [P, I, I, I, P, P, I, P],
+    "mpx_sa3_front_bf16x3_probe": [P, I, I, P, P, I, P, P],
     "mpx_groupnorm_leaky_grad": [P, P, P, P, I, I, I, F, P, P, P, P, P],
     "mpx_act_backward": [P, P, L, I, P, P],
     "mpx_linear_dact": [P, I, P, I, I, I, P, I, I, P, I, P],
@@ -97,7 +102,7 @@ PROTOTYPES = {
     "mpx_rollout_step": [P, P, P, I, P, P, I, P, P, P, L, P],
     "mpx_rollout": [P, P, P, P, I, P, P, I, P, P, P, L, P],
 }
-RESTYPES = {"mpx_last_error": c_char_p, "mpx_sa_pack_size": c_int64, "mpx_sa_pack_bf16x3_size": c_int64,
+RESTYPES = {"mpx_last_error": c_char_p, "mpx_sa_pack_size": c_int64, "mpx_sa3_front_bf16x3_pack_size": c_int64, "mpx_sa_pack_bf16x3_size": c_int64,
             "mpx_linear_wgrad_scratch": c_int64, "mpx_linear_workspace": c_int64, "mpx_policy_workspace": c_int64, "mpx_rollout_workspace": c_int64}
 
 _lib: Optional[ctypes.CDLL] = None

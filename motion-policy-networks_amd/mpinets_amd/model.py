@@ -71,6 +71,10 @@ class MPiNetsPointNet(nn.Module):
         )
         self._sa3_w0 = None  # first group-all layer with K padded 259 -> 272 (whole 16-float slabs: direct-to-LDS GEMM)
         self._sa3_pk = None  # (key, mpx_sa3_pack_weights of the group-all module)
+        self._sa3_fp = None  # (key, mpx_sa3_front_bf16x3_pack, last layer's permuted weight pairs): bf16x3 mode
+        # bf16x3 only: the group-all module's first two layers as one kernel (default) or layer by layer (the round-5 form,
+        # bit-identical to the chain through fp32 rows; kept for the tests that pin the fused kernel to it)
+        self.sa3_front_fused = True
         self.dense_precision = "fp32"  # "bf16x3": the large dense layers on the bf16 matrix cores (set_precision)
         self.train_precision = "fp32"  # "bf16x3": the grouped / group-all MLPs' training GEMMs in split bf16 (set_training_precision)
         self._split = SplitWeights()
@@ -94,6 +98,25 @@ class MPiNetsPointNet(nn.Module):
         them) instead of fp32 rows.  Bit-identical to the fp32-row chain (same split, same accumulation order).  Rows
         go in chunks that keep an operand under the 4 GB a buffer descriptor spans."""
         lib, dev = _lib, h.device
+        front = self._sa3_front_pack(h.size(1)) if self.sa3_front_fused else None
+        if front is not None:
+            # layers 1-2 as ONE kernel (rows divided among the waves, activations in registers, the weights through an LDS
+            # ring once per environment: csrc/sa3_front_bf16.hip); its rows carry their k-steps in the kernel's channel
+            # order, the last layer's weight pairs have their columns permuted to match.  Equal to the layer-by-layer form
+            # to rounding (1e-7 relative), not bit for bit.
+            pack, w3p = front
+            n2, n3 = c3[1].out_channels, c3[2].out_channels
+            pooled = (torch.empty((B, 2 * n3), dtype=torch.bfloat16, device=dev) if pooled_pairs else
+                      torch.empty((B, n3), dtype=torch.float32, device=dev))
+            step = max(1, min(65535, ((1 << 32) - 4096) // (128 * 4 * n2)))  # environments per call (4 GB descriptors)
+            p2 = torch.empty((min(step, B) * 128, 2 * n2), dtype=torch.bfloat16, device=dev)
+            for b0 in range(0, B, step):
+                nb = min(step, B - b0)
+                lib.call("mpx_sa3_front_bf16x3", lib.ptr(h[b0 * 128:]), h.stride(0), nb, 128, lib.ptr(pack), lib.ptr(p2), 2 * n2)
+                lib.call("mpx_linear_rowmax_bf16x3_pairs", lib.ptr(p2), 2 * n2, lib.ptr(w3p), lib.ptr(c3[2].bias), nb * 128, n3, n2,
+                         128, None if pooled_pairs else lib.ptr(pooled[b0:]), 0 if pooled_pairs else pooled.stride(0),
+                         lib.ptr(pooled[b0:]) if pooled_pairs else None, pooled.stride(0) if pooled_pairs else 0)
+            return pooled
         w = [self._sa3_first_weight(), c3[1].weight.view(c3[1].out_channels, -1), c3[2].weight.view(c3[2].out_channels, -1)]
         wp = [self._split.get(w[0], c3[0].weight), self._split.get(w[1]), self._split.get(w[2])]
         n1, n2, n3 = (x.size(0) for x in w)
@@ -211,6 +234,28 @@ class MPiNetsPointNet(nn.Module):
             w = conv.weight.detach().reshape(conv.out_channels, -1)
             self._sa3_w0 = (key, torch.nn.functional.pad(w, (0, (-w.size(1)) % 16)).contiguous())
         return self._sa3_w0[1]
+
+    def _sa3_front_pack(self, K3: int):
+        """(weight pack of ``mpx_sa3_front_bf16x3``, the last layer's weight pairs in its channel order), or None when the
+        group-all MLP does not have the widths the kernel is built for."""
+        c3 = self.SA_modules[2].convs()
+        dims = (K3, c3[0].out_channels, c3[1].out_channels)
+        n = _lib.load().mpx_sa3_front_bf16x3_pack_size(*dims)
+        if n < 0 or c3[2].out_channels % 16:
+            return None
+        ps = [p for c in c3 for p in (c.weight, c.bias)]
+        key = tuple((p._version, p.data_ptr()) for p in ps) + dims
+        if self._sa3_fp is None or self._sa3_fp[0] != key:
+            dev = c3[0].weight.device
+            w = [_lib.f32c(c.weight.detach().view(c.out_channels, -1)) for c in c3]
+            b = [_lib.f32c(c.bias.detach()) for c in c3]
+            pack = torch.empty(n, dtype=torch.uint8, device=dev)
+            _lib.call("mpx_sa3_front_bf16x3_pack", _lib.ptr(w[0]), w[0].size(1), _lib.ptr(b[0]), _lib.ptr(w[1]), _lib.ptr(b[1]), *dims,
+                      _lib.ptr(pack))
+            w3p = torch.empty((w[2].size(0), 2 * w[2].size(1)), dtype=torch.bfloat16, device=dev)
+            _lib.call("mpx_sa3_front_bf16x3_w3_pairs", _lib.ptr(w[2]), w[2].size(0), w[2].size(1), _lib.ptr(w3p))
+            self._sa3_fp = (key, pack, w3p)
+        return self._sa3_fp[1], self._sa3_fp[2]
 
     def _sa3_pack(self, K3: int) -> Optional[torch.Tensor]:
         """The group-all module's three layers in the stream order of ``mpx_sa3_chain`` (None: unsupported widths)."""
@@ -469,6 +514,7 @@ class MotionPolicyNetwork(nn.Module):
         enc._split.cache.clear()
         enc._sa3_w0 = None
         enc._sa3_pk = None
+        enc._sa3_fp = None
         self._q_w0 = None
         return self
 

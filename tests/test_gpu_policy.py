@@ -543,18 +543,27 @@ def test_linear_bf16x3_pairs_chain_is_bit_identical_to_the_row_chain():
 
 
 def test_policy_forward_bf16x3_pairs_on_and_off_agree():
-    """The policy forward in bf16x3 with the group-all MLP through pairs (default) == with fp32 rows, bit for bit."""
+    """The policy forward in bf16x3 with the group-all MLP layer by layer through pairs == with fp32 rows, bit for bit; the
+    default -- its first two layers as ONE kernel (mpx_sa3_front_bf16x3: another order of the 16 products inside an MFMA
+    step, the bias added last instead of in the epilogue's place) -- equals both to rounding."""
     from mpinets_amd.model import MotionPolicyNetwork
     from mpinets_amd.scenes import make_problem_batch
 
     torch.manual_seed(5)
     mdl = MotionPolicyNetwork().to(dev()).eval().set_precision("bf16x3")
+    enc = mdl.point_cloud_encoder
     prob = make_problem_batch(6, seed=31, device=dev())
     with torch.no_grad():
+        fused = mdl(prob["xyz"], prob["q_norm"]).clone()
+        assert enc._sa3_fp is not None  # (the fused kernel served the default call)
+        enc.sa3_front_fused = False
         a = mdl(prob["xyz"], prob["q_norm"]).clone()
-        mdl.point_cloud_encoder.dense_through_pairs = False
+        enc.dense_through_pairs = False
         b = mdl(prob["xyz"], prob["q_norm"]).clone()
     assert torch.equal(a, b)
+    err = (fused - a).abs().max().item()
+    print("bf16x3: fused group-all front vs layer by layer: %.2e" % err)
+    assert err <= 2e-6
 
 
 @pytest.mark.parametrize("B", [1, 5, 9, 40])
