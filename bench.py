@@ -362,7 +362,7 @@ def main():
         torch.cuda.synchronize()
         shard.barrier()
         dense_calls = ("mpx_linear_bf16x3", "mpx_linear_rowmax_bf16x3", "mpx_linear_bf16x3_to_pairs", "mpx_linear_bf16x3_pairs",
-                       "mpx_linear_rowmax_bf16x3_pairs", "mpx_linear", "mpx_linear_ws")
+                       "mpx_linear_rowmax_bf16x3_pairs", "mpx_sa3_front_bf16x3", "mpx_linear", "mpx_linear_ws")
         _lib.profile_start("mpx_sa_mlp_bf16x3", "mpx_sa_mlp_bf16x3_factored", *dense_calls)
         tf0 = time.perf_counter()
         for _ in range(args.fast_steps):

@@ -33,7 +33,7 @@ eng = RolloutEngine(mdl, prob, rerender_scene=True, scene_seed=17, resample_subs
 eng.step()
 torch.cuda.synchronize()
 names = ("mpx_sa_mlp_bf16x3", "mpx_sa_mlp_bf16x3_factored", "mpx_linear_bf16x3", "mpx_linear_bf16x3_to_pairs",
-         "mpx_linear_bf16x3_pairs", "mpx_linear_rowmax_bf16x3_pairs", "mpx_groupnorm_leaky_to_pairs", "mpx_linear", "mpx_fps",
+         "mpx_linear_bf16x3_pairs", "mpx_linear_rowmax_bf16x3_pairs", "mpx_sa3_front_bf16x3", "mpx_groupnorm_leaky_to_pairs", "mpx_linear", "mpx_fps",
          "mpx_ball_query", "mpx_sort_queries")
 _lib.profile_start(*names)
 t0 = time.perf_counter()
