@@ -285,6 +285,11 @@ static int wgrad_run(const char *name, bool x3, const float *dy, int lddy, const
   const int S = wgrad_splits(M, N, K), T = wgrad_tile(N, K);
   const int rps = cdiv(cdiv(M, S), WG_BK) * WG_BK;
   MPX_REQUIRE(cdiv(N, T) <= 65535 && S <= 65535, "%s: grid too large", name);
+  // ONE split (few rows: the reference's batch of 10 through the dense heads) and dw | db adjacent, as every split's slice
+  // is laid out: the kernel writes the gradients themselves.  (The reduction of a single split was a copy on 16 lanes per
+  // element -- 134 M threads for the 4096 x 2048 layer: 0.72 of the 5.2 ms of a batch-10 step.)
+  const bool direct = S == 1 && (db == nullptr || db == dw + (size_t)N * K);
+  if (direct) scratch = dw;
   if (x3 && T == 128)
     mpx_wgrad_bf16x3_launch(dy, lddy, x, ldx, M, N, K, rps, S, scratch, db ? 1 : 0, mpx_s(stream));
   else if (T == 64)
@@ -295,7 +300,8 @@ static int wgrad_run(const char *name, bool x3, const float *dy, int lddy, const
                        ldx, M, N, K, rps, scratch, db ? 1 : 0);
   // dw [N*K] and db [N] are adjacent in every split's slice: one reduction (db lands right behind dw if the caller
   // laid them out that way, else two launches)
-  if (db == dw + (size_t)N * K) {
+  if (direct) {
+  } else if (db == dw + (size_t)N * K) {
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(per * 16, 256)), dim3(256), 0, mpx_s(stream), scratch, S, per, per, dw);
   } else {
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv((int64_t)N * K * 16, 256)), dim3(256), 0, mpx_s(stream), scratch, S,
