@@ -29,7 +29,9 @@ typedef void *mpx_stream_t;
 
 #define MPX_NUM_FRAMES 15 /* link0..8, hand, leftfinger, rightfinger, l/r fingertip, right_gripper */
 
-int mpx_version(void); /* 320: mpx_linear_dact, mpx_segment_max_grad_act, mpx_linear_bf16x3_dact, mpx_linear_wgrad_bf16x3 (additions only); mpx_franka_collision accepts
+int mpx_version(void); /* 330: mpx_sa3_front_bf16x3 / _pack / _pack_size / _w3_pairs (additions), the measurement hooks mpx_sa3_chain_probe / mpx_sa2_bf16x3_set_probe /
+                          mpx_sa3_front_bf16x3_probe declared, mpx_sa_mlp_bf16x3_factored refuses nsample > 128;
+                          320: mpx_linear_dact, mpx_segment_max_grad_act, mpx_linear_bf16x3_dact, mpx_linear_wgrad_bf16x3 (additions only); mpx_franka_collision accepts
                           frame pointers that are not 16-byte aligned;
                           310: struct mpx_policy_weights ends with sa3_pack (NULL = layer-by-layer group-all module at every
                           batch size; a caller built against the 200 header must be rebuilt), MPX_VARIANT_UNIT_QUEUE,

@@ -828,16 +828,6 @@ static_assert(Cfg::ST2 == 32 && Cfg::ST3 == 64 && Cfg::KS1 == 8 && Cfg::KS2 == 8
 }  // namespace v2
 
 #define V2_FENCE() __builtin_amdgcn_sched_barrier(0)
-#ifndef MPX_V2_GAPMAP
-#define MPX_V2_GAPMAP 1  // the next tile's row -> (query, neighbour) map, the tile's boundary shape and pair B's biases ride in the
-                         // fetch-free gaps of layer 2's first output pair (0: round 4: all in front of the tile's first MFMA)
-#endif
-#ifndef MPX_V2_TWOACC
-#define MPX_V2_TWOACC 1  // tiles with ONE query boundary: branch-free two-way pooling, flush deferred into the next tile (0: round 4)
-#endif
-#ifndef MPX_V2_SMOOTH
-#define MPX_V2_SMOOTH 1  // fillers of the tile loop in half quanta, one piece per MFMA gap (0: round 3's placement)
-#endif
 
 // Unit queues of the persistent kernel: 8 counters (one per XCD) per launch, in device memory that belongs to the
 // library image (nothing is allocated).  ONE SLOT PER (device, stream): the launches of a stream are ordered (memset,
@@ -954,24 +944,13 @@ __global__ void __launch_bounds__(64 * v2::WV) __attribute__((amdgpu_waves_per_e
   // relu(pre - ctr) + split behind the tile's last MFMA, 1.7 k cycles between two tiles.  Pinning every quantum in its gap
   // with an empty volatile asm on its operand registers moves those cycles INTO the layer loops and leaves the tile time
   // where it was (14.9 k / 17.9 k cycles with / without a query boundary): the fillers are not what the tile waits for.)
-  // relu + hi / lo split of elements (2e, 2e+1) of a 16-float accumulator tile into the packed bf16 operand pairs
-  // (one "quantum": ~8 VALU) -- relu_split_tile, two elements at a time
-  auto split_q = [&](const f32x16 &acc, bf16x8 (&hi)[2], bf16x8 (&lo)[2], int e) __attribute__((always_inline)) {
-    const int u = e >> 2, k = 2 * (e & 3);
-    const float v0 = fmaxf(acc[8 * u + k], 0.0f), v1 = fmaxf(acc[8 * u + k + 1], 0.0f);
-    const __bf16 h0 = (__bf16)v0, h1 = (__bf16)v1;
-    hi[u][k] = h0;
-    hi[u][k + 1] = h1;
-    lo[u][k] = (__bf16)(v0 - (float)h0);
-    lo[u][k + 1] = (__bf16)(v1 - (float)h1);
-  };
-
+  // relu + hi / lo split of elements (2e, 2e+1) of a 16-float accumulator tile into the packed bf16 operand pairs = one
+  // "quantum" (~8 VALU; relu_split_tile, two elements at a time).
   // Half quanta (round 4): a gap between two MFMAs of a lone in-order wave hides about three plain VALU; a fourth costs
   // ~2 cycles, a burst of 9-13 (a whole quantum) stalls the next MFMA for the burst's own issue time (micro-benchmark:
   // tools/probes/mfma_bf16_stream.hip).  So a quantum is cut in two -- relu + hi, then lo -- and the halves go into
   // consecutive gaps; the empty volatile asm pins each half where it is written (the compiler otherwise sinks most of
   // them behind the tile's last MFMA).
-  (void)split_q;  // (round 3's whole-quantum form: MPX_V2_SMOOTH=0)
   float tv0 = 0.0f, tv1 = 0.0f;  // relu'd pair between the two halves of a split
   auto split_h = [&](const f32x16 &acc, bf16x8 (&hi)[2], bf16x8 (&lo)[2], int e, int part) __attribute__((always_inline)) {
     const int u = e >> 2, k = 2 * (e & 3);
@@ -1160,7 +1139,6 @@ __global__ void __launch_bounds__(64 * v2::WV) __attribute__((amdgpu_waves_per_e
       m_cur = (unsigned)__builtin_amdgcn_ballot_w64(ql_tile == cur);
     };
     auto shape_b = [&]() __attribute__((always_inline)) {
-#if MPX_V2_TWOACC
       m_last = (unsigned)__builtin_amdgcn_ballot_w64(ql_tile == gq[7]);
       g1 = (m_cur == 0xffffffffu ? 32 : __builtin_ctz(~m_cur)) >> 2;
       one_b = gq[7] != cur && (m_cur | m_last) == 0xffffffffu;
@@ -1171,7 +1149,6 @@ __global__ void __launch_bounds__(64 * v2::WV) __attribute__((amdgpu_waves_per_e
       if constexpr (PROBE) {  // boundary shape of the tile beside its stamps: 0 none, 1 one boundary, 2 more
         if (blockIdx.x == 100 && threadIdx.x == 0 && (pi >> 2) < 24) probe[96 + (pi >> 2)] = g1 == 8 ? 0 : (one_b ? 1 : 2);
       }
-#endif
     };
     f32x16 a3[2][2];
     auto pool = [&](int pr, int part) __attribute__((always_inline)) {  // output pair pr, tile o = part
@@ -1206,14 +1183,12 @@ __global__ void __launch_bounds__(64 * v2::WV) __attribute__((amdgpu_waves_per_e
       const float *gm = gmb[part];
       if (gq[7] == cur) {  // the whole tile belongs to the query being merged (the common case)
         run[ot] = fmaxf(run[ot], fmaxf(fmaxf(gm[0], gm[1]), fmaxf(gm[2], gm[3])));
-#if MPX_V2_TWOACC
       } else if (one_b) {  // one boundary: the finished query's side is completed and stored, the rest starts the new one
         const float o0 = fminf(gm[0], limo[0]), o1 = fminf(gm[1], limo[1]), o2 = fminf(gm[2], limo[2]), o3 = fminf(gm[3], limo[3]);
         const float n0 = fminf(gm[0], -limo[0]), n1 = fminf(gm[1], -limo[1]), n2 = fminf(gm[2], -limo[2]), n3 = fminf(gm[3], -limo[3]);
         const float done = mpx_max_across_halves(fmaxf(fmaxf(run[ot], fmaxf(o0, o1)), fmaxf(o2, o3)));
         out_unit[cur_off + ot * 32] = fmaxf(done + b3v[ot], 0.0f);
         run[ot] = fmaxf(fmaxf(n0, n1), fmaxf(n2, n3));
-#endif
       } else {
         int c = cur;
 #pragma unroll
@@ -1252,28 +1227,13 @@ __global__ void __launch_bounds__(64 * v2::WV) __attribute__((amdgpu_waves_per_e
       const float *cq_next = ctr_w + ql_next * C1 + 4 * half;  // LDS row of the next tile's query (this lane's row)
       ql_cur = ql_next;
       V2_FENCE();
-#if !MPX_V2_GAPMAP
-      {  // index of the row after next: issued now, consumed a tile later (rows past the end are clamped by map_row)
-        int off;
-        map_row(rt + 64 + col, ql_next, env_next, off);
-        k_next = idx_unit[ql_next * nsample + off];
-      }
-#endif
       int mr_n = 0, mr_pre = 0, mr_cnt = 0, mr_env = 0;  // (GAPMAP: the map of row rt + 64 + col between its three steps)
-#if !MPX_V2_GAPMAP
-      shape_a();
-      shape_b();
-#endif
       V2_FENCE();
       // ---- layer 2: Ht = W . Xt, pair A then pair B; MFMA m of a pair = (s, pass, o) = (m / 6, (m % 6) / 2, m % 2) -----
       f32x16 a2[4];
       bf16x8 h2[4][2], l2[4][2];
       a2[0] = bias_tile_lds(bias2_s, 0, half);
       a2[1] = bias_tile_lds(bias2_s, 1, half);
-#if !MPX_V2_GAPMAP
-      a2[2] = bias_tile_lds(bias2_s, 2, half);
-      a2[3] = bias_tile_lds(bias2_s, 3, half);
-#endif
       V2_FENCE();
 #pragma unroll
       for (int m = 0; m < 96; ++m) {
@@ -1281,7 +1241,6 @@ __global__ void __launch_bounds__(64 * v2::WV) __attribute__((amdgpu_waves_per_e
         if (mm % 6 < 4 && n + RD < 16) fetch2_part(n + RD, mm % 6);  // (the ring never holds more than RS = RD + 1 steps)
         a2[2 * pair + o] = mfma_bf16(as_bf(ring[n % RS][2 * o + (pass == 1 ? 1 : 0)]),
                                      pass == 2 ? l1[s >> 1][s & 1] : h1[s >> 1][s & 1], a2[2 * pair + o]);
-#if MPX_V2_SMOOTH
         // pair A's accumulators are final after MFMA 47: their relu + split rides behind pair B's MFMAs, one HALF quantum
         // per gap in two gaps of three; the third kind of gap (no weight fetch: mm % 6 >= 4) carries one load of the
         // next tile's rows, consumed from output pair 1 of layer 3 on
@@ -1290,7 +1249,6 @@ __global__ void __launch_bounds__(64 * v2::WV) __attribute__((amdgpu_waves_per_e
           split_h(a2[q >> 3], h2[q >> 3], l2[q >> 3], q & 7, hh & 1);
         }
         if (pair == 1 && mm % 6 >= 4) gather_part(env_gather, k_gather, (mm / 6) * 2 + (mm % 6 - 4));
-#if MPX_V2_GAPMAP
         // pair A's fetch-free gaps (mm % 6 >= 4; nothing else rides there): the map of the row after next in three
         // steps an LDS round trip apart, the tile's boundary shape (needed from layer 3's second output pair on), pair
         // B's biases
@@ -1307,11 +1265,6 @@ __global__ void __launch_bounds__(64 * v2::WV) __attribute__((amdgpu_waves_per_e
           if (mm == 28) a2[2] = bias_tile_lds(bias2_s, 2, half);
           if (mm == 34) a2[3] = bias_tile_lds(bias2_s, 3, half);
         }
-#endif
-#else
-        // pair A's accumulators are final after MFMA 47: their relu + split rides behind pair B's MFMAs (16 quanta)
-        if (pair == 1 && mm % 3 == 2) split_q(a2[(mm / 3) >> 3], h2[(mm / 3) >> 3], l2[(mm / 3) >> 3], (mm / 3) & 7);
-#endif
         V2_FENCE();
       }
       stamp();
@@ -1347,16 +1300,12 @@ __global__ void __launch_bounds__(64 * v2::WV) __attribute__((amdgpu_waves_per_e
       for (int m = 0; m < 192; ++m) {
         const int pr = m / 48, mm = m % 48, s = mm / 6, pass = (mm % 6) / 2, o = mm % 2, n3 = pr * 8 + s;
         if (mm % 6 < 4 && n3 + 2 < 32) load3_part(n3 + 2, mm % 6);
-#if !MPX_V2_SMOOTH
-        if (m >= 4 && m < 4 + 2 * (C1 / 8) && (m & 1) == 0) gather_part(env_gather, k_gather, (m - 4) >> 1);  // the next tile's rows
-#endif
         {
           const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
           const bf16x8 x = pass == 2 ? l2[s >> 1][s & 1] : h2[s >> 1][s & 1];
           const bf16x8 w = w3r[n3 % 3][2 * o + (pass == 1 ? 1 : 0)];
           a3[pr & 1][o] = mfma_bf16(x, w, (s == 0 && pass == 0) ? zero : a3[pr & 1][o]);
         }
-#if MPX_V2_SMOOTH
         // fillers, one small piece per gap:
         if (pr == 0) {  // pair B's split in half quanta: tile 2 in gaps 0..15 (needed from s = 4), tile 3 in gaps 16..31
           if (mm < 32) split_h(a2[2 + mm / 16], h2[2 + mm / 16], l2[2 + mm / 16], (mm % 16) >> 1, mm & 1);
@@ -1380,25 +1329,10 @@ __global__ void __launch_bounds__(64 * v2::WV) __attribute__((amdgpu_waves_per_e
             form_h(cq_next, hh >> 1, hh & 1);
           }
         }
-#else
-        // fillers, by position in the tile:
-        if (pr == 0) {  // pair B's split: tile 2 behind the first 12 MFMAs (needed from s = 4), tile 3 behind the next 12
-          if (mm < 24 && mm % 3 == 0) split_q(a2[2 + mm / 12], h2[2 + mm / 12], l2[2 + mm / 12], (mm % 12) / 3 * 2);
-          if (mm < 24 && mm % 3 == 1) split_q(a2[2 + mm / 12], h2[2 + mm / 12], l2[2 + mm / 12], (mm % 12) / 3 * 2 + 1);
-        } else {
-          // pooling of the pair before: its two tiles behind MFMAs 0 and 24 of this pair
-          if (mm == 0) pool(pr - 1, 0);
-          if (mm == 24) pool(pr - 1, 1);
-          // the NEXT tile's layer-2 operands: 32 quanta over output pairs 2 and 3 (the rows were requested at the end of
-          // layer 2)
-          if (pr >= 2 && mm % 3 == 1) form_q(cq_next, (pr - 2) * 16 + mm / 3);
-        }
-#endif
         // the first layer-2 stages of the NEXT tile (the weights never change): one block per gap over the last MFMAs
         if (m >= 192 - 4 * RD) fetch2_part((m - (192 - 4 * RD)) >> 2, (m - (192 - 4 * RD)) & 3);
         V2_FENCE();
       }
-#if MPX_V2_SMOOTH
 #pragma unroll
       for (int part = 0; part < 2; ++part) {
 #pragma unroll
@@ -1407,11 +1341,6 @@ __global__ void __launch_bounds__(64 * v2::WV) __attribute__((amdgpu_waves_per_e
       }
       (void)pool;
       cur = gq[7];
-#else
-      pool(3, 0);
-      pool(3, 1);
-      cur = gq[7];
-#endif
       stamp();
       stamp();  // (back to back: the cost of a stamp itself)
       V2_FENCE();
