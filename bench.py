@@ -137,8 +137,8 @@ def cpu_baseline(prob, model, n_env: int):
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 vector peak (64 FLOP / clk / SIMD)
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak at 2.4 GHz
-TRAFFIC_RECORD = "r05_traffic.json"  # written by tools/pmc_traffic.py from the PMC passes of this round
-FAST_RECORD = "r05_fast_traffic.json"  # the same for the bf16x3 kernels (tools/pmc_fast.py)
+TRAFFIC_RECORD = "r06_traffic.json"  # written by tools/pmc_traffic.py from the PMC passes of this round
+FAST_RECORD = "r06_fast_traffic.json"  # the same for the bf16x3 kernels (tools/pmc_fast.py)
 
 # FLOPs per (collision sphere, unmasked primitive) pair, counted from csrc/sdf_device.h (one fma = 2): cuboid =
 # projection 18 + 3 abs-sub + 3 max + 5 (norm) + sqrt + 3 (max3, min) + 2 (add, min-select) = 35; cylinder = 18 + 4 (rho)
@@ -165,7 +165,7 @@ def kernel_source_hash(files=("sa_mlp.hip", "common.h")) -> str:
     return h.hexdigest()
 
 
-FAST_SOURCES = ("sa_mlp_bf16.hip", "dense_bf16.hip", "common.h")
+FAST_SOURCES = ("sa_mlp_bf16.hip", "dense_bf16.hip", "sa3_front_bf16.hip", "common.h")
 
 
 def stage_table(prof, steps, B, sa1_ms, sa1_exec, sa2_ms, sa2_exec, col_flops):
@@ -616,7 +616,7 @@ def main():
                          "unit": "TFLOP/s", "frac": c4_flop / (c4_ms * 1e-3) / 1e12 / (FP32_VALU_PEAK_TFLOPS * n_gpus),
                          "executed_gflop": c4_flop / 1e9,
                          "note": "executed FLOPs: unmasked primitives only (35 per sphere-cuboid, 33 per sphere-cylinder pair, "
-                                 "csrc/sdf_device.h) vs the fp32 VALU peak of all ranks; counters: profiles/r05_collision_pmc_pass*.csv"},
+                                 "csrc/sdf_device.h) vs the fp32 VALU peak of all ranks; counters: profiles/r06_collision_pmc_pass*.csv"},
             "what": "FK + 56-sphere SDF vs 40 cuboids + 16 cylinders (zero-padded), has_collision[B] (model.py:293-314)"}
         extra["c2_fk_sdf_1024"] = {
             "envs": c2_envs, "envs_per_rank": [r["c2_envs"] for r in recs], "ms": c2_ms, "ms_per_rank": [r["c2_ms"] for r in recs],

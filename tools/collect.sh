@@ -1,7 +1,7 @@
 #!/bin/bash
 # gpurun_out/<round>ev/ (tools/evidence.sh <round>) -> profiles/<round>_* (tracked).  usage: bash tools/collect.sh r05
 set -e
-R=${1:-r05}
+R=${1:-r06}
 S=gpurun_out/${R}ev; P=profiles
 tail -1 $S/bench.log > $P/${R}_bench_n1.json
 cp $S/stats_head_kernel_stats.csv $P/${R}_bench_kernel_stats.csv
@@ -21,3 +21,5 @@ cp $S/stats_trainx3_kernel_stats.csv $P/${R}_train_step_bf16x3_kernel_stats.csv
 grep -v amdgpu.ids $S/sa2_bf16_phase_probe.log > $P/${R}_sa2_bf16_phase_probe.log
 cp $S/box.log $P/${R}_box.log
 ls -la $P/${R}_* | awk '{print $5, $9}'
+grep -v amdgpu.ids $S/sa3_front_timing.log > $P/${R}_sa3_front_timing.log
+cp $S/mfma_power_probe.log $P/${R}_mfma_power_probe.log

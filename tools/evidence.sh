@@ -2,7 +2,7 @@
 # Evidence run of a round (one MI355X): GPU tests, bench line (+ whole configs[4] extra), kernel stats, PMC passes of the
 # fp32 headline and of the bf16x3 mode, collision counters.  usage (on the box): bash tools/evidence.sh r05 [notests]
 # Everything lands in gpurun_out/<round>ev/; tools/collect.sh <round> copies the summaries into profiles/.
-R=${1:-r05}
+R=${1:-r06}
 mkdir -p gpurun_out/${R}ev
 export PYTHONUNBUFFERED=1
 REPO=$(pwd); O=$REPO/gpurun_out/${R}ev
@@ -51,3 +51,6 @@ python tools/train_timing.py 256 5 bf16x3 >> $O/train_256.log 2>&1
 stats trainx3 tools/train_timing.py 256 5 bf16x3
 python tools/probes/sa2_bf16_phase_probe.py > $O/sa2_bf16_phase_probe.log 2>&1
 echo done
+python tools/sa3_front_timing.py 8192 5 > $O/sa3_front_timing.log 2>&1
+( hipcc --offload-arch=gfx950 -O3 -o /tmp/mfma_pw tools/probes/mfma_power_probe.hip > /dev/null 2>&1 && /tmp/mfma_pw ) > $O/mfma_power_probe.log 2>&1
+echo done2

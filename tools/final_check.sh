@@ -1,6 +1,6 @@
 #!/bin/bash
-# final check of the tree: GPU suite, smoke, training-step timings + kernel stats (profiles/r05_train_step*)
-mkdir -p gpurun_out/r05ev; O=$(pwd)/gpurun_out/r05ev; export PYTHONUNBUFFERED=1; REPO=$(pwd)
+# final check of the tree: GPU suite, smoke, training-step timings + kernel stats (profiles/r06_train_step*)
+mkdir -p gpurun_out/r06ev; O=$(pwd)/gpurun_out/r06ev; export PYTHONUNBUFFERED=1; REPO=$(pwd)
 timeout 1800 python -m pytest tests -m gpu -q -rA --tb=short -p no:cacheprovider > $O/pytest_gpu.log 2>&1
 echo "pytest exit: $?" >> $O/pytest_gpu.log; tail -3 $O/pytest_gpu.log | cut -c1-200
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1

@@ -19,7 +19,7 @@ from bench import FAST_SOURCES, kernel_source_hash  # noqa: E402
 KERNELS = {"sa2_bf16x3_persistent_kernel": "sa2_bf16x3_persistent_kernel",
            "sa_mlp_bf16_resident_kernel": "sa_mlp_bf16_resident_kernel<1, 64, 64, 64, 16, true>",
            "linear_bf16x3_pairs_kernel<3>": "linear_bf16x3_pairs_kernel<3>",   # 512 -> 1024 + pooling, pairs in / pairs out
-           "linear_bf16x3_pairs_kernel<1>": "linear_bf16x3_pairs_kernel<1>"}   # 512 -> 512, pairs in / pairs out
+           "sa3_front_bf16x3_kernel": "sa3_front_bf16x3_kernel<false>"}       # 272 -> 512 -> 512 fused, fp32 rows in / pairs out
 d, envs, out = sys.argv[1], int(sys.argv[2]), sys.argv[3]
 
 
