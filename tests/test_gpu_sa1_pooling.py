@@ -22,7 +22,7 @@ def test_lds_pooling_equals_register_merge_and_all_slots(B, kinds):
     dev = torch.device("cuda:0")
     torch.manual_seed(3)
     sa = PointnetSAModule(npoint=512, radius=0.05, nsample=128, mlp=[1, 64, 64, 64], bn=False).to(dev)
-    prob = make_problem_batch(B, seed=17 + B, device=dev, kinds=kinds, device_clouds=True)
+    prob = make_problem_batch(B, seed=17 + B, device=dev, kinds=kinds, device_clouds=True, scene_pool=64)
     pc = prob["xyz"]
     # one dense cluster so that some neighbourhoods are FULL (128 of 128 slots, several tiles of one query)
     pc[0, 2048:2048 + 600, :3] = pc[0, 2048, :3] + 0.01 * torch.rand(600, 3, device=dev)
