@@ -8,7 +8,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import kernel_source_hash  # noqa: E402  (stamps the record: bench.py drops it when the kernel source changes)
 
-KERNEL = "sa_mlp_packed_kernel<64, 128, 128, 256, 8, true>"
+KERNEL = "sa_mlp_packed_kernel<64, 128, 128, 256, 8, true"  # (prefix: the row-map size is a further template argument since round 6)
 d, envs, out = sys.argv[1], int(sys.argv[2]), sys.argv[3]
 
 

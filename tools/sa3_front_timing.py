@@ -58,11 +58,12 @@ if B > 300:
     n = int((tt[:8] != 0).sum())
     print("deltas of workgroup 300:", [int(tt[i + 1] - tt[i]) for i in range(n - 1)])
     w = tt[64:].reshape(B, 4)
+    w = w[w[:, 0] > 0]  # (rows of workgroups that did not report are zero)
     t0 = w[:, 0].min()
     start, end = w[:, 0] - t0, w[:, 1] - t0
     dur = end - start
     cu = (w[:, 3] & 0xf) * 10000 + ((w[:, 2] >> 13) & 7) * 1000 + ((w[:, 2] >> 12) & 1) * 100 + ((w[:, 2] >> 8) & 15)
-    print("workgroups:", B, "distinct (xcc, se, sh, cu):", len(set(cu.tolist())), "kernel span (ticks):", int(end.max()),
+    print("workgroups:", len(w), "distinct (xcc, se, sh, cu):", len(set(cu.tolist())), "kernel span (ticks):", int(end.max()),
           "duration min / median / max:", int(dur.min()), int(np.median(dur)), int(dur.max()))
     gaps, busy = [], []
     for c in sorted(set(cu.tolist())):
@@ -72,5 +73,5 @@ if B > 300:
         gaps += list(s_[1:] - e_[:-1])
         busy.append(dur[m].sum() / end.max())
     gaps = np.array(gaps)
-    print("per-CU: workgroups", B / len(set(cu.tolist())), "busy fraction min / median / max: %.2f %.2f %.2f" % (min(busy), float(np.median(busy)), max(busy)),
+    print("per-CU: workgroups", len(w) / len(set(cu.tolist())), "busy fraction min / median / max: %.2f %.2f %.2f" % (min(busy), float(np.median(busy)), max(busy)),
           "gap between consecutive workgroups of a CU min / median / max:", int(gaps.min()), int(np.median(gaps)), int(gaps.max()))
