@@ -63,15 +63,13 @@ if B > 300:
     start, end = w[:, 0] - t0, w[:, 1] - t0
     dur = end - start
     cu = (w[:, 3] & 0xf) * 10000 + ((w[:, 2] >> 13) & 7) * 1000 + ((w[:, 2] >> 12) & 1) * 100 + ((w[:, 2] >> 8) & 15)
-    print("workgroups:", len(w), "distinct (xcc, se, sh, cu):", len(set(cu.tolist())), "kernel span (ticks):", int(end.max()),
-          "duration min / median / max:", int(dur.min()), int(np.median(dur)), int(dur.max()))
-    gaps, busy = [], []
+    print("workgroups:", len(w), "distinct (xcc, se, sh, cu):", len(set(cu.tolist())),
+          "ticks per workgroup min / median / max:", int(dur.min()), int(np.median(dur)), int(dur.max()))
+    gaps = []  # (s_memtime bases differ between XCDs: only differences inside one CU mean anything)
     for c in sorted(set(cu.tolist())):
         m = cu == c
         o = np.argsort(start[m])
-        s_, e_ = start[m][o], end[m][o]
-        gaps += list(s_[1:] - e_[:-1])
-        busy.append(dur[m].sum() / end.max())
+        gaps += list(start[m][o][1:] - end[m][o][:-1])
     gaps = np.array(gaps)
-    print("per-CU: workgroups", len(w) / len(set(cu.tolist())), "busy fraction min / median / max: %.2f %.2f %.2f" % (min(busy), float(np.median(busy)), max(busy)),
-          "gap between consecutive workgroups of a CU min / median / max:", int(gaps.min()), int(np.median(gaps)), int(gaps.max()))
+    print("workgroups per CU", len(w) / len(set(cu.tolist())), "gap between consecutive workgroups of a CU min / median / max:",
+          int(gaps.min()), int(np.median(gaps)), int(gaps.max()))
