@@ -29,7 +29,8 @@ typedef void *mpx_stream_t;
 
 #define MPX_NUM_FRAMES 15 /* link0..8, hand, leftfinger, rightfinger, l/r fingertip, right_gripper */
 
-int mpx_version(void); /* 330: mpx_sa3_front_bf16x3 / _pack / _pack_size / _w3_pairs (additions), the measurement hooks mpx_sa3_chain_probe / mpx_sa2_bf16x3_set_probe /
+int mpx_version(void); /* 340: mpx_pool_wgrad / mpx_pool_wgrad_scratch / mpx_pool_dgrad (additions only);
+                          330: mpx_sa3_front_bf16x3 / _pack / _pack_size / _w3_pairs (additions), the measurement hooks mpx_sa3_chain_probe / mpx_sa2_bf16x3_set_probe /
                           mpx_sa3_front_bf16x3_probe declared, mpx_sa_mlp_bf16x3_factored refuses nsample > 128;
                           320: mpx_linear_dact, mpx_segment_max_grad_act, mpx_linear_bf16x3_dact, mpx_linear_wgrad_bf16x3 (additions only); mpx_franka_collision accepts
                           frame pointers that are not 16-byte aligned;
@@ -256,6 +257,23 @@ int mpx_segment_max_grad(const float *grad_out, int grad_stride, const int64_t *
 int mpx_segment_max_grad_act(const float *grad_out, int grad_stride, const int64_t *arg, const float *out,
                              int out_stride, const int64_t *offsets, int64_t Q, int C, int act, float *grad_y,
                              mpx_stream_t stream);
+/* Backward of [dense layer (W [C,K], b) + activation `act` + segment max-pool] that never forms the [R, C] gradient in
+ * front of the pool: per (query, channel) only the arg-max row carries gz[q,c] = grad_out[q,c] * act'(out[q,c]) (out = the
+ * pooled rows).  x [R, >= K] = the layer's INPUT rows (ldx floats apart), arg = mpx_segment_max's (global row numbers).
+ *   mpx_pool_wgrad: dw[c,k] = sum_q gz[q,c] * x[arg[q,c], k], db[c] = sum_q gz[q,c]  (db NULL or == dw + C*K: one fixed-order
+ *                   reduction over the query splits; scratch = mpx_pool_wgrad_scratch(Q, C, K) floats);
+ *   mpx_pool_dgrad: gx[r,k] = below'(x[r,k]) * sum_{c: arg[q,c] == r} gz[q,c] * w[c,k] for EVERY row r of every segment (no
+ *                   zero fill needed; `below` = activation code of the layer that produced x, 0 = none; max_rows = the
+ *                   longest segment the caller expects (a hint, any value works); C <= 65535).
+ * fp32 FMAs in a fixed order: deterministic; the same sums as mpx_segment_max_grad_act + mpx_linear_wgrad / mpx_linear_dact
+ * in another summation order.  (Reference: the autograd of pointnet2_ops' QueryAndGroup + max_pool2d, model.py:366-383.) */
+int64_t mpx_pool_wgrad_scratch(int64_t Q, int C, int K);
+int mpx_pool_wgrad(const float *grad_out, int grad_stride, const int64_t *arg, const float *out, int out_stride,
+                   int64_t Q, int C, int act, const float *x, int ldx, int K, float *dw, float *db, float *scratch,
+                   mpx_stream_t stream);
+int mpx_pool_dgrad(const float *grad_out, int grad_stride, const int64_t *arg, const float *out, int out_stride,
+                   const int64_t *offsets, int64_t Q, int C, int act, const float *w, int ldw, const float *x, int ldx,
+                   int below, int K, int max_rows, float *gx, int ldg, mpx_stream_t stream);
 
 /* ---- batch assembly from the dataset arrays (row N2; mpinets/data_loader.py:141-280, 390-417) ------- */
 

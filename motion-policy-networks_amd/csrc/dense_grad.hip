@@ -138,6 +138,11 @@ __global__ void __launch_bounds__(256)
   if (i < n && l == 0) out[i] = acc;
 }
 
+// (train_ops.hip: the sparse pool backward adds its splits through the same kernel)
+void mpx_reduce_partials_launch(const float *partial, int S, int64_t stride, int64_t n, float *out, hipStream_t stream) {
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(n * 16, 256)), dim3(256), 0, stream, partial, S, stride, n, out);
+}
+
 // dz = dy * act'(y): ReLU -> y > 0; LeakyReLU(0.01) -> y >= 0 ? 1 : 0.01 (sign of the output = sign of the input)
 __global__ void __launch_bounds__(256)
     act_backward_kernel(const float *dy, const float *__restrict__ y, int64_t n, int act,  // (dy may be dz: in place)

@@ -43,6 +43,9 @@ PROTOTYPES = {
     "mpx_segment_max": [P, I, P, L, P, I, P, P],
     "mpx_segment_max_grad": [P, I, P, L, I, P, P],
     "mpx_segment_max_grad_act": [P, I, P, P, I, P, L, I, I, P, P],
+    "mpx_pool_wgrad_scratch": [L, I, I],
+    "mpx_pool_wgrad": [P, I, P, P, I, L, I, I, P, I, I, P, P, P, P],
+    "mpx_pool_dgrad": [P, I, P, P, I, P, L, I, I, P, I, P, I, I, I, I, P, I, P],
     "mpx_batch_configs": [P, L, I, P, P, P, F, ctypes.c_uint64, L, I, I, F, P, P, P, P, P, P],
     "mpx_gather_rows": [P, P, I, I, P, P],
     "mpx_depth_render": [P, F, F, F, F, I, I, I, P, P, I, P, P, P, I, P, P, I, F, P, P],
@@ -103,7 +106,7 @@ PROTOTYPES = {
     "mpx_rollout": [P, P, P, P, I, P, P, I, P, P, P, L, P],
 }
 RESTYPES = {"mpx_last_error": c_char_p, "mpx_sa_pack_size": c_int64, "mpx_sa3_front_bf16x3_pack_size": c_int64, "mpx_sa_pack_bf16x3_size": c_int64,
-            "mpx_linear_wgrad_scratch": c_int64, "mpx_linear_workspace": c_int64, "mpx_policy_workspace": c_int64, "mpx_rollout_workspace": c_int64}
+            "mpx_linear_wgrad_scratch": c_int64, "mpx_pool_wgrad_scratch": c_int64, "mpx_linear_workspace": c_int64, "mpx_policy_workspace": c_int64, "mpx_rollout_workspace": c_int64}
 
 _lib: Optional[ctypes.CDLL] = None
 

@@ -216,8 +216,10 @@ class MPiNetsPointNet(nn.Module):
         f2 = sa_module_train(sa2.convs(), xyz1, 3, xyz2, 3, f1, f1.size(2), f1.size(2), nbr2, cnt2,
                              (B, sa1.npoint, sa2.npoint, sa2.nsample), tp)
         h = torch.cat((xyz2, f2), dim=2)  # group-all: absolute coordinates | features
-        h = mlp_chain_train(h, [(c.weight.view(c.out_channels, -1), c.bias) for c in sa3.convs()], [ACT_RELU] * 3, precision=tp)
-        pooled = h.max(dim=1).values
+        # (one segment per environment: the pool and its backward are the grouped modules' kernels)
+        seg = torch.arange(B + 1, dtype=torch.int64, device=dev) * sa2.npoint
+        pooled = mlp_chain_train(h.view(B * sa2.npoint, -1), [(c.weight.view(c.out_channels, -1), c.bias) for c in sa3.convs()],
+                                 [ACT_RELU] * 3, offsets=seg, precision=tp, offsets_checked=True)
         self.last_counts = (cnt1, cnt2)
         if aux is not None:
             aux.update(fps_idx1=idx1, xyz1=xyz1, ball_idx1=nbr1, ball_cnt1=cnt1, f1=f1, fps_idx2=idx2, ball_idx2=nbr2,

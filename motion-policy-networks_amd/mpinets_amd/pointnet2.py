@@ -153,6 +153,10 @@ def groupnorm_leaky(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, g
 
 
 PRECISIONS = ("fp32", "bf16x3")
+# training: the backward of [last dense layer + ReLU + max-pool] walks the pool's Q * C non-zero gradients
+# (mpx_pool_wgrad / mpx_pool_dgrad) instead of forming the [rows, C] gradient and running two dense GEMMs over its zeros;
+# False = the dense route (mpx_segment_max_grad_act + mpx_linear_wgrad / mpx_linear_dact), kept for A/B tests
+SPARSE_POOL_BACKWARD = True
 
 
 class SAWeights:
@@ -490,6 +494,8 @@ class _MLPChainFn(torch.autograd.Function):
         else:
             ctx.save_for_backward(*xs, *ws, h)
         ctx.meta = (tuple(acts), tuple(meta), M, K0, offsets is not None, bool(x3))
+        # LDS window of mpx_pool_dgrad (a hint: longer segments take more passes): twice the mean segment, 32 .. 128 rows
+        ctx.max_rows = 128 if offsets is None else min(128, max(32, -(-2 * M // max(offsets.numel() - 1, 1) // 16) * 16))
         return pooled if offsets is not None else h
 
     @staticmethod
@@ -501,7 +507,35 @@ class _MLPChainFn(torch.autograd.Function):
         g = _lib.f32c(g)
         dev = g.device
         N_last = meta[-1][0]
-        if pooled_out:
+        grads = [None] * (2 * L)
+        top = L - 1  # the layers [0, top] go through the dense GEMMs below
+        if pooled_out and SPARSE_POOL_BACKWARD:
+            # the pool hands each (query, channel) gradient to ONE row: the last layer's two products walk those Q * C
+            # non-zeros instead of an [M, C] matrix of zeros (never written, never read: mpx_pool_wgrad / mpx_pool_dgrad)
+            pooled, arg, offsets = saved[2 * L], saved[2 * L + 1], saved[2 * L + 2]
+            Q, C = pooled.shape
+            N, K, has_bias = meta[top]
+            Kp = ws[top].size(1)
+            assert C == N and ws[top].size(0) == N
+            lib = _lib.load()
+            if ctx.needs_input_grad[4 + 2 * top] or (has_bias and ctx.needs_input_grad[5 + 2 * top]):
+                both = torch.empty(N * Kp + N, dtype=torch.float32, device=dev)  # dw | db: one reduction launch
+                scratch = torch.empty(lib.mpx_pool_wgrad_scratch(Q, N, Kp), dtype=torch.float32, device=dev)
+                _lib.call("mpx_pool_wgrad", _lib.ptr(g), g.stride(0), _lib.ptr(arg), _lib.ptr(pooled), C, Q, N, acts[top],
+                          _lib.ptr(xs[top]), xs[top].stride(0), Kp, _lib.ptr(both), _lib.ptr(both[N * Kp:]),
+                          _lib.ptr(scratch))
+                grads[2 * top] = both[:N * Kp].view(N, Kp)[:, :K]
+                grads[2 * top + 1] = both[N * Kp:] if has_bias else None
+            if top > 0 or ctx.needs_input_grad[0]:
+                below = acts[top - 1] if top > 0 else 0
+                dz = torch.empty((M, Kp), dtype=torch.float32, device=dev)  # (every row is written: the segments tile [0, M))
+                _lib.call("mpx_pool_dgrad", _lib.ptr(g), g.stride(0), _lib.ptr(arg), _lib.ptr(pooled), C, _lib.ptr(offsets),
+                          Q, N, acts[top], _lib.ptr(ws[top]), Kp, _lib.ptr(xs[top]) if below else None, xs[top].stride(0),
+                          below, Kp, ctx.max_rows, _lib.ptr(dz), Kp)
+            else:
+                dz = None
+            top -= 1
+        elif pooled_out:
             pooled, arg, offsets = saved[2 * L], saved[2 * L + 1], saved[2 * L + 2]
             Q, C = pooled.shape
             dz = torch.empty((M, C), dtype=torch.float32, device=dev)  # (every row is written: the segments tile [0, M))
@@ -514,8 +548,7 @@ class _MLPChainFn(torch.autograd.Function):
                 _lib.call("mpx_act_backward", _lib.ptr(g), _lib.ptr(y_last), g.numel(), acts[-1], _lib.ptr(dz))
             else:
                 dz = g
-        grads = [None] * (2 * L)
-        for i in range(L - 1, -1, -1):
+        for i in range(top, -1, -1):
             N, K, has_bias = meta[i]
             Np, Kp = (N + 3) // 4 * 4, ws[i].size(1)
             dz = _pad4(dz) if dz.size(1) != Np else dz

@@ -60,7 +60,7 @@ def test_library_loads_and_reports_errors_without_gpu():
     from mpinets_amd import _lib
 
     lib = _lib.load()
-    assert lib.mpx_version() == 330
+    assert lib.mpx_version() == 340
     assert lib.mpx_sa_pack_size(1, 64, 64, 64) == (4 + 64 + 64) * 64 + 3 * 64
     assert lib.mpx_sa_pack_size(64, 128, 128, 256) == (136 + 256 + 512) * 64 + 128 + 128 + 256
     assert lib.mpx_sa_pack_size(5, 8, 8, 8) == -1

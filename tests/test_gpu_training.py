@@ -173,15 +173,21 @@ def test_linear_train_matches_torch_autograd():
     assert torch.equal(outs[0], outs[1])
 
 
-@pytest.mark.parametrize("pooled", [False, True])
-def test_mlp_chain_is_the_per_layer_backward_without_the_activation_passes(pooled):
+@pytest.mark.parametrize("pooled", [False, True, "sparse"])
+def test_mlp_chain_is_the_per_layer_backward_without_the_activation_passes(pooled, monkeypatch):
     """``mlp_chain_train`` (one autograd node for a stack of dense layers; the activation's elementwise backward rides in
     the input-gradient GEMM's epilogue, mpx_linear_dact, or in the max-pool's backward, mpx_segment_max_grad_act) vs the
     per-layer nodes (``linear_train`` + ``_SegmentMax``): the same kernels' arithmetic per element -- gradients equal bit
     for bit at sizes where both take the 128 x 128 tile GEMM -- and vs torch autograd in float64.
     Widths as in the set-abstraction modules (67 -> 128 -> 128 -> 256; a 7-wide output for the decoder's shape)."""
+    from mpinets_amd import pointnet2
     from mpinets_amd.pointnet2 import _SegmentMax, linear_train, mlp_chain_train
 
+    # "sparse" (the default route): the pooled stack's last layer goes through mpx_pool_wgrad / mpx_pool_dgrad -- the same
+    # sums in another order, so that case is held to the float64 reference only; True = the dense route (bit-equal)
+    sparse = pooled == "sparse"
+    pooled = bool(pooled)
+    monkeypatch.setattr(pointnet2, "SPARSE_POOL_BACKWARD", sparse)
     rng = np.random.default_rng(3)
     M = 3000
     widths, acts = ((67, 128, 128, 256), (1, 1, 1)) if pooled else ((132, 512, 64, 7), (2, 2, 0))
@@ -216,7 +222,10 @@ def test_mlp_chain_is_the_per_layer_backward_without_the_activation_passes(poole
     y_l, g_l = run("layers")
     assert torch.equal(y_c, y_l)
     for a, b_ in zip(g_c, g_l):
-        assert torch.equal(a, b_)
+        if sparse:
+            assert (a - b_).abs().max() <= 2e-5 * max(b_.abs().max().item(), 1e-6) * np.sqrt(M / 64)
+        else:
+            assert torch.equal(a, b_)
     # float64 reference
     xd = x0.double().requires_grad_(True)
     wd = [t.double().requires_grad_(True) for t in ws]
@@ -235,6 +244,58 @@ def test_mlp_chain_is_the_per_layer_backward_without_the_activation_passes(poole
     w = [t.clone().requires_grad_(True) for t in ws]
     mlp_chain_train(xn, [(w[i], None) for i in range(3)], acts, offsets=offsets).sum().backward()
     assert all(t.grad is not None and torch.isfinite(t.grad).all() for t in w)
+
+
+@pytest.mark.parametrize("Q,C,K,act,below,win", [(37, 256, 128, 1, 1, 128), (64, 64, 64, 1, 1, 16), (5, 1024, 512, 1, 1, 128),
+                                                  (50, 96, 68, 2, 2, 32), (33, 70, 20, 0, 0, 128), (9, 130, 132, 1, 0, 16)])
+def test_sparse_pool_backward_kernels_match_float64(Q, C, K, act, below, win):
+    """mpx_pool_wgrad / mpx_pool_dgrad (the backward of [dense layer + activation + segment max-pool] over the pool's
+    Q * C non-zero gradients) vs the dense definition in float64: segments of 1..200 rows and one of 600 (more than the
+    input-gradient kernel's 256-row window: several passes), channel / column counts that are not multiples of 64, every activation code, dead channels
+    (pooled value <= 0 under ReLU), several channels sharing one arg-max row, rows that receive no gradient at all."""
+    from mpinets_amd import _lib
+
+    rng = np.random.default_rng(Q * 1000 + C)
+    lens = rng.integers(1, 200 if Q < 40 else 30, size=Q)
+    lens[1] = 600  # more rows than one window of the input-gradient kernel (256)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    R = int(off[-1])
+    T = lambda a, dt=torch.float32: torch.tensor(a, dtype=dt, device=dev())
+    x = rng.normal(size=(R, K)).astype(np.float32)
+    w = (rng.normal(size=(C, K)) / np.sqrt(K)).astype(np.float32)
+    pooled = rng.normal(size=(Q, C)).astype(np.float32)  # the activation's output at the arg-max (sign decides act')
+    g = rng.normal(size=(Q, C)).astype(np.float32)
+    arg = np.stack([off[q] + rng.integers(0, lens[q], size=C) for q in range(Q)]).astype(np.int64)
+    arg[0, : C // 2] = off[0]  # half of the first query's channels share one row
+    d = lambda o, a: np.ones_like(o) if a == 0 else ((o > 0).astype(np.float64) if a == 1 else np.where(o >= 0, 1.0, 0.01))
+    gz = g.astype(np.float64) * d(pooled.astype(np.float64), act)
+    dz = np.zeros((R, C))
+    for q in range(Q):
+        dz[arg[q], np.arange(C)] += gz[q]
+    dw_ref, db_ref = dz.T @ x.astype(np.float64), dz.sum(0)
+    gx_ref = (dz @ w.astype(np.float64)) * d(x.astype(np.float64), below)
+
+    lib = _lib.load()
+    xd, wd, pd, gd, ad, od = T(x), T(w), T(pooled), T(g), T(arg, torch.int64), T(off, torch.int64)
+    both = torch.full((C * K + C,), float("nan"), device=dev())
+    scratch = torch.empty(lib.mpx_pool_wgrad_scratch(Q, C, K), dtype=torch.float32, device=dev())
+    _lib.call("mpx_pool_wgrad", _lib.ptr(gd), C, _lib.ptr(ad), _lib.ptr(pd), C, Q, C, act, _lib.ptr(xd), K, K, _lib.ptr(both),
+              _lib.ptr(both[C * K:]), _lib.ptr(scratch))
+    gx = torch.full((R, K), float("nan"), device=dev())
+    _lib.call("mpx_pool_dgrad", _lib.ptr(gd), C, _lib.ptr(ad), _lib.ptr(pd), C, _lib.ptr(od), Q, C, act, _lib.ptr(wd), K,
+              _lib.ptr(xd) if below else None, K, below, K, win, _lib.ptr(gx), K)
+    torch.cuda.synchronize()
+    tol = lambda ref: 2e-6 * max(np.abs(ref).max(), 1e-6) * np.sqrt(max(Q, 64) / 64)
+    dw, db = both[:C * K].view(C, K).cpu().numpy().astype(np.float64), both[C * K:].cpu().numpy().astype(np.float64)
+    assert np.abs(dw - dw_ref).max() <= tol(dw_ref) and np.abs(db - db_ref).max() <= tol(db_ref)
+    assert np.abs(gx.cpu().numpy().astype(np.float64) - gx_ref).max() <= tol(gx_ref)
+    # a second run gives the same bits (fixed summation order)
+    both2, gx2 = torch.empty_like(both), torch.empty_like(gx)
+    _lib.call("mpx_pool_wgrad", _lib.ptr(gd), C, _lib.ptr(ad), _lib.ptr(pd), C, Q, C, act, _lib.ptr(xd), K, K, _lib.ptr(both2),
+              _lib.ptr(both2[C * K:]), _lib.ptr(scratch))
+    _lib.call("mpx_pool_dgrad", _lib.ptr(gd), C, _lib.ptr(ad), _lib.ptr(pd), C, _lib.ptr(od), Q, C, act, _lib.ptr(wd), K,
+              _lib.ptr(xd) if below else None, K, below, K, win, _lib.ptr(gx2), K)
+    assert torch.equal(both, both2) and torch.equal(gx, gx2)
 
 
 def test_split_bf16_training_gemms_match_float64():
