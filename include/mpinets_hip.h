@@ -29,7 +29,7 @@ typedef void *mpx_stream_t;
 
 #define MPX_NUM_FRAMES 15 /* link0..8, hand, leftfinger, rightfinger, l/r fingertip, right_gripper */
 
-int mpx_version(void); /* 340: mpx_pool_wgrad / mpx_pool_wgrad_scratch / mpx_pool_dgrad (additions only);
+int mpx_version(void); /* 340: mpx_pool_wgrad / mpx_pool_wgrad_scratch / mpx_pool_dgrad, mpx_linear_segmax / mpx_linear_segmax_bf16x3 (additions only);
                           330: mpx_sa3_front_bf16x3 / _pack / _pack_size / _w3_pairs (additions), the measurement hooks mpx_sa3_chain_probe / mpx_sa2_bf16x3_set_probe /
                           mpx_sa3_front_bf16x3_probe declared, mpx_sa_mlp_bf16x3_factored refuses nsample > 128;
                           320: mpx_linear_dact, mpx_segment_max_grad_act, mpx_linear_bf16x3_dact, mpx_linear_wgrad_bf16x3 (additions only); mpx_franka_collision accepts
@@ -256,6 +256,17 @@ int mpx_segment_max_grad(const float *grad_out, int grad_stride, const int64_t *
  * EVERY row r of segment q -- grad_y needs no zero fill                                                         */
 int mpx_segment_max_grad_act(const float *grad_out, int grad_stride, const int64_t *arg, const float *out,
                              int out_stride, const int64_t *offsets, int64_t Q, int C, int act, float *grad_y,
+                             mpx_stream_t stream);
+/* Forward of [dense layer + activation + segment max-pool] without the [M, N] matrix in memory: pooled[q, n] = max over the
+ * rows r with seg[r] == q of act(x[r] . w[n] + bias[n]), arg[q, n] = the first such row -- mpx_linear followed by
+ * mpx_segment_max, bit for bit (the same tile kernel; its epilogue folds the tile into 64-bit {value, ~row} keys with
+ * atomicMax).  seg int32 [M]: the segment of every row, non-decreasing, every q in [0, Q) present; keys: Q*N*8 bytes of
+ * scratch (8-byte aligned); pooled [Q, >= N] (ldp floats apart), arg int64 [Q, N].  _bf16x3: the product in split bf16
+ * (w_pairs from mpx_split_bf16, as mpx_linear_bf16x3).  (Reference: pointnet2_ops' SharedMLP + max_pool2d, model.py:366-383.) */
+int mpx_linear_segmax(const float *x, int ldx, const float *w, const float *bias, int M, int N, int K, int act,
+                      const int32_t *seg, int64_t Q, void *keys, float *pooled, int ldp, int64_t *arg, mpx_stream_t stream);
+int mpx_linear_segmax_bf16x3(const float *x, int ldx, const void *w_pairs, const float *bias, int M, int N, int K, int act,
+                             const int32_t *seg, int64_t Q, void *keys, float *pooled, int ldp, int64_t *arg,
                              mpx_stream_t stream);
 /* Backward of [dense layer (W [C,K], b) + activation `act` + segment max-pool] that never forms the [R, C] gradient in
  * front of the pool: per (query, channel) only the arg-max row carries gz[q,c] = grad_out[q,c] * act'(out[q,c]) (out = the

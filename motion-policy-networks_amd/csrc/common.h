@@ -97,6 +97,56 @@ __device__ __forceinline__ float mpx_sqdist(float dx, float dy, float dz) {
 #endif
 }
 
+// ---- segmented max-pool in a GEMM epilogue (training: the last layer of a grouped MLP + its max-pool, row N1) ----------
+// Rows belong to segments (seg[row], non-decreasing); per (segment, column) the largest activated value and the FIRST row
+// attaining it are kept as one 64-bit key {order-preserving bits of the value, ~row} by atomicMax -- the [rows, columns]
+// matrix never reaches memory.  keys are zeroed by the launcher (0 is below every real key) and unpacked afterwards.
+__device__ __forceinline__ unsigned mpx_ordered_bits(float v) {  // monotone map float -> unsigned
+  const unsigned u = __float_as_uint(v);
+  return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__device__ __forceinline__ float mpx_ordered_float(unsigned u) {
+  return __uint_as_float(u ^ ((u >> 31) ? 0x80000000u : 0xFFFFFFFFu));
+}
+// the 128 x 128 tile kernels' accumulator layout: a lane holds column col_base + 32 j + l31 of rows
+// row_base + 32 i + (r & 3) + 8 (r >> 2) + 4 half, ascending in (i, r).  val(i, j, r) = the activated value.
+template <class F>
+__device__ __forceinline__ void mpx_segpool_tile(F &&val, int row_base, int col_base, int M, int N, int half, int l31,
+                                                 const int32_t *__restrict__ seg, int row0,
+                                                 unsigned long long *__restrict__ keys, int ldk) {
+  int sg[2][16];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = row_base + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      sg[i][r] = row < M ? seg[row] : -1;
+    }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = col_base + j * 32 + l31;
+    if (col >= N) continue;
+    int cs = -1;
+    unsigned long long best = 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int s = sg[i][r];
+        if (s < 0) continue;
+        const unsigned row = (unsigned)(row0 + row_base + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half);
+        const unsigned long long key = ((unsigned long long)mpx_ordered_bits(val(i, j, r)) << 32) | (0xFFFFFFFFu - row);
+        if (s != cs) {
+          if (cs >= 0) atomicMax(keys + (size_t)cs * ldk + col, best);
+          cs = s, best = key;
+        } else {
+          best = key > best ? key : best;
+        }
+      }
+    if (cs >= 0) atomicMax(keys + (size_t)cs * ldk + col, best);
+  }
+}
+
 // Cody-Waite by pi/2 + fixed polynomials; |x| up to ~1e3 rad is far more than joint angles need.
 __device__ __forceinline__ void mpx_sincos(float x, float &s, float &c) {
   const float TWO_OVER_PI = 0.63661977236758134308f;

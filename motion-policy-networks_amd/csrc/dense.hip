@@ -42,7 +42,8 @@ template <int BK, bool POOL, bool DMA>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DMA ? 4 : 3, DMA ? 4 : 3)))
     linear_kernel(const float *__restrict__ x, int ldx, const float *__restrict__ w, int ldw,
                   const float *__restrict__ bias, int M, int N, int K, int act, float *__restrict__ y, int ldy,
-                  int kslice, size_t zstride, const float *__restrict__ dact_of, int lddact, int dact) {
+                  int kslice, size_t zstride, const float *__restrict__ dact_of, int lddact, int dact,
+                  const int32_t *__restrict__ seg, int seg_row0) {
   static_assert(!DMA || BK == 16, "the DMA layout is written for 16-float slabs");
   constexpr int LDT = DMA ? BK : BK + 4;  // padded row (or xor-swizzled chunks): conflict-free 16-byte fragment reads
   constexpr int HK = BK / 2;        // k-values per lane-half per slab
@@ -188,6 +189,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DMA ? 
   }
 
   // epilogue: C[row][col], col = lane&31, row = (r&3) + 8*(r>>2) + 4*half
+  if (POOL && seg != nullptr) {  // max over each SEGMENT of rows (training; y = the 64-bit keys, ldy in keys: common.h)
+    float bvj[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn * 64 + j * 32 + l31;
+      bvj[j] = (bias && col < N) ? bias[col] : 0.0f;
+    }
+    mpx_segpool_tile([&](int i, int j, int r) __attribute__((always_inline)) { return act_apply(acc[i][j][r] + bvj[j], act); },
+                     m0 + wm * 64, n0 + wn * 64, M, N, half, l31, seg, seg_row0, reinterpret_cast<unsigned long long *>(y), ldy);
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int col = n0 + wn * 64 + j * 32 + l31;
@@ -452,10 +464,10 @@ MPX_EXPORT int mpx_linear(const float *x, int ldx, const float *w, const float *
   // 64-cycle fp32 MFMAs four waves per SIMD cover more than the leaner slab does.)
   if (dma_ok(M, N, K, ldx, K))
     hipLaunchKernelGGL((linear_kernel<16, false, true>), dim3(cdiv(N, BN), cdiv(M, BM)), dim3(256), 0, mpx_s(stream), x,
-                       ldx, w, K, bias, M, N, K, act, y, ldy, K, (size_t)0, static_cast<const float *>(nullptr), 0, 0);
+                       ldx, w, K, bias, M, N, K, act, y, ldy, K, (size_t)0, static_cast<const float *>(nullptr), 0, 0, static_cast<const int32_t *>(nullptr), 0);
   else
     hipLaunchKernelGGL((linear_kernel<16, false, false>), dim3(cdiv(N, BN), cdiv(M, BM)), dim3(256), 0, mpx_s(stream), x,
-                       ldx, w, K, bias, M, N, K, act, y, ldy, K, (size_t)0, static_cast<const float *>(nullptr), 0, 0);
+                       ldx, w, K, bias, M, N, K, act, y, ldy, K, (size_t)0, static_cast<const float *>(nullptr), 0, 0, static_cast<const int32_t *>(nullptr), 0);
   MPX_LAUNCH_CHECK("mpx_linear");
 }
 
@@ -483,11 +495,11 @@ MPX_EXPORT int mpx_linear_dact(const float *x, int ldx, const float *w, int M, i
   if (dma_ok(M, N, K, ldx, K))
     hipLaunchKernelGGL((linear_kernel<16, false, true>), dim3(cdiv(N, BN), cdiv(M, BM)), dim3(256), 0, mpx_s(stream), x,
                        ldx, w, K, static_cast<const float *>(nullptr), M, N, K, MPX_ACT_NONE, y, ldy, K, (size_t)0, dact_of,
-                       lddact, dact);
+                       lddact, dact, static_cast<const int32_t *>(nullptr), 0);
   else
     hipLaunchKernelGGL((linear_kernel<16, false, false>), dim3(cdiv(N, BN), cdiv(M, BM)), dim3(256), 0, mpx_s(stream), x,
                        ldx, w, K, static_cast<const float *>(nullptr), M, N, K, MPX_ACT_NONE, y, ldy, K, (size_t)0, dact_of,
-                       lddact, dact);
+                       lddact, dact, static_cast<const int32_t *>(nullptr), 0);
   MPX_LAUNCH_CHECK("mpx_linear_dact");
 }
 
@@ -547,10 +559,10 @@ MPX_EXPORT int mpx_linear_ws(const float *x, int ldx, const float *w, const floa
   const size_t zstride = (size_t)M * N;
   if (dma_ok(M, N, K, ldx, K))  // (slices are multiples of the slab, so every slice keeps whole slabs too)
     hipLaunchKernelGGL((linear_kernel<16, false, true>), dim3(cdiv(N, BN), cdiv(M, BM), S), dim3(256), 0, mpx_s(stream), x,
-                       ldx, w, K, static_cast<const float *>(nullptr), M, N, K, MPX_ACT_NONE, part, N, kslice, zstride, static_cast<const float *>(nullptr), 0, 0);
+                       ldx, w, K, static_cast<const float *>(nullptr), M, N, K, MPX_ACT_NONE, part, N, kslice, zstride, static_cast<const float *>(nullptr), 0, 0, static_cast<const int32_t *>(nullptr), 0);
   else
     hipLaunchKernelGGL((linear_kernel<16, false, false>), dim3(cdiv(N, BN), cdiv(M, BM), S), dim3(256), 0, mpx_s(stream), x,
-                       ldx, w, K, static_cast<const float *>(nullptr), M, N, K, MPX_ACT_NONE, part, N, kslice, zstride, static_cast<const float *>(nullptr), 0, 0);
+                       ldx, w, K, static_cast<const float *>(nullptr), M, N, K, MPX_ACT_NONE, part, N, kslice, zstride, static_cast<const float *>(nullptr), 0, 0, static_cast<const int32_t *>(nullptr), 0);
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv((int64_t)M * N, 256)), dim3(256), 0, mpx_s(stream), part, S,
                      zstride, bias, M, N, act, y, ldy);
   MPX_LAUNCH_CHECK("mpx_linear_ws");
@@ -576,11 +588,72 @@ MPX_EXPORT int mpx_linear_rowmax(const float *x, int ldx, const float *w, const 
   MPX_REQUIRE(e == hipSuccess, "mpx_linear_rowmax: memset failed: %s", hipGetErrorString(e));
   if (dma_ok(M, N, K, ldx, K))
     hipLaunchKernelGGL((linear_kernel<16, true, true>), dim3(cdiv(N, BN), M / BM), dim3(256), 0, mpx_s(stream), x, ldx, w,
-                       K, bias, M, N, K, MPX_ACT_RELU, y, ldy, K, (size_t)0, static_cast<const float *>(nullptr), 0, 0);
+                       K, bias, M, N, K, MPX_ACT_RELU, y, ldy, K, (size_t)0, static_cast<const float *>(nullptr), 0, 0, static_cast<const int32_t *>(nullptr), 0);
   else
     hipLaunchKernelGGL((linear_kernel<16, true, false>), dim3(cdiv(N, BN), M / BM), dim3(256), 0, mpx_s(stream), x, ldx, w,
-                       K, bias, M, N, K, MPX_ACT_RELU, y, ldy, K, (size_t)0, static_cast<const float *>(nullptr), 0, 0);
+                       K, bias, M, N, K, MPX_ACT_RELU, y, ldy, K, (size_t)0, static_cast<const float *>(nullptr), 0, 0, static_cast<const int32_t *>(nullptr), 0);
   MPX_LAUNCH_CHECK("mpx_linear_rowmax");
+}
+
+// ---- last layer of a grouped MLP + activation + max over each query's rows (training, row N1) -------------------------
+// pooled[q, n] = max over the rows r of segment q of act(x[r] . w[n] + b[n]), arg[q, n] = the first such row -- what
+// mpx_linear + mpx_segment_max give, bit for bit, without the [M, N] matrix in memory (2 GB for the second module at
+// batch 256): the tile kernel's epilogue folds its 128 x 128 tile into 64-bit {value, ~row} keys (common.h), unpacked here.
+__global__ void __launch_bounds__(256)
+    segmax_unpack_kernel(const unsigned long long *__restrict__ keys, int64_t Q, int N, float *__restrict__ pooled, int ldp,
+                         int64_t *__restrict__ arg) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= Q * N) return;
+  const int64_t q = e / N;
+  const int n = (int)(e - q * N);
+  const unsigned long long k = keys[e];
+  pooled[q * ldp + n] = mpx_ordered_float((unsigned)(k >> 32));
+  arg[e] = (int64_t)(0xFFFFFFFFu - (unsigned)k);
+}
+int mpx_segmax_unpack_launch(const unsigned long long *keys, int64_t Q, int N, float *pooled, int ldp, int64_t *arg,
+                             hipStream_t stream) {  // (dense_bf16.hip shares it)
+  hipLaunchKernelGGL(segmax_unpack_kernel, dim3(cdiv(Q * N, 256)), dim3(256), 0, stream, keys, Q, N, pooled, ldp, arg);
+  return 0;
+}
+int mpx_segmax_check(const char *name, int M, const int32_t *seg, int64_t Q, int N, const void *keys, const float *pooled,
+                     int ldp, const int64_t *arg) {
+  MPX_REQUIRE(seg && keys && pooled && arg, "%s: NULL operand", name);
+  MPX_REQUIRE(Q >= 1 && Q * N < ((int64_t)1 << 37) && ldp >= N, "%s: bad pooled shape", name);
+  MPX_REQUIRE(((uintptr_t)keys & 7) == 0, "%s: keys must be 8-byte aligned", name);
+  MPX_REQUIRE(M >= 1, "%s: every segment holds at least one row", name);
+  return 0;
+}
+static int segmax_rows(const float *x, int ldx, const float *w, const float *bias, int M, int N, int K, int act,
+                       const int32_t *seg, int row0, unsigned long long *keys, mpx_stream_t stream) {
+  if (const int64_t slab = mpx_row_slab(BM, (int64_t)ldx * 4); M > slab) {  // more rows than one launch covers
+    for (int64_t m0 = 0; m0 < M; m0 += slab)
+      if (int rc = segmax_rows(x + m0 * ldx, ldx, w, bias, (int)(M - m0 < slab ? M - m0 : slab), N, K, act, seg + m0,
+                               row0 + (int)m0, keys, stream))
+        return rc;
+    return 0;
+  }
+  float *ky = reinterpret_cast<float *>(keys);
+  if (dma_ok(M, N, K, ldx, K))
+    hipLaunchKernelGGL((linear_kernel<16, true, true>), dim3(cdiv(N, BN), cdiv(M, BM)), dim3(256), 0, mpx_s(stream), x, ldx, w,
+                       K, bias, M, N, K, act, ky, N, K, (size_t)0, static_cast<const float *>(nullptr), 0, 0, seg, row0);
+  else
+    hipLaunchKernelGGL((linear_kernel<16, true, false>), dim3(cdiv(N, BN), cdiv(M, BM)), dim3(256), 0, mpx_s(stream), x, ldx, w,
+                       K, bias, M, N, K, act, ky, N, K, (size_t)0, static_cast<const float *>(nullptr), 0, 0, seg, row0);
+  return 0;
+}
+MPX_EXPORT int mpx_linear_segmax(const float *x, int ldx, const float *w, const float *bias, int M, int N, int K, int act,
+                                 const int32_t *seg, int64_t Q, void *keys, float *pooled, int ldp, int64_t *arg,
+                                 mpx_stream_t stream) {
+  MPX_REQUIRE(M >= 0 && N >= 1 && K >= 1, "mpx_linear_segmax: bad size");
+  MPX_REQUIRE(K % 4 == 0 && ldx % 4 == 0, "mpx_linear_segmax: K and ldx must be multiples of 4 (got %d, %d)", K, ldx);
+  MPX_REQUIRE((((uintptr_t)x | (uintptr_t)w) & 15) == 0, "mpx_linear_segmax: x and w must be 16-byte aligned");
+  MPX_REQUIRE(ldx >= K && act >= 0 && act <= 2, "mpx_linear_segmax: leading dimension too small / unknown activation");
+  if (mpx_segmax_check("mpx_linear_segmax", M, seg, Q, N, keys, pooled, ldp, arg)) return 1;
+  hipError_t e = hipMemsetAsync(keys, 0, (size_t)Q * N * 8, mpx_s(stream));
+  MPX_REQUIRE(e == hipSuccess, "mpx_linear_segmax: memset failed: %s", hipGetErrorString(e));
+  if (int rc = segmax_rows(x, ldx, w, bias, M, N, K, act, seg, 0, static_cast<unsigned long long *>(keys), stream)) return rc;
+  mpx_segmax_unpack_launch(static_cast<const unsigned long long *>(keys), Q, N, pooled, ldp, arg, mpx_s(stream));
+  MPX_LAUNCH_CHECK("mpx_linear_segmax");
 }
 
 // ---- GroupNorm + LeakyReLU ---------------------------------------------------------------------------

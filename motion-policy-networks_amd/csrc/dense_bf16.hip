@@ -100,7 +100,8 @@ template <bool POOL>
 __global__ void __launch_bounds__(256)
     linear_bf16x3_kernel(const float *__restrict__ x, int ldx, const __bf16 *__restrict__ w, int ldw,
                          const float *__restrict__ bias, int M, int N, int K, int Kp, int act, float *__restrict__ y,
-                         int ldy, __bf16 *__restrict__ yp, int ldp, const float *__restrict__ dact_of, int lddact, int dact) {
+                         int ldy, __bf16 *__restrict__ yp, int ldp, const float *__restrict__ dact_of, int lddact, int dact,
+                         const int32_t *__restrict__ seg, int seg_row0) {
   // [stage][plane: A_hi, A_lo, B_hi, B_lo][128 rows x LDT]
   __shared__ __attribute__((aligned(16))) __bf16 smem[2 * 4 * HB_BM * HB_LDT];
   auto plane = [&](int stage, int p) { return smem + ((stage * 4 + p) * HB_BM) * HB_LDT; };
@@ -189,7 +190,16 @@ __global__ void __launch_bounds__(256)
   }
 
   // epilogue: C[row][col], col = lane&31, row = (r&3) + 8*(r>>2) + 4*half (same as the fp32 kernel)
-  if (POOL) {
+  if (POOL && seg != nullptr) {  // max over each SEGMENT of rows (training; y = the 64-bit keys, ldy in keys: common.h)
+    float bvj[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wn * 64 + j * 32 + l31;
+      bvj[j] = (bias && col < N) ? bias[col] : 0.0f;
+    }
+    mpx_segpool_tile([&](int i, int j, int r) __attribute__((always_inline)) { return hb_act(acc[i][j][r] + bvj[j], act); },
+                     m0 + wm * 64, n0 + wn * 64, M, N, half, l31, seg, seg_row0, reinterpret_cast<unsigned long long *>(y), ldy);
+  } else if (POOL) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int col = n0 + wn * 64 + j * 32 + l31;
@@ -474,7 +484,7 @@ MPX_EXPORT int mpx_linear_bf16x3(const float *x, int ldx, const void *w_pairs, c
   }
   hipLaunchKernelGGL((linear_bf16x3_kernel<false>), dim3(cdiv(N, HB_BN), cdiv(M, HB_BM)), dim3(256), 0, mpx_s(stream), x,
                      ldx, reinterpret_cast<const __bf16 *>(w_pairs), 2 * hb_kp(K), bias, M, N, K, hb_kp(K), act, y, ldy,
-                     (__bf16 *)nullptr, 0, (const float *)nullptr, 0, 0);
+                     (__bf16 *)nullptr, 0, (const float *)nullptr, 0, 0, static_cast<const int32_t *>(nullptr), 0);
   MPX_LAUNCH_CHECK("mpx_linear_bf16x3");
 }
 
@@ -493,7 +503,7 @@ MPX_EXPORT int mpx_linear_bf16x3_to_pairs(const float *x, int ldx, const void *w
   }
   hipLaunchKernelGGL((linear_bf16x3_kernel<false>), dim3(cdiv(N, HB_BN), cdiv(M, HB_BM)), dim3(256), 0, mpx_s(stream), x,
                      ldx, reinterpret_cast<const __bf16 *>(w_pairs), 2 * hb_kp(K), bias, M, N, K, hb_kp(K), act,
-                     (float *)nullptr, 0, reinterpret_cast<__bf16 *>(y_pairs), ldp, (const float *)nullptr, 0, 0);
+                     (float *)nullptr, 0, reinterpret_cast<__bf16 *>(y_pairs), ldp, (const float *)nullptr, 0, 0, static_cast<const int32_t *>(nullptr), 0);
   MPX_LAUNCH_CHECK("mpx_linear_bf16x3_to_pairs");
 }
 
@@ -514,8 +524,32 @@ MPX_EXPORT int mpx_linear_rowmax_bf16x3(const float *x, int ldx, const void *w_p
   MPX_REQUIRE(e == hipSuccess, "mpx_linear_rowmax_bf16x3: memset failed: %s", hipGetErrorString(e));
   hipLaunchKernelGGL((linear_bf16x3_kernel<true>), dim3(cdiv(N, HB_BN), M / HB_BM), dim3(256), 0, mpx_s(stream), x, ldx,
                      reinterpret_cast<const __bf16 *>(w_pairs), 2 * hb_kp(K), bias, M, N, K, hb_kp(K), (int)MPX_ACT_RELU, y,
-                     ldy, (__bf16 *)nullptr, 0, (const float *)nullptr, 0, 0);
+                     ldy, (__bf16 *)nullptr, 0, (const float *)nullptr, 0, 0, static_cast<const int32_t *>(nullptr), 0);
   MPX_LAUNCH_CHECK("mpx_linear_rowmax_bf16x3");
+}
+
+// the grouped MLPs' last layer + activation + max over each query's rows (dense.hip: mpx_linear_segmax) in split bf16
+int mpx_segmax_unpack_launch(const unsigned long long *keys, int64_t Q, int N, float *pooled, int ldp, int64_t *arg,
+                             hipStream_t stream);  // dense.hip
+int mpx_segmax_check(const char *name, int M, const int32_t *seg, int64_t Q, int N, const void *keys, const float *pooled,
+                     int ldp, const int64_t *arg);
+MPX_EXPORT int mpx_linear_segmax_bf16x3(const float *x, int ldx, const void *w_pairs, const float *bias, int M, int N, int K,
+                                        int act, const int32_t *seg, int64_t Q, void *keys, float *pooled, int ldp,
+                                        int64_t *arg, mpx_stream_t stream) {
+  if (hb_check("mpx_linear_segmax_bf16x3", x, ldx, w_pairs, M, N, K, N)) return 1;
+  MPX_REQUIRE(act >= 0 && act <= 2, "mpx_linear_segmax_bf16x3: unknown activation %d", act);
+  if (mpx_segmax_check("mpx_linear_segmax_bf16x3", M, seg, Q, N, keys, pooled, ldp, arg)) return 1;
+  hipError_t e = hipMemsetAsync(keys, 0, (size_t)Q * N * 8, mpx_s(stream));
+  MPX_REQUIRE(e == hipSuccess, "mpx_linear_segmax_bf16x3: memset failed: %s", hipGetErrorString(e));
+  const int64_t slab = mpx_row_slab(HB_BM, 0);
+  for (int64_t m0 = 0; m0 < M; m0 += slab) {
+    const int m = (int)(M - m0 < slab ? M - m0 : slab);
+    hipLaunchKernelGGL((linear_bf16x3_kernel<true>), dim3(cdiv(N, HB_BN), cdiv(m, HB_BM)), dim3(256), 0, mpx_s(stream),
+                       x + m0 * ldx, ldx, reinterpret_cast<const __bf16 *>(w_pairs), 2 * hb_kp(K), bias, m, N, K, hb_kp(K), act,
+                       reinterpret_cast<float *>(keys), N, (__bf16 *)nullptr, 0, (const float *)nullptr, 0, 0, seg + m0, (int)m0);
+  }
+  mpx_segmax_unpack_launch(static_cast<const unsigned long long *>(keys), Q, N, pooled, ldp, arg, mpx_s(stream));
+  MPX_LAUNCH_CHECK("mpx_linear_segmax_bf16x3");
 }
 
 static int pb_check(const char *name, const void *a, int lda, const void *w, int M, int N, int K) {
@@ -613,7 +647,7 @@ MPX_EXPORT int mpx_linear_bf16x3_dact(const float *x, int ldx, const void *w_pai
   }
   hipLaunchKernelGGL((linear_bf16x3_kernel<false>), dim3(cdiv(N, HB_BN), cdiv(M, HB_BM)), dim3(256), 0, mpx_s(stream), x,
                      ldx, reinterpret_cast<const __bf16 *>(w_pairs), 2 * hb_kp(K), (const float *)nullptr, M, N, K, hb_kp(K),
-                     (int)MPX_ACT_NONE, y, ldy, (__bf16 *)nullptr, 0, dact_of, lddact, dact);
+                     (int)MPX_ACT_NONE, y, ldy, (__bf16 *)nullptr, 0, dact_of, lddact, dact, static_cast<const int32_t *>(nullptr), 0);
   MPX_LAUNCH_CHECK("mpx_linear_bf16x3_dact");
 }
 

@@ -43,6 +43,8 @@ PROTOTYPES = {
     "mpx_segment_max": [P, I, P, L, P, I, P, P],
     "mpx_segment_max_grad": [P, I, P, L, I, P, P],
     "mpx_segment_max_grad_act": [P, I, P, P, I, P, L, I, I, P, P],
+    "mpx_linear_segmax": [P, I, P, P, I, I, I, I, P, L, P, P, I, P, P],
+    "mpx_linear_segmax_bf16x3": [P, I, P, P, I, I, I, I, P, L, P, P, I, P, P],
     "mpx_pool_wgrad_scratch": [L, I, I],
     "mpx_pool_wgrad": [P, I, P, P, I, L, I, I, P, I, I, P, P, P, P],
     "mpx_pool_dgrad": [P, I, P, P, I, P, L, I, I, P, I, P, I, I, I, I, P, I, P],

@@ -157,6 +157,9 @@ PRECISIONS = ("fp32", "bf16x3")
 # (mpx_pool_wgrad / mpx_pool_dgrad) instead of forming the [rows, C] gradient and running two dense GEMMs over its zeros;
 # False = the dense route (mpx_segment_max_grad_act + mpx_linear_wgrad / mpx_linear_dact), kept for A/B tests
 SPARSE_POOL_BACKWARD = True
+# training: the last layer's GEMM of a pooled stack max-pools in its epilogue (mpx_linear_segmax*): bit-identical to
+# mpx_linear + mpx_segment_max, without the [rows, C] matrix in memory; False = the two-step form (A/B tests)
+FUSED_POOL_FORWARD = True
 
 
 class SAWeights:
@@ -467,12 +470,32 @@ class _MLPChainFn(torch.autograd.Function):
         M, K0 = x.shape
         h = _pad4(_lib.f32c(x.detach()))
         xs, ws, meta = [], [], []
+        pooled = arg = None
         for i in range(L):
             w, b = wb[2 * i], wb[2 * i + 1]
             N, K = w.shape
             wp = _pad4(_lib.f32c(w.detach()))
             assert h.size(1) == wp.size(1), "layer widths do not chain"
             bias = None if b is None else _lib.f32c(b.detach())
+            if offsets is not None and i == L - 1 and FUSED_POOL_FORWARD:
+                # the last layer's GEMM pools in its epilogue: its [M, N] rows (2 GB for the second module at batch 256) are
+                # neither written nor read back -- the same values and arg-max rows as the two-step form, bit for bit
+                Q = offsets.numel() - 1
+                seg = torch.repeat_interleave(torch.arange(Q, dtype=torch.int32, device=h.device), offsets[1:] - offsets[:-1],
+                                              output_size=M)
+                pooled = torch.empty((Q, N), dtype=torch.float32, device=h.device)
+                arg = torch.empty((Q, N), dtype=torch.int64, device=h.device)
+                keys = torch.empty((Q, N), dtype=torch.int64, device=h.device)
+                if _MLPChainFn._use_x3(x3, M, N, wp.size(1)):
+                    _lib.call("mpx_linear_segmax_bf16x3", _lib.ptr(h), h.stride(0), _lib.ptr(split_pairs(wp)), _lib.ptr(bias), M, N,
+                              wp.size(1), acts[i], _lib.ptr(seg), Q, _lib.ptr(keys), _lib.ptr(pooled), N, _lib.ptr(arg))
+                else:
+                    _lib.call("mpx_linear_segmax", _lib.ptr(h), h.stride(0), _lib.ptr(wp), _lib.ptr(bias), M, N, wp.size(1),
+                              acts[i], _lib.ptr(seg), Q, _lib.ptr(keys), _lib.ptr(pooled), N, _lib.ptr(arg))
+                xs.append(h)
+                ws.append(wp)
+                meta.append((N, K, b is not None))
+                break
             if _MLPChainFn._use_x3(x3, M, N, wp.size(1)):
                 y = torch.empty((M, N), dtype=torch.float32, device=h.device)
                 _lib.call("mpx_linear_bf16x3", _lib.ptr(h), h.stride(0), _lib.ptr(split_pairs(wp)), _lib.ptr(bias), M, N,
@@ -483,13 +506,13 @@ class _MLPChainFn(torch.autograd.Function):
             ws.append(wp)
             meta.append((N, K, b is not None))
             h = _pad4(y) if (i + 1 < L and N % 4) else y
-        pooled = arg = None
         if offsets is not None:
-            Q = offsets.numel() - 1
-            C = h.size(1)
-            pooled = torch.empty((Q, C), dtype=torch.float32, device=h.device)
-            arg = torch.empty((Q, C), dtype=torch.int64, device=h.device)
-            _lib.call("mpx_segment_max", _lib.ptr(h), C, _lib.ptr(offsets), Q, _lib.ptr(pooled), C, _lib.ptr(arg))
+            if pooled is None:
+                Q = offsets.numel() - 1
+                C = h.size(1)
+                pooled = torch.empty((Q, C), dtype=torch.float32, device=h.device)
+                arg = torch.empty((Q, C), dtype=torch.int64, device=h.device)
+                _lib.call("mpx_segment_max", _lib.ptr(h), C, _lib.ptr(offsets), Q, _lib.ptr(pooled), C, _lib.ptr(arg))
             ctx.save_for_backward(*xs, *ws, pooled, arg, offsets)  # (the last layer's rows are not needed again)
         else:
             ctx.save_for_backward(*xs, *ws, h)

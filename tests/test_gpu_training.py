@@ -246,6 +246,51 @@ def test_mlp_chain_is_the_per_layer_backward_without_the_activation_passes(poole
     assert all(t.grad is not None and torch.isfinite(t.grad).all() for t in w)
 
 
+@pytest.mark.parametrize("x3", [False, True])
+@pytest.mark.parametrize("M,N,K,act", [(3000, 256, 128, 1), (1000, 64, 64, 1), (515, 200, 68, 2), (700, 130, 20, 0)])
+def test_fused_pool_forward_is_the_two_step_form_bit_for_bit(M, N, K, act, x3):
+    """mpx_linear_segmax (_bf16x3): the GEMM's epilogue max-pools each query's rows through 64-bit {value, ~row} keys; pooled
+    values AND arg-max rows equal mpx_linear (_bf16x3) + mpx_segment_max exactly -- negative values (no activation /
+    LeakyReLU), ties (duplicated rows: the first one wins), row and column counts that are not multiples of the tile."""
+    from mpinets_amd import _lib
+    from mpinets_amd.pointnet2 import split_pairs
+
+    if x3 and K % 16:
+        K = (K + 15) // 16 * 16
+    rng = np.random.default_rng(M + N)
+    lens = []
+    while sum(lens) < M:
+        lens.append(int(rng.integers(1, 90)))
+    lens[-1] -= sum(lens) - M
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    Q = len(lens)
+    x = rng.normal(size=(M, K)).astype(np.float32)
+    x[5] = x[4]  # a tie inside the first segment(s)
+    w = (rng.normal(size=(N, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.normal(size=N).astype(np.float32)
+    T = lambda a, dt=torch.float32: torch.tensor(a, dtype=dt, device=dev())
+    xd, wd, bd, od = T(x), T(w), T(b), T(off, torch.int64)
+    seg = torch.repeat_interleave(torch.arange(Q, dtype=torch.int32, device=dev()), od[1:] - od[:-1])
+    y = torch.empty((M, N), device=dev())
+    if x3:
+        wp = split_pairs(wd)
+        _lib.call("mpx_linear_bf16x3", _lib.ptr(xd), K, _lib.ptr(wp), _lib.ptr(bd), M, N, K, act, _lib.ptr(y), N)
+    else:
+        _lib.call("mpx_linear", _lib.ptr(xd), K, _lib.ptr(wd), _lib.ptr(bd), M, N, K, act, _lib.ptr(y), N)
+    p0, a0 = torch.empty((Q, N), device=dev()), torch.empty((Q, N), dtype=torch.int64, device=dev())
+    _lib.call("mpx_segment_max", _lib.ptr(y), N, _lib.ptr(od), Q, _lib.ptr(p0), N, _lib.ptr(a0))
+    p1, a1 = torch.full((Q, N), float("nan"), device=dev()), torch.full((Q, N), -1, dtype=torch.int64, device=dev())
+    keys = torch.empty((Q, N), dtype=torch.int64, device=dev())
+    if x3:
+        _lib.call("mpx_linear_segmax_bf16x3", _lib.ptr(xd), K, _lib.ptr(wp), _lib.ptr(bd), M, N, K, act, _lib.ptr(seg), Q,
+                  _lib.ptr(keys), _lib.ptr(p1), N, _lib.ptr(a1))
+    else:
+        _lib.call("mpx_linear_segmax", _lib.ptr(xd), K, _lib.ptr(wd), _lib.ptr(bd), M, N, K, act, _lib.ptr(seg), Q,
+                  _lib.ptr(keys), _lib.ptr(p1), N, _lib.ptr(a1))
+    assert torch.equal(p0, p1)
+    assert torch.equal(a0, a1)
+
+
 @pytest.mark.parametrize("Q,C,K,act,below,win", [(37, 256, 128, 1, 1, 128), (64, 64, 64, 1, 1, 16), (5, 1024, 512, 1, 1, 128),
                                                   (50, 96, 68, 2, 2, 32), (33, 70, 20, 0, 0, 128), (9, 130, 132, 1, 0, 16)])
 def test_sparse_pool_backward_kernels_match_float64(Q, C, K, act, below, win):
