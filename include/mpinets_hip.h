@@ -29,7 +29,7 @@ typedef void *mpx_stream_t;
 
 #define MPX_NUM_FRAMES 15 /* link0..8, hand, leftfinger, rightfinger, l/r fingertip, right_gripper */
 
-int mpx_version(void); /* 340: mpx_pool_wgrad / mpx_pool_wgrad_scratch / mpx_pool_dgrad, mpx_linear_segmax / mpx_linear_segmax_bf16x3 (additions only);
+int mpx_version(void); /* 340: mpx_pool_wgrad / mpx_pool_wgrad_scratch / mpx_pool_dgrad, mpx_linear_segmax / mpx_linear_segmax_bf16x3, mpx_pack_rows_ld / mpx_pack_rows_grad_ld (additions only);
                           330: mpx_sa3_front_bf16x3 / _pack / _pack_size / _w3_pairs (additions), the measurement hooks mpx_sa3_chain_probe / mpx_sa2_bf16x3_set_probe /
                           mpx_sa3_front_bf16x3_probe declared, mpx_sa_mlp_bf16x3_factored refuses nsample > 128;
                           320: mpx_linear_dact, mpx_segment_max_grad_act, mpx_linear_bf16x3_dact, mpx_linear_wgrad_bf16x3 (additions only); mpx_franka_collision accepts
@@ -241,10 +241,18 @@ int mpx_pack_rows(const float *xyz, int xyz_stride, const float *new_xyz, int ne
                   const float *feat, int feat_stride, int C, const int32_t *idx, const int32_t *cnt,
                   const int64_t *offsets, int B, int N, int npoint, int nsample, float *rows,
                   mpx_stream_t stream);
+/* ... with the rows `ld` >= 3 + C floats apart and the columns behind 3 + C zero-filled (ld % 4 == 0: no padding copy in
+ * front of the GEMMs)                                                                                 */
+int mpx_pack_rows_ld(const float *xyz, int xyz_stride, const float *new_xyz, int new_stride, const float *feat,
+                     int feat_stride, int C, const int32_t *idx, const int32_t *cnt, const int64_t *offsets, int B, int N,
+                     int npoint, int nsample, float *rows, int ld, mpx_stream_t stream);
 /* backward: grad_feat[b, idx[q,r], c] += grad_rows[offsets[q]+r, 3+c] (atomic adds; grad_feat pre-zeroed) */
 int mpx_pack_rows_grad(const float *grad_rows, int C, const int32_t *idx, const int32_t *cnt,
                        const int64_t *offsets, int B, int N, int npoint, int nsample, float *grad_feat,
                        int feat_stride, mpx_stream_t stream);
+int mpx_pack_rows_grad_ld(const float *grad_rows, int ld, int C, const int32_t *idx, const int32_t *cnt,
+                          const int64_t *offsets, int B, int N, int npoint, int nsample, float *grad_feat, int feat_stride,
+                          mpx_stream_t stream); /* (gradient rows ld >= 3 + C floats apart) */
 /* out[q,c] = max over the rows of segment q of y[R,C]; arg[q,c] = first row attaining it           */
 int mpx_segment_max(const float *y, int C, const int64_t *offsets, int64_t Q, float *out, int out_stride,
                     int64_t *arg, mpx_stream_t stream);

@@ -24,7 +24,7 @@ void mpx_set_error(const char *fmt, ...) {
   va_end(ap);
 }
 MPX_EXPORT const char *mpx_last_error(void) { return g_err; }
-MPX_EXPORT int mpx_version(void) { return 340; }  // 340: mpx_pool_wgrad / _scratch / mpx_pool_dgrad, mpx_linear_segmax / _bf16x3; 330: mpx_sa3_front_bf16x3 (+ _pack, _pack_size, _w3_pairs), the three measurement hooks declared, mpx_sa_mlp_bf16x3_factored refuses nsample > 128; 320: mpx_linear_dact, mpx_segment_max_grad_act, mpx_linear_bf16x3_dact, mpx_linear_wgrad_bf16x3, unaligned frames accepted by mpx_franka_collision; 310: sa3_pack may be NULL, MPX_VARIANT_UNIT_QUEUE; 300: mpx_set_variant, wants_order(nsample); 200: env_offset arguments, mpx_rollout
+MPX_EXPORT int mpx_version(void) { return 340; }  // 340: mpx_pool_wgrad / _scratch / mpx_pool_dgrad, mpx_linear_segmax / _bf16x3, mpx_pack_rows_ld / _grad_ld; 330: mpx_sa3_front_bf16x3 (+ _pack, _pack_size, _w3_pairs), the three measurement hooks declared, mpx_sa_mlp_bf16x3_factored refuses nsample > 128; 320: mpx_linear_dact, mpx_segment_max_grad_act, mpx_linear_bf16x3_dact, mpx_linear_wgrad_bf16x3, unaligned frames accepted by mpx_franka_collision; 310: sa3_pack may be NULL, MPX_VARIANT_UNIT_QUEUE; 300: mpx_set_variant, wants_order(nsample); 200: env_offset arguments, mpx_rollout
 MPX_EXPORT int mpx_device_info(char *name, int name_len, int *cu_count, int *lds_bytes) {
   int dev = 0;
   hipDeviceProp_t p;

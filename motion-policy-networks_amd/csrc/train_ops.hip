@@ -11,7 +11,7 @@ __global__ void __launch_bounds__(256)
     pack_rows_kernel(const float *__restrict__ xyz, int xs, const float *__restrict__ nxyz, int ns,
                      const float *__restrict__ feat, int fs, int C, const int32_t *__restrict__ idx,
                      const int32_t *__restrict__ cnt, const int64_t *__restrict__ off, int64_t Q, int N, int npoint,
-                     int nsample, float *__restrict__ rows) {
+                     int nsample, float *__restrict__ rows, int ld) {
   const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (q >= Q) return;
   const int lane = threadIdx.x & 63, W = 3 + C;
@@ -19,14 +19,14 @@ __global__ void __launch_bounds__(256)
   const int n = max(cnt[q], 1);
   const float cx = nxyz[q * ns], cy = nxyz[q * ns + 1], cz = nxyz[q * ns + 2];
   const int32_t *id = idx + q * nsample;
-  float *dst = rows + off[q] * W;
+  float *dst = rows + off[q] * ld;
   for (int r = 0; r < n; ++r) {
     const int64_t p = b * N + id[r];
-    for (int ch = lane; ch < W; ch += 64) {
-      float v;
+    for (int ch = lane; ch < ld; ch += 64) {  // (columns [W, ld): zero padding for the GEMMs' 16-byte rows)
+      float v = 0.0f;
       if (ch < 3) v = xyz[p * xs + ch] - (ch == 0 ? cx : ch == 1 ? cy : cz);
-      else v = feat[p * fs + (ch - 3)];
-      dst[(int64_t)r * W + ch] = v;
+      else if (ch < W) v = feat[p * fs + (ch - 3)];
+      dst[(int64_t)r * ld + ch] = v;
     }
   }
 }
@@ -35,10 +35,10 @@ __global__ void __launch_bounds__(256)
 __global__ void __launch_bounds__(256)
     pack_rows_grad_kernel(const float *__restrict__ drows, int C, const int32_t *__restrict__ idx,
                           const int32_t *__restrict__ cnt, const int64_t *__restrict__ off, int64_t Q, int N,
-                          int npoint, int nsample, float *__restrict__ dfeat, int fs) {
+                          int npoint, int nsample, float *__restrict__ dfeat, int fs, int W) {
   const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (q >= Q) return;
-  const int lane = threadIdx.x & 63, W = 3 + C;
+  const int lane = threadIdx.x & 63;
   const int64_t b = q / npoint;
   const int n = max(cnt[q], 1);
   const int32_t *id = idx + q * nsample;
@@ -377,8 +377,21 @@ MPX_EXPORT int mpx_pack_rows(const float *xyz, int xyz_stride, const float *new_
   const int64_t Q = (int64_t)B * npoint;
   if (Q == 0) return 0;
   hipLaunchKernelGGL(pack_rows_kernel, dim3(cdiv(Q, 4)), dim3(256), 0, mpx_s(stream), xyz, xyz_stride, new_xyz,
-                     new_stride, feat, feat_stride, C, idx, cnt, offsets, Q, N, npoint, nsample, rows);
+                     new_stride, feat, feat_stride, C, idx, cnt, offsets, Q, N, npoint, nsample, rows, 3 + C);
   MPX_LAUNCH_CHECK("mpx_pack_rows");
+}
+// the same with rows `ld` >= 3 + C floats apart, the columns behind 3 + C zero-filled (ld a multiple of 4: the rows feed the
+// GEMMs without a padding copy)
+MPX_EXPORT int mpx_pack_rows_ld(const float *xyz, int xyz_stride, const float *new_xyz, int new_stride, const float *feat,
+                                int feat_stride, int C, const int32_t *idx, const int32_t *cnt, const int64_t *offsets, int B,
+                                int N, int npoint, int nsample, float *rows, int ld, mpx_stream_t stream) {
+  MPX_REQUIRE(B >= 0 && N > 0 && npoint > 0 && nsample > 0 && C >= 0 && ld >= 3 + C, "mpx_pack_rows_ld: bad size");
+  MPX_REQUIRE(xyz_stride >= 3 && new_stride >= 3 && (C == 0 || feat_stride >= C), "mpx_pack_rows_ld: bad stride");
+  const int64_t Q = (int64_t)B * npoint;
+  if (Q == 0) return 0;
+  hipLaunchKernelGGL(pack_rows_kernel, dim3(cdiv(Q, 4)), dim3(256), 0, mpx_s(stream), xyz, xyz_stride, new_xyz,
+                     new_stride, feat, feat_stride, C, idx, cnt, offsets, Q, N, npoint, nsample, rows, ld);
+  MPX_LAUNCH_CHECK("mpx_pack_rows_ld");
 }
 
 MPX_EXPORT int mpx_pack_rows_grad(const float *grad_rows, int C, const int32_t *idx, const int32_t *cnt,
@@ -388,8 +401,20 @@ MPX_EXPORT int mpx_pack_rows_grad(const float *grad_rows, int C, const int32_t *
   const int64_t Q = (int64_t)B * npoint;
   if (Q == 0) return 0;
   hipLaunchKernelGGL(pack_rows_grad_kernel, dim3(cdiv(Q, 4)), dim3(256), 0, mpx_s(stream), grad_rows, C, idx, cnt,
-                     offsets, Q, N, npoint, nsample, grad_feat, feat_stride);
+                     offsets, Q, N, npoint, nsample, grad_feat, feat_stride, 3 + C);
   MPX_LAUNCH_CHECK("mpx_pack_rows_grad");
+}
+// (gradient rows `ld` >= 3 + C floats apart)
+MPX_EXPORT int mpx_pack_rows_grad_ld(const float *grad_rows, int ld, int C, const int32_t *idx, const int32_t *cnt,
+                                     const int64_t *offsets, int B, int N, int npoint, int nsample, float *grad_feat,
+                                     int feat_stride, mpx_stream_t stream) {
+  MPX_REQUIRE(B >= 0 && N > 0 && npoint > 0 && nsample > 0 && C > 0 && feat_stride >= C && ld >= 3 + C,
+              "mpx_pack_rows_grad_ld: bad size");
+  const int64_t Q = (int64_t)B * npoint;
+  if (Q == 0) return 0;
+  hipLaunchKernelGGL(pack_rows_grad_kernel, dim3(cdiv(Q, 4)), dim3(256), 0, mpx_s(stream), grad_rows, C, idx, cnt,
+                     offsets, Q, N, npoint, nsample, grad_feat, feat_stride, ld);
+  MPX_LAUNCH_CHECK("mpx_pack_rows_grad_ld");
 }
 
 MPX_EXPORT int mpx_segment_max(const float *y, int C, const int64_t *offsets, int64_t Q, float *out, int out_stride,

@@ -40,6 +40,8 @@ PROTOTYPES = {
     "mpx_franka_cloud_grad": [P, I, F, P, P, P, I, P, L, I, P, P],
     "mpx_pack_rows": [P, I, P, I, P, I, I, P, P, P, I, I, I, I, P, P],
     "mpx_pack_rows_grad": [P, I, P, P, P, I, I, I, I, P, I, P],
+    "mpx_pack_rows_ld": [P, I, P, I, P, I, I, P, P, P, I, I, I, I, P, I, P],
+    "mpx_pack_rows_grad_ld": [P, I, I, P, P, P, I, I, I, I, P, I, P],
     "mpx_segment_max": [P, I, P, L, P, I, P, P],
     "mpx_segment_max_grad": [P, I, P, L, I, P, P],
     "mpx_segment_max_grad_act": [P, I, P, P, I, P, L, I, I, P, P],

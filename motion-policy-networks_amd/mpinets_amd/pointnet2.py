@@ -387,9 +387,10 @@ class _PackRows(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feat, xyz, xyz_stride, new_xyz, new_stride, feat_stride, C, idx, cnt, offsets, R, dims):
         B, N, npoint, nsample = dims
-        rows = torch.empty((R, 3 + C), dtype=torch.float32, device=idx.device)
-        _lib.call("mpx_pack_rows", _lib.ptr(xyz), xyz_stride, _lib.ptr(new_xyz), new_stride, _lib.ptr(feat),
-                  feat_stride, C, _lib.ptr(idx), _lib.ptr(cnt), _lib.ptr(offsets), B, N, npoint, nsample, _lib.ptr(rows))
+        ld = (3 + C + 3) // 4 * 4  # rows padded to 16 bytes (zero columns): the GEMMs take them as they are, no padding copy
+        rows = torch.empty((R, ld), dtype=torch.float32, device=idx.device)
+        _lib.call("mpx_pack_rows_ld", _lib.ptr(xyz), xyz_stride, _lib.ptr(new_xyz), new_stride, _lib.ptr(feat),
+                  feat_stride, C, _lib.ptr(idx), _lib.ptr(cnt), _lib.ptr(offsets), B, N, npoint, nsample, _lib.ptr(rows), ld)
         ctx.save_for_backward(idx, cnt, offsets)
         ctx.meta = (C, dims, tuple(feat.shape), feat_stride)
         return rows
@@ -400,10 +401,11 @@ class _PackRows(torch.autograd.Function):
         C, (B, N, npoint, nsample), shape, feat_stride = ctx.meta
         if not ctx.needs_input_grad[0]:
             return (None,) * 12
-        g = _lib.f32c(g)
+        if g.dtype != torch.float32 or g.stride(1) != 1 or g.stride(0) < 3 + C:
+            g = _lib.f32c(g)
         gf = torch.zeros(shape, dtype=torch.float32, device=g.device)
-        _lib.call("mpx_pack_rows_grad", _lib.ptr(g), C, _lib.ptr(idx), _lib.ptr(cnt), _lib.ptr(offsets), B, N, npoint,
-                  nsample, _lib.ptr(gf), gf.stride(1))
+        _lib.call("mpx_pack_rows_grad_ld", _lib.ptr(g), g.stride(0), C, _lib.ptr(idx), _lib.ptr(cnt), _lib.ptr(offsets), B, N,
+                  npoint, nsample, _lib.ptr(gf), gf.stride(1))
         return (gf,) + (None,) * 11
 
 
