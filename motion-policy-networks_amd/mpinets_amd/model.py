@@ -188,7 +188,7 @@ class MPiNetsPointNet(nn.Module):
     def forward_train(self, point_cloud: torch.Tensor, aux: Optional[dict] = None) -> torch.Tensor:
         """Differentiable forward (training_step, model.py:185-240): sampling / neighbour search / grouping /
         max-pool are this engine's kernels (no padding rows), the dense layers are torch ops under autograd."""
-        from .pointnet2 import sa_module_train
+        from .pointnet2 import sa_module_train, segment_offsets
 
         pc = _lib.f32c(point_cloud)
         B, N, _ = pc.shape
@@ -202,9 +202,8 @@ class MPiNetsPointNet(nn.Module):
         cnt1 = torch.empty((B, sa1.npoint), dtype=torch.int32, device=dev)
         lib.call("mpx_ball_query", lib.ptr(xyz1), 3, lib.ptr(pc), 4, B, N, sa1.npoint, float(sa1.radius),
                  sa1.nsample, lib.ptr(nbr1), lib.ptr(cnt1))
-        # the slab is read in place: coordinates at stride 4, label column = the one input feature (no gradient)
-        tp = self.train_precision
-        f1 = sa_module_train(sa1.convs(), pc, 4, xyz1, 3, pc[:, :, 3:], 4, 1, nbr1, cnt1, (B, N, sa1.npoint, sa1.nsample), tp)
+        # sampling and neighbour search of BOTH modules first: they depend on coordinates only, so the two row counts that
+        # size the packed activations reach the host with one sync, after which nothing in the step waits for the device
         idx2 = torch.empty((B, sa2.npoint), dtype=torch.int32, device=dev)
         xyz2 = torch.empty((B, sa2.npoint, 3), dtype=torch.float32, device=dev)
         lib.call("mpx_fps", lib.ptr(xyz1), B, sa1.npoint, 3, sa2.npoint, lib.ptr(idx2), lib.ptr(xyz2), 3)
@@ -212,9 +211,15 @@ class MPiNetsPointNet(nn.Module):
         cnt2 = torch.empty((B, sa2.npoint), dtype=torch.int32, device=dev)
         lib.call("mpx_ball_query", lib.ptr(xyz2), 3, lib.ptr(xyz1), 3, B, sa1.npoint, sa2.npoint, float(sa2.radius),
                  sa2.nsample, lib.ptr(nbr2), lib.ptr(cnt2))
+        off1, off2 = segment_offsets(cnt1), segment_offsets(cnt2)
+        R1, R2 = (int(v) for v in torch.stack((off1[-1], off2[-1])).tolist())
+        # the slab is read in place: coordinates at stride 4, label column = the one input feature (no gradient)
+        tp = self.train_precision
+        f1 = sa_module_train(sa1.convs(), pc, 4, xyz1, 3, pc[:, :, 3:], 4, 1, nbr1, cnt1, (B, N, sa1.npoint, sa1.nsample), tp,
+                             offsets=off1, R=R1)
         f1 = f1.contiguous()
         f2 = sa_module_train(sa2.convs(), xyz1, 3, xyz2, 3, f1, f1.size(2), f1.size(2), nbr2, cnt2,
-                             (B, sa1.npoint, sa2.npoint, sa2.nsample), tp)
+                             (B, sa1.npoint, sa2.npoint, sa2.nsample), tp, offsets=off2, R=R2)
         h = torch.cat((xyz2, f2), dim=2)  # group-all: absolute coordinates | features
         # (one segment per environment: the pool and its backward are the grouped modules' kernels)
         seg = torch.arange(B + 1, dtype=torch.int64, device=dev) * sa2.npoint

@@ -631,15 +631,26 @@ def mlp_chain_train(x: torch.Tensor, layers, acts, offsets: Optional[torch.Tenso
     return y if offsets is not None else y.reshape(lead + (y.size(-1),))
 
 
+def segment_offsets(cnt: torch.Tensor) -> torch.Tensor:
+    """int64 [Q+1]: start of every query's rows in the packed matrix (a query without a hit keeps one row)."""
+    offsets = torch.zeros(cnt.numel() + 1, dtype=torch.int64, device=cnt.device)
+    torch.cumsum(cnt.reshape(-1).clamp(min=1), 0, out=offsets[1:])
+    return offsets
+
+
 def sa_module_train(convs: List[nn.Conv2d], xyz: torch.Tensor, xyz_stride: int, new_xyz: torch.Tensor,
                     new_stride: int, feat: torch.Tensor, feat_stride: int, C: int, idx: torch.Tensor,
-                    cnt: torch.Tensor, dims: Tuple[int, int, int, int], precision: str = "fp32") -> torch.Tensor:
+                    cnt: torch.Tensor, dims: Tuple[int, int, int, int], precision: str = "fp32",
+                    offsets: Optional[torch.Tensor] = None, R: Optional[int] = None) -> torch.Tensor:
     """Differentiable set-abstraction MLP + max-pool -> [B, npoint, C_out].  ``feat`` is any tensor whose storage
-    holds the point-major features (``feat_stride`` floats between points); it receives the gradient."""
+    holds the point-major features (``feat_stride`` floats between points); it receives the gradient.
+    ``offsets`` / ``R`` (``segment_offsets(cnt)`` and its last entry as a host int): a caller that has them already --
+    the model reads both modules' row counts with ONE host sync -- passes them in."""
     B, N, npoint, nsample = dims
-    offsets = torch.zeros(B * npoint + 1, dtype=torch.int64, device=idx.device)
-    torch.cumsum(cnt.reshape(-1).clamp(min=1), 0, out=offsets[1:])
-    R = int(offsets[-1].item())  # one host sync per module and step: the row count sizes the activations
+    if offsets is None:
+        offsets = segment_offsets(cnt)
+    if R is None:
+        R = int(offsets[-1].item())  # a host sync: the row count sizes the activations
     h = _PackRows.apply(feat, xyz, xyz_stride, new_xyz, new_stride, feat_stride, C, idx, cnt, offsets, R, dims)
     layers = [(conv.weight.view(conv.out_channels, -1), conv.bias) for conv in convs]
     # (offsets = cumsum of the clamped counts, R = its last entry = the rows _PackRows made: the segments tile them)
