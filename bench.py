@@ -517,20 +517,26 @@ def main():
             ms_max = shard.max_over_ranks(per_step[-1] * 1e-3, dev) * 1e3
             c1t, c2t = tm.point_cloud_encoder.last_counts
             rows1, rows2 = int(c1t.clamp(min=1).sum()), int(c2t.clamp(min=1).sum())
-            # executed matrix work: forward over the hit rows only (the differentiable path packs them), backward = 2x
+            # matrix work: forward over the hit rows only (the differentiable path packs them); a dense backward is 2x that
+            # (`nominal`); the backward of the three pooled layers walks the pool's non-zero gradients instead (mpx_pool_wgrad /
+            # mpx_pool_dgrad: Q x C x K fused multiply-adds each on the vector unit), so `executed` drops their two GEMMs
             fwd = 2.0 * (rows1 * 8448 + rows2 * 57728 + nb * (128 * 919040 + HEAD_MACS))
+            pooled_dense = 2.0 * 2 * (rows1 * 4096 + rows2 * 32768 + nb * 128 * 524288)
+            pooled_sparse = 2.0 * 2 * (c1t.numel() * 64 * 64 + c2t.numel() * 256 * 128 + nb * 1024 * 512)
+            executed = 3 * fwd - pooled_dense + pooled_sparse
             training[f"batch_{tb}" + ("" if prec == "fp32" else "_" + prec)] = {
                 "samples_per_gpu": nb, "steps": n_t, "ms_per_step": el_t / n_t * 1e3, "ms_min": per_step[0],
                 "ms_max": ms_max, "ms_wall_mean": wall_t / n_t * 1e3,
                 "samples_per_s": nb * n_gpus * n_t / el_t, "loss": float(loss.item()), "dtype": prec,
-                "executed_tflops": 3 * fwd / (el_t / n_t) / 1e12,
-                "frac_of_fp32_mfma_peak": 3 * fwd / (el_t / n_t) / 1e12 / FP32_MFMA_PEAK_TFLOPS}
+                "nominal_tflops": 3 * fwd / (el_t / n_t) / 1e12, "executed_tflops": executed / (el_t / n_t) / 1e12,
+                "frac_of_fp32_mfma_peak": executed / (el_t / n_t) / 1e12 / FP32_MFMA_PEAK_TFLOPS}
         tm.set_training_precision("fp32")
         training["what"] = ("TrainingMotionPolicyNetwork.training_step + backward + bucketed gradient all-reduce + clip(1.0) + Adam "
                             "(mpinets_amd.training.train_step); batch_10 = jobconfig.yaml's batch size per GPU; batch_256_bf16x3 = the same step "
                             "with set_training_precision('bf16x3') (the grouped MLPs' GEMMs in split bf16, fp32 accumulate and master "
-                            "weights: the engine's form of the reference's precision=16); FLOPs = 3 x the forward's executed matrix "
-                            "work (hit rows only), always against the fp32 MFMA peak")
+                            "weights: the engine's form of the reference's precision=16); nominal FLOPs = 3 x the forward's matrix "
+                            "work over the hit rows; executed = that minus the dense backward of the three pooled layers, which "
+                            "runs over the max-pool's non-zero gradients; the fraction is executed work against the fp32 MFMA peak")
         training["allreduce_ranks"] = n_gpus if dist_backend is not None else 1
         del tm, opt, batch
         model.eval()
