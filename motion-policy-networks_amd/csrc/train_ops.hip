@@ -6,7 +6,11 @@
 // and its gradient ignore repeats), packed as rows of one [R, 3+C] matrix with a segment per query.
 #include "common.h"
 
-// rows[off[q] + r, :] = [xyz[idx[q,r]] - new_xyz[q] | feat[idx[q,r], :]],  r < max(cnt[q], 1)
+// rows[off[q] + r, :] = [xyz[idx[q,r]] - new_xyz[q] | feat[idx[q,r], :] | 0 ...],  r < max(cnt[q], 1)
+// One wave per query.  The (row, column) elements of the query's block are dealt to the lanes as ONE flat sequence (lane
+// takes elements lane, lane + 64, ...: a row of 68 floats does not cost two passes of 64 lanes), the neighbour ids of 64
+// rows at a time sit in the lanes and are fetched with a shuffle, and four elements per lane are in flight -- a first form
+// walked the rows one by one with a dependent id -> row load chain (0.45 ms for the second module at batch 256).
 __global__ void __launch_bounds__(256)
     pack_rows_kernel(const float *__restrict__ xyz, int xs, const float *__restrict__ nxyz, int ns,
                      const float *__restrict__ feat, int fs, int C, const int32_t *__restrict__ idx,
@@ -20,18 +24,37 @@ __global__ void __launch_bounds__(256)
   const float cx = nxyz[q * ns], cy = nxyz[q * ns + 1], cz = nxyz[q * ns + 2];
   const int32_t *id = idx + q * nsample;
   float *dst = rows + off[q] * ld;
-  for (int r = 0; r < n; ++r) {
-    const int64_t p = b * N + id[r];
-    for (int ch = lane; ch < ld; ch += 64) {  // (columns [W, ld): zero padding for the GEMMs' 16-byte rows)
-      float v = 0.0f;
-      if (ch < 3) v = xyz[p * xs + ch] - (ch == 0 ? cx : ch == 1 ? cy : cz);
-      else if (ch < W) v = feat[p * fs + (ch - 3)];
-      dst[(int64_t)r * ld + ch] = v;
+  const int drow = 64 / ld, dch = 64 % ld;  // one step of 64 elements in (row, column)
+  for (int rb = 0; rb < n; rb += 64) {  // 64 rows per window: their ids in the lanes
+    const int nr = min(64, n - rb);
+    const int my_id = id[rb + min(lane, nr - 1)];
+    int row = lane / ld, ch = lane % ld;
+    const int total = nr * ld;
+    for (int e = lane; e - lane < total; e += 256) {  // four elements per lane per trip (uniform trip count)
+      float v[4];
+      int rr[4], cc[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        rr[u] = row, cc[u] = ch;
+        const bool in = e + 64 * u < total;
+        const int64_t p = b * N + __shfl(my_id, in ? row : 0);
+        v[u] = 0.0f;
+        if (in) {
+          if (ch < 3) v[u] = xyz[p * xs + ch] - (ch == 0 ? cx : ch == 1 ? cy : cz);
+          else if (ch < W) v[u] = feat[p * fs + (ch - 3)];
+        }
+        row += drow, ch += dch;
+        if (ch >= ld) ch -= ld, ++row;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (e + 64 * u < total) dst[(int64_t)(rb + rr[u]) * ld + cc[u]] = v[u];
     }
   }
 }
 
 // dfeat[b, idx[q,r], c] += drows[off[q] + r, 3 + c]   (the coordinates carry no gradient: they are data)
+// (the same flat dealing of (row, channel) elements; W = floats between gradient rows)
 __global__ void __launch_bounds__(256)
     pack_rows_grad_kernel(const float *__restrict__ drows, int C, const int32_t *__restrict__ idx,
                           const int32_t *__restrict__ cnt, const int64_t *__restrict__ off, int64_t Q, int N,
@@ -42,10 +65,30 @@ __global__ void __launch_bounds__(256)
   const int64_t b = q / npoint;
   const int n = max(cnt[q], 1);
   const int32_t *id = idx + q * nsample;
-  const float *src = drows + off[q] * W;
-  for (int r = 0; r < n; ++r) {
-    const int64_t p = b * N + id[r];
-    for (int c = lane; c < C; c += 64) atomicAdd(dfeat + p * fs + c, src[(int64_t)r * W + 3 + c]);
+  const float *src = drows + off[q] * W + 3;
+  const int drow = 64 / C, dch = 64 % C;
+  for (int rb = 0; rb < n; rb += 64) {
+    const int nr = min(64, n - rb);
+    const int my_id = id[rb + min(lane, nr - 1)];
+    int row = lane / C, ch = lane % C;
+    const int total = nr * C;
+    for (int e = lane; e - lane < total; e += 256) {
+      float v[4];
+      int64_t pp[4];
+      int cc[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const bool in = e + 64 * u < total;
+        pp[u] = b * N + __shfl(my_id, in ? row : 0);
+        cc[u] = ch;
+        v[u] = in ? src[(int64_t)(rb + row) * W + ch] : 0.0f;
+        row += drow, ch += dch;
+        if (ch >= C) ch -= C, ++row;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (e + 64 * u < total) atomicAdd(dfeat + pp[u] * fs + cc[u], v[u]);
+    }
   }
 }
 
