@@ -121,26 +121,38 @@ __global__ void __launch_bounds__(256)
     }
 }
 
-// out[i] = sum_s partial[s * stride + i] in a FIXED order: sixteen lanes per output element, lane l adds the splits l,
-// l + 16, ... in ascending order, then the sixteen sums are added pairwise in a fixed tree (deterministic; one thread
-// per element walked up to 1024 dependent loads -- 90 us per layer at the batch sizes of training)
-__global__ void __launch_bounds__(256)
+// out[i] = sum_s partial[s * stride + i] in a FIXED order: sixteen partial sums per output element (sum l adds the splits
+// l, l + 16, ... in ascending order), added pairwise in a fixed tree (deterministic; one thread per element walked up to
+// 1024 dependent loads -- 90 us per layer at the batch sizes of training)
+__global__ void __launch_bounds__(1024)
     reduce_partials_kernel(const float *__restrict__ partial, int S, int64_t stride, int64_t n, float *__restrict__ out) {
-  const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
-  const int l = threadIdx.x & 15;
+  // A workgroup owns 64 consecutive elements: lane = element (a split row is read as one 256-byte piece per wave), wave w of
+  // the 16 adds the splits w, w + 16, ... in ascending order, and the sixteen sums meet in LDS in the pairwise tree
+  // ((0+8)+(4+12)) + ... of the 16-lane form this replaces (same sums, same order, bit for bit; that form had the sixteen
+  // splits of ONE element in adjacent lanes: every 4-byte read its own cache line, 1.6 TB/s).
+  __shared__ float part[16][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 64 + lane;
   float acc = 0.0f;
   if (i < n)
-    for (int s = l; s < S; s += 16) acc += partial[(size_t)s * stride + i];
-  acc += __shfl_xor(acc, 8, 16);
-  acc += __shfl_xor(acc, 4, 16);
-  acc += __shfl_xor(acc, 2, 16);
-  acc += __shfl_xor(acc, 1, 16);
-  if (i < n && l == 0) out[i] = acc;
+    for (int s = w; s < S; s += 16) acc += partial[(size_t)s * stride + i];
+  part[w][lane] = acc;
+  __syncthreads();
+  if (w == 0 && i < n) {
+    float v[16];
+#pragma unroll
+    for (int l = 0; l < 16; ++l) v[l] = part[l][lane];
+#pragma unroll
+    for (int o = 8; o >= 1; o >>= 1)  // lane l of the old form ends with v[l] + v[l ^ o] at every level: the same pairs
+#pragma unroll
+      for (int l = 0; l < o; ++l) v[l] = v[l] + v[l + o];
+    out[i] = v[0];
+  }
 }
 
 // (train_ops.hip: the sparse pool backward adds its splits through the same kernel)
 void mpx_reduce_partials_launch(const float *partial, int S, int64_t stride, int64_t n, float *out, hipStream_t stream) {
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(n * 16, 256)), dim3(256), 0, stream, partial, S, stride, n, out);
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(n, 64)), dim3(1024), 0, stream, partial, S, stride, n, out);
 }
 
 // dz = dy * act'(y): ReLU -> y > 0; LeakyReLU(0.01) -> y >= 0 ? 1 : 0.01 (sign of the output = sign of the input)
@@ -307,12 +319,12 @@ static int wgrad_run(const char *name, bool x3, const float *dy, int lddy, const
   // laid them out that way, else two launches)
   if (direct) {
   } else if (db == dw + (size_t)N * K) {
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(per * 16, 256)), dim3(256), 0, mpx_s(stream), scratch, S, per, per, dw);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(per, 64)), dim3(1024), 0, mpx_s(stream), scratch, S, per, per, dw);
   } else {
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv((int64_t)N * K * 16, 256)), dim3(256), 0, mpx_s(stream), scratch, S,
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv((int64_t)N * K, 64)), dim3(1024), 0, mpx_s(stream), scratch, S,
                        per, (int64_t)N * K, dw);
     if (db)
-      hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv((int64_t)N * 16, 256)), dim3(256), 0, mpx_s(stream),
+      hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv((int64_t)N, 64)), dim3(1024), 0, mpx_s(stream),
                          scratch + (size_t)N * K, S, per, (int64_t)N, db);
   }
   MPX_LAUNCH_CHECK(name);
