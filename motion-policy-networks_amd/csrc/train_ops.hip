@@ -159,7 +159,9 @@ __global__ void __launch_bounds__(256)
 // non-zeros:
 //   dX[r, k] = act_below'(x[r,k]) * sum_{c : arg[q,c] == r} gz[q,c] * W[c,k]      (mpx_pool_dgrad)
 //   dW[c, k] = sum_q gz[q,c] * x[arg[q,c], k],   db[c] = sum_q gz[q,c]            (mpx_pool_wgrad)
-// fp32 FMAs in a fixed order (deterministic; a different summation order than the dense kernels).
+// fp32 FMAs in an order fixed by the launch (a different summation order than the dense kernels; inside a row of
+// mpx_pool_dgrad the channels are added in the order of an LDS counter's ranks: the hardware's lane order, the same
+// from run to run -- tests/test_gpu_training.py asserts repeated launches bit-identical).
 constexpr int PB_KC = 64;  // columns of a wave's task: one per lane
 __device__ __forceinline__ float pool_gz(float g, float o, int act) {
   return act == MPX_ACT_RELU ? (o > 0.0f ? g : 0.0f) : (act == MPX_ACT_LEAKY ? (o >= 0.0f ? g : 0.01f * g) : g);

@@ -246,6 +246,42 @@ def test_mlp_chain_is_the_per_layer_backward_without_the_activation_passes(poole
     assert all(t.grad is not None and torch.isfinite(t.grad).all() for t in w)
 
 
+@pytest.mark.parametrize("C,N,npoint,nsample", [(1, 300, 40, 128), (64, 200, 24, 128), (5, 90, 17, 32)])
+def test_pack_rows_and_its_scatter_backward_match_torch_indexing(C, N, npoint, nsample):
+    """mpx_pack_rows_ld / mpx_pack_rows_grad_ld (QueryAndGroup over the distinct neighbours, rows at a 16-byte pitch) vs plain
+    torch indexing and its autograd: queries with 0 hits (one row: slot 0), with more than 64 rows (two id windows of the
+    kernel), feature widths of 1 (the first module), 64 (the second, 68-float rows: not a multiple of the wave) and 5."""
+    from mpinets_amd.pointnet2 import _PackRows, segment_offsets
+
+    B = 3
+    rng = np.random.default_rng(C * 100 + N)
+    T = lambda a, dt=torch.float32: torch.tensor(a, dtype=dt, device=dev())
+    xyz, new_xyz = T(rng.normal(size=(B, N, 3))), T(rng.normal(size=(B, npoint, 3)))
+    feat = T(rng.normal(size=(B, N, C))).requires_grad_(True)
+    cnt = rng.integers(0, nsample + 1, size=(B, npoint)).astype(np.int32)
+    cnt[0, 0], cnt[0, 1], cnt[1, 2] = 0, nsample, 1
+    idx = rng.integers(0, N, size=(B, npoint, nsample)).astype(np.int32)
+    cnt_d, idx_d = T(cnt, torch.int32), T(idx, torch.int32)
+    off = segment_offsets(cnt_d)
+    R = int(off[-1])
+    rows = _PackRows.apply(feat, xyz, 3, new_xyz, 3, C, C, idx_d, cnt_d, off, R, (B, N, npoint, nsample))
+    ld = (3 + C + 3) // 4 * 4
+    assert rows.shape == (R, ld)
+    # reference: per query its first max(cnt, 1) slots
+    fr = feat.detach().clone().requires_grad_(True)
+    parts = []
+    for b in range(B):
+        for j in range(npoint):
+            k = torch.as_tensor(idx[b, j, :max(int(cnt[b, j]), 1)].astype(np.int64), device=dev())
+            parts.append(torch.cat((xyz[b, k] - new_xyz[b, j], fr[b, k], torch.zeros(k.numel(), ld - 3 - C, device=dev())), dim=1))
+    ref = torch.cat(parts)
+    assert torch.equal(rows.detach(), ref.detach())
+    g = T(rng.normal(size=(R, ld)))
+    (rows * g).sum().backward()
+    (ref * g).sum().backward()
+    assert (feat.grad - fr.grad).abs().max() <= 1e-5 * max(fr.grad.abs().max().item(), 1.0)  # (atomic adds: order free)
+
+
 @pytest.mark.parametrize("x3", [False, True])
 @pytest.mark.parametrize("M,N,K,act", [(3000, 256, 128, 1), (1000, 64, 64, 1), (515, 200, 68, 2), (700, 130, 20, 0)])
 def test_fused_pool_forward_is_the_two_step_form_bit_for_bit(M, N, K, act, x3):
